@@ -1,0 +1,166 @@
+/*
+ * mojosplat_hip.h -- C ABI of libmojosplat_hip.so, the MI355X (gfx950) backend for the
+ * mojosplat render path: EWA projection -> tile binning/sort -> tile rasteriser.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one custom-op / external call
+ * of the reference (paths relative to the reference repo root):
+ *
+ *   ms_project_gaussians_fwd          op "project_gaussians", mojosplat/kernels/projection.mojo:260-326,
+ *                                     called from mojosplat/projection.py:429-454; and
+ *                                     gsplat.fully_fused_projection, projection.py:381-397
+ *   ms_isect_tiles_count / _emit      gsplat.isect_tiles, mojosplat/binning.py:73-82
+ *   ms_isect_offset_encode            gsplat.isect_offset_encode, mojosplat/binning.py:84
+ *   ms_rasterize_to_pixels_3dgs_fwd   op "rasterize_to_pixels_3dgs_fwd",
+ *                                     mojosplat/kernels/rasterization.mojo:169-240, called from
+ *                                     mojosplat/rasterization.py:169-183; and
+ *                                     gsplat.rasterize_to_pixels, rasterization.py:109-122
+ *   ms_rasterize_to_pixels_3dgs_bwd,  no reference counterpart (reference is forward-only,
+ *   ms_project_gaussians_bwd          render.py:11); gsplat's backward semantics
+ *   ms_render_fwd                     the whole of render_gaussians' device work
+ *                                     (mojosplat/render.py:63-101) in one call
+ *
+ * Conventions (same as the reference's op convention, projection.py:438-454):
+ *   - destination passing: the caller (PyTorch) owns and pre-allocates every buffer,
+ *     including scratch; the library never allocates device memory and keeps no state;
+ *   - all pointers are DEVICE pointers unless a parameter says "host"; tensors are
+ *     contiguous row-major with the layouts written next to each parameter;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); nothing
+ *     here synchronises, so calls can be captured into a hipGraph;
+ *   - every function returns 0 on success or a non-zero ms_status; no C++ exception
+ *     crosses this boundary.  ms_last_error_string() describes the last failure on the
+ *     calling thread.
+ *   - single camera (C = 1), like every wrapper of the reference (projection.py:431,
+ *     rasterization.py:175).
+ */
+#ifndef MOJOSPLAT_HIP_H
+#define MOJOSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_ABI_VERSION 1
+
+typedef enum ms_status {
+    MS_OK = 0,
+    MS_ERR_INVALID_ARG = 1,   /* null pointer, negative size, unsupported channel count ... */
+    MS_ERR_WORKSPACE = 2,     /* workspace too small (ask ms_*_workspace_bytes)           */
+    MS_ERR_TOO_LARGE = 3,     /* tile grid does not fit the binning kernels' LDS budget   */
+    MS_ERR_HIP = 4            /* a HIP runtime call failed; see ms_last_error_string()    */
+} ms_status;
+
+typedef enum ms_color_dtype { MS_COLOR_F32 = 0, MS_COLOR_F16 = 1 } ms_color_dtype;
+
+int ms_version(void);
+const char *ms_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Projection (EWA 3D -> 2D), gsplat semantics.
+ *   in : means3d f32[N,3]; scales f32[N,3] (log-space when scales_are_log != 0, the exp is
+ *        fused; linear otherwise, which is what the reference's kernel receives);
+ *        quats f32[N,4] wxyz (normalised in-kernel); opacities f32[N] or NULL (NULL = no
+ *        opacity cull / no opacity-aware extent); viewmat f32[16] row-major world->camera
+ *        IN DEVICE MEMORY; pinhole fx fy cx cy; image W H; eps2d (0.3), near, far,
+ *        radius_clip (0).
+ *   out: means2d f32[N,2]; conics f32[N,3] (a,b,c of the inverse blurred 2x2 covariance);
+ *        depths f32[N]; radii i32[N,2].  Culled Gaussians get radii = 0 and zeros elsewhere.
+ * ------------------------------------------------------------------------------------- */
+int ms_project_gaussians_fwd(int64_t N, const float *means3d, const float *scales,
+                             int scales_are_log, const float *quats, const float *opacities,
+                             const float *viewmat, float fx, float fy, float cx, float cy,
+                             int W, int H, float eps2d, float near_plane, float far_plane,
+                             float radius_clip, float *means2d, float *conics, float *depths,
+                             int32_t *radii, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Binning.  Two calls around the one unavoidable size hand-off (the number of
+ * intersections M is data dependent), exactly where gsplat.isect_tiles has its own.
+ *
+ * ms_isect_tiles_count: per-tile counts -> exclusive offsets.
+ *   in : means2d f32[N,2], radii i32[N,2]; tile_size; tile grid tile_w x tile_h;
+ *        [row_begin,row_end) restricts binning to a band of tile rows (multi-GPU
+ *        sharding; pass 0,tile_h for the whole image);
+ *        workspace of ms_isect_workspace_bytes(...) bytes.
+ *   out: tile_ranges i32[tile_h,tile_w,2] = [start,end) into the sorted intersection list
+ *        (tiles outside the band get empty ranges);
+ *        tiles_per_gauss i32[N] or NULL;
+ *        isect_info i64[4] (device): {M, largest per-tile count, #tiles needing the
+ *        large-tile sort, #tiles needing the merge fallback}.  Copy it to the host to
+ *        size flatten_ids and to drive ms_isect_tiles_emit.
+ *
+ * ms_isect_tiles_emit: scatter (depth,id) keys into their tile segments and depth-sort
+ * every segment.  Order inside a tile: ascending (float bits of depth, Gaussian index) --
+ * identical to a stable radix sort of (tile<<32 | depth_bits) keys emitted in Gaussian
+ * order, i.e. gsplat.isect_tiles(sort=True).
+ *   in : as above plus depths f32[N]; the SAME workspace the count call filled;
+ *        host_info = the 4 values of isect_info as read by the host; M = host_info[0].
+ *   out: flatten_ids i32[M]; isect_ids i64[M] or NULL (sorted keys (tile<<32)|depth_bits).
+ *        sort_keys u64[M] and sort_tmp u64[M or 0] are caller-allocated scratch
+ *        (sort_tmp is only touched when host_info[3] > 0).
+ * ------------------------------------------------------------------------------------- */
+size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h);
+
+int ms_isect_tiles_count(int64_t N, const float *means2d, const int32_t *radii, int tile_size,
+                         int tile_w, int tile_h, int row_begin, int row_end, void *workspace,
+                         size_t workspace_bytes, int32_t *tiles_per_gauss, int32_t *tile_ranges,
+                         int64_t *isect_info, void *stream);
+
+int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
+                        const float *depths, int tile_size, int tile_w, int tile_h,
+                        int row_begin, int row_end, void *workspace, size_t workspace_bytes,
+                        const int32_t *tile_ranges, const int64_t *host_info, uint64_t *sort_keys,
+                        uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
+                        void *stream);
+
+/* gsplat.isect_offset_encode: from SORTED keys (tile<<32|depth_bits) to per-tile start
+ * offsets i32[tile_h*tile_w] (empty tiles inherit the next start; trailing tiles get M). */
+int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_w, int tile_h,
+                           int32_t *offsets, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Rasteriser forward: per tile, front-to-back alpha compositing of its sorted list.
+ *   in : means2d f32[N,2], conics f32[N,3], colors [N,CDIM] (f32 or f16, CDIM 1..32),
+ *        opacities f32[N], backgrounds f32[CDIM] or NULL, tile_ranges i32[th,tw,2],
+ *        flatten_ids i32[M].
+ *   out: render_colors f32[H,W,CDIM]; render_alphas f32[H,W] or NULL; last_ids i32[H,W]
+ *        or NULL (index into flatten_ids of the last contributing intersection).
+ * ------------------------------------------------------------------------------------- */
+int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float *means2d,
+                                    const float *conics, const void *colors, int color_dtype,
+                                    int CDIM, const float *opacities, const float *backgrounds,
+                                    int W, int H, int tile_size, const int32_t *tile_ranges,
+                                    const int32_t *flatten_ids, float *render_colors,
+                                    float *render_alphas, int32_t *last_ids, void *stream);
+
+/* Rasteriser backward (gsplat rasterize_to_pixels backward semantics, absgrad off).
+ *   in : forward inputs + render_alphas, last_ids from the forward,
+ *        v_render_colors f32[H,W,CDIM], v_render_alphas f32[H,W] or NULL.
+ *   out: v_means2d f32[N,2], v_conics f32[N,3], v_colors f32[N,CDIM], v_opacities f32[N];
+ *        ACCUMULATED INTO (caller zero-fills).                                           */
+int ms_rasterize_to_pixels_3dgs_bwd(int64_t N, int64_t M, const float *means2d,
+                                    const float *conics, const float *colors, int CDIM,
+                                    const float *opacities, const float *backgrounds, int W,
+                                    int H, int tile_size, const int32_t *tile_ranges,
+                                    const int32_t *flatten_ids, const float *render_alphas,
+                                    const int32_t *last_ids, const float *v_render_colors,
+                                    const float *v_render_alphas, float *v_means2d,
+                                    float *v_conics, float *v_colors, float *v_opacities,
+                                    void *stream);
+
+/* Projection backward: gradients of (means2d, conics, depths) w.r.t. means3d, scales
+ * (w.r.t. the log-scales when scales_are_log), quats.  Culled Gaussians get zero grads.
+ *   out: v_means3d f32[N,3], v_scales f32[N,3], v_quats f32[N,4] (overwritten).          */
+int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scales,
+                             int scales_are_log, const float *quats, const float *viewmat,
+                             float fx, float fy, float cx, float cy, int W, int H, float eps2d,
+                             const int32_t *radii, const float *v_means2d,
+                             const float *v_conics, const float *v_depths, float *v_means3d,
+                             float *v_scales, float *v_quats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOJOSPLAT_HIP_H */

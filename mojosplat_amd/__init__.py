@@ -1,0 +1,15 @@
+"""mojosplat_amd -- MI355X (gfx950) backend for the mojosplat 3D-Gaussian-splatting render path.
+
+Public surface = the reference's (mojosplat/render.py, projection.py, binning.py,
+rasterization.py, utils.py): ``render_gaussians``, ``Camera``, ``project_gaussians``,
+``bin_gaussians_to_tiles``, ``rasterize_gaussians``, each with a ``backend=`` switch that gains
+``"hip"``.  Importing this package needs neither a GPU nor the built library.
+"""
+from .utils import Camera, look_at
+from .projection import project_gaussians
+from .binning import bin_gaussians_to_tiles
+from .rasterization import rasterize_gaussians
+from .render import render_gaussians, TILE_SIZE
+
+__all__ = ["Camera", "look_at", "project_gaussians", "bin_gaussians_to_tiles",
+           "rasterize_gaussians", "render_gaussians", "TILE_SIZE"]

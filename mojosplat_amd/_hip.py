@@ -1,0 +1,122 @@
+"""ctypes binding of libmojosplat_hip.so (the C ABI declared in include/mojosplat_hip.h).
+
+This replaces the reference's plugin mechanism -- ``CustomOpLibrary(kernels_dir)`` created at
+import time (reference mojosplat/projection.py:12-13, rasterization.py:9-10).  Differences by
+design: the library is loaded lazily on the first ``backend="hip"`` call (so importing the
+package works on a box with no GPU), it is a prebuilt gfx950 shared object rather than a
+JIT-specialised kernel per (N, W, H, M) (projection.py:429-436, rasterization.py:169-179),
+and a missing library or GPU is a hard error: there is no CPU fallback behind ``"hip"``.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmojosplat_hip.so")
+_lib = None
+
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); mirrors include/mojosplat_hip.h one to one
+_SIGNATURES = {
+    "ms_version": (c_int, []),
+    "ms_last_error_string": (ctypes.c_char_p, []),
+    "ms_project_gaussians_fwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_float, c_float, c_float, c_float, c_int, c_int,
+                                         c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    "ms_isect_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "ms_isect_tiles_count": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ms_isect_tiles_emit": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
+    "ms_isect_offset_encode": (c_int, [c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ms_rasterize_to_pixels_3dgs_fwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                                c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
+}
+
+# entry points added after ABI v1's first cut; bound when present
+_OPTIONAL = {
+    "ms_rasterize_to_pixels_3dgs_bwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                                c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ms_project_gaussians_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_float, c_float, c_float, c_float, c_int, c_int, c_float,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
+    "ms_render_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load and type the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipBackendError(
+            f"{_LIB_PATH} not found: build it with `python -m mojosplat_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950). backend='hip' has no fallback.")
+    L = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the ABI is incomplete
+        fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _OPTIONAL.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+    if L.ms_version() != ABI_VERSION:
+        raise HipBackendError(f"ABI mismatch: library {L.ms_version()} != binding {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def lib():
+    """The library, for launching work: additionally requires a visible GPU."""
+    L = load()
+    if not torch.cuda.is_available():
+        raise HipBackendError("backend='hip' needs a ROCm GPU (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback for this backend")
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().ms_last_error_string().decode("utf-8", "replace")
+        raise HipBackendError(f"{what or 'libmojosplat_hip'} failed (status {rc}): {msg}")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors, what="input"):
+    for t in tensors:
+        if t is not None and not (isinstance(t, torch.Tensor) and t.is_cuda):
+            raise ValueError(f"backend='hip': every {what} must be a CUDA/ROCm tensor")
+
+
+def f32c(t):
+    """contiguous fp32 view/copy (no copy when already so)"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

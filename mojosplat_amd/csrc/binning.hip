@@ -1,0 +1,540 @@
+// Tile binning + per-tile depth sort for gfx950.
+//
+// Replaces gsplat.isect_tiles / isect_offset_encode as the reference calls them
+// (mojosplat/binning.py:73-84) and the [start,end) conversion at binning.py:88-100.
+// Result contract (bit-exact): intersections ordered by (tile id, float bits of depth,
+// Gaussian index) -- what a stable radix sort of (tile<<32 | depth_bits) keys emitted in
+// Gaussian order yields.
+//
+// MI355X design: instead of a 6-pass global LSD radix sort over 64-bit keys (24 B x M of HBM
+// traffic per pass), the tile id is resolved by ONE bucket pass whose histograms live in LDS
+// (the tile grid of a 1080p frame is 8 160 counters = 32 KB, a 4K frame 130 KB -- both fit the
+// 160 KB LDS of a CU), and depth order is established inside each tile segment by an LDS
+// bitonic sort on (depth_bits<<32 | gaussian) keys.  No global atomics anywhere: LDS atomics
+// only, so the HBM side sees M x 8 B written once, read once, and M x 4 B of ids written.
+//
+//   k_isect_hist      G workgroups, each histograms a contiguous chunk of Gaussians into LDS
+//   k_tile_scan_wg    per tile: exclusive prefix over the G partial counts (16 waves split G)
+//   k_tile_scan_total one workgroup: exclusive scan over tiles -> tile_ranges, M, work lists
+//   k_isect_scatter   same chunks; LDS cursors hand out slots inside each tile segment
+//   k_tile_sort_small one workgroup per tile with <= 2048 entries (16 KB LDS)
+//   k_tile_sort_large work list of tiles with <= 16384 entries (128 KB LDS)
+//   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
+#include "ms_common.hpp"
+
+namespace {
+
+constexpr int kHistThreads = 1024;
+constexpr int kMaxG = 512;
+constexpr int kSmallCap = 2048;    // entries sorted by a 256-thread workgroup in 16 KB LDS
+constexpr int kLargeCap = 16384;   // entries sorted by a 1024-thread workgroup in 128 KB LDS
+constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
+constexpr size_t kMaxLds = 160 * 1024;
+
+struct Grid {
+    int ts, tw, th, row_begin, row_end;
+};
+
+__device__ __forceinline__ int clampi(float v, int lo, int hi) {
+    if (!(v > (float)lo)) return lo;  // also NaN
+    if (v >= (float)hi) return hi;
+    return (int)v;
+}
+
+// gsplat tile bounding box: min inclusive, max exclusive, clamped to the grid, then to the band
+__device__ __forceinline__ void tile_bbox(float2 m, int2 r, const Grid &g, int &x0, int &x1,
+                                          int &y0, int &y1) {
+    const float fts = (float)g.ts;
+    const float trx = (float)r.x / fts, try_ = (float)r.y / fts;
+    const float tx = m.x / fts, ty = m.y / fts;
+    x0 = clampi(floorf(tx - trx), 0, g.tw);
+    x1 = clampi(ceilf(tx + trx), 0, g.tw);
+    y0 = clampi(floorf(ty - try_), 0, g.th);
+    y1 = clampi(ceilf(ty + try_), 0, g.th);
+    y0 = max(y0, g.row_begin);
+    y1 = min(y1, g.row_end);
+    y1 = max(y1, y0);
+}
+
+// Walk every (Gaussian, tile) pair of one chunk; F(local_tile, gaussian_index, lane_payload).
+// Small boxes are walked by their own lane, big ones by the whole wave.
+template <class F>
+__device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const float *means2d,
+                                               const int32_t *radii, const Grid &g,
+                                               int32_t *tiles_per_gauss, F &&f) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = i0; base < i1; base += kHistThreads) {
+        const int64_t i = base + threadIdx.x;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
+        if (i < i1) {
+            const int2 r = reinterpret_cast<const int2 *>(radii)[i];
+            if (r.x > 0 && r.y > 0) {
+                const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+                tile_bbox(m, r, g, x0, x1, y0, y1);
+                n = (x1 - x0) * (y1 - y0);
+            }
+            if (tiles_per_gauss) tiles_per_gauss[i] = n;
+        }
+        const bool big = n > kCoopThreshold;
+        if (n > 0 && !big) {
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) f((y - g.row_begin) * g.tw + x, i);
+        }
+        unsigned long long bigmask = __ballot(big);
+        while (bigmask) {
+            const int src = __ffsll((long long)bigmask) - 1;
+            bigmask &= bigmask - 1;
+            const int bx0 = __shfl(x0, src), bx1 = __shfl(x1, src);
+            const int by0 = __shfl(y0, src), by1 = __shfl(y1, src);
+            const int64_t bi = base + (threadIdx.x & ~63) + src;
+            const int w = bx1 - bx0, cnt = w * (by1 - by0);
+            for (int k = lane; k < cnt; k += 64) {
+                const int y = by0 + k / w, x = bx0 + k % w;
+                f((y - g.row_begin) * g.tw + x, bi);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kHistThreads) void k_isect_hist(
+    int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii, Grid g,
+    int64_t chunk, uint32_t *__restrict__ hist, int32_t *__restrict__ tiles_per_gauss) {
+    extern __shared__ uint32_t s_cnt[];
+    const int T_local = (g.row_end - g.row_begin) * g.tw;
+    for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
+    for_each_isect(i0, i1, means2d, radii, g, tiles_per_gauss,
+                   [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
+    __syncthreads();
+    uint32_t *row = hist + (size_t)blockIdx.x * T_local;
+    for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
+}
+
+// hist[g][t] -> exclusive prefix over g (in place); tile_count[t] = sum over g.
+__global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
+                                                       uint32_t *__restrict__ hist,
+                                                       uint32_t *__restrict__ tile_count) {
+    __shared__ uint32_t s_part[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const int per = (G + 15) / 16;
+    const int g0 = w * per, g1 = min(G, g0 + per);
+    uint32_t v[kMaxG / 16];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxG / 16; ++k) {
+        const int gg = g0 + k;
+        v[k] = (gg < g1 && t < T_local) ? hist[(size_t)gg * T_local + t] : 0u;
+        sum += v[k];
+    }
+    s_part[w][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) {
+        const uint32_t p = s_part[ww][lane];
+        if (ww < w) run += p;
+        total += p;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxG / 16; ++k) {
+        const int gg = g0 + k;
+        if (gg < g1 && t < T_local) {
+            hist[(size_t)gg * T_local + t] = run;
+            run += v[k];
+        }
+    }
+    if (w == 0 && t < T_local) tile_count[t] = total;
+}
+
+// One workgroup: exclusive scan of the per-tile counts over the FULL grid (tiles outside
+// the band count 0), tile_ranges, totals and the work lists of over-sized tiles.
+__global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t *__restrict__ tile_count,
+                                                          int32_t *__restrict__ tile_ranges,
+                                                          int32_t *__restrict__ large_list,
+                                                          int32_t *__restrict__ xl_list,
+                                                          int64_t *__restrict__ info) {
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned int s_nlarge, s_nxl, s_max;
+    const int T = g.tw * g.th;
+    const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
+    const int K = (T + 1023) / 1024;
+    const int t0 = threadIdx.x * K, t1 = min(T, t0 + K);
+    if (threadIdx.x == 0) { s_nlarge = 0; s_nxl = 0; s_max = 0; }
+    unsigned long long sum = 0;
+    for (int t = t0; t < t1; ++t)
+        if (t >= band0 && t < band1) sum += tile_count[t - band0];
+    // block exclusive scan of `sum`
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    unsigned long long wave_base = 0, grand = 0;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) {
+        if (ww < w) wave_base += s_wave[ww];
+        grand += s_wave[ww];
+    }
+    unsigned long long run = wave_base + incl - sum;
+    unsigned int lmax = 0;
+    for (int t = t0; t < t1; ++t) {
+        const unsigned int c = (t >= band0 && t < band1) ? tile_count[t - band0] : 0u;
+        // offsets saturate at INT32_MAX; the host rejects M > INT32_MAX before emitting
+        const unsigned long long e = run + c;
+        tile_ranges[2 * t] = (int32_t)min(run, 0x7fffffffull);
+        tile_ranges[2 * t + 1] = (int32_t)min(e, 0x7fffffffull);
+        run = e;
+        lmax = max(lmax, c);
+        if (c > (unsigned)kLargeCap) xl_list[atomicAdd(&s_nxl, 1u)] = t;
+        else if (c > (unsigned)kSmallCap) large_list[atomicAdd(&s_nlarge, 1u)] = t;
+    }
+    atomicMax(&s_max, lmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[0] = (int64_t)grand;
+        info[1] = (int64_t)s_max;
+        info[2] = (int64_t)s_nlarge;
+        info[3] = (int64_t)s_nxl;
+    }
+}
+
+__global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
+    int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    const float *__restrict__ depths, Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
+    const int32_t *__restrict__ tile_ranges, int64_t M, uint64_t *__restrict__ keys) {
+    extern __shared__ uint32_t s_cur[];
+    const int T_local = (g.row_end - g.row_begin) * g.tw;
+    const int band0 = g.row_begin * g.tw;
+    const uint32_t *row = hist + (size_t)blockIdx.x * T_local;
+    for (int t = threadIdx.x; t < T_local; t += kHistThreads)
+        s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
+    for_each_isect(i0, i1, means2d, radii, g, nullptr, [&](int t, int64_t i) {
+        const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+        const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
+        if ((int64_t)slot < M) keys[slot] = key;
+    });
+}
+
+// ---- LDS bitonic sort of 64-bit keys -------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *s, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < (P >> 1); i += THREADS) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const uint64_t a = s[lo], b = s[hi];
+                if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+template <int THREADS>
+__device__ __forceinline__ void sort_segment_lds(uint64_t *s, const uint64_t *__restrict__ keys_in,
+                                                 int start, int n, int tile,
+                                                 int32_t *__restrict__ flatten_ids,
+                                                 int64_t *__restrict__ isect_ids,
+                                                 uint64_t *__restrict__ keys_out) {
+    const int P = max(2, next_pow2(n));
+    for (int i = threadIdx.x; i < P; i += THREADS) s[i] = i < n ? keys_in[start + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds<THREADS>(s, P);
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const uint64_t k = s[i];
+        if (flatten_ids) flatten_ids[start + i] = (int32_t)(uint32_t)k;
+        if (isect_ids) isect_ids[start + i] = ((int64_t)tile << 32) | (int64_t)(k >> 32);
+        if (keys_out) keys_out[start + i] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restrict__ tile_ranges,
+                                                         const uint64_t *__restrict__ keys,
+                                                         int32_t *__restrict__ flatten_ids,
+                                                         int64_t *__restrict__ isect_ids) {
+    __shared__ uint64_t s[kSmallCap];
+    const int tile = blockIdx.x;
+    const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+    if (n <= 0 || n > kSmallCap) return;
+    sort_segment_lds<256>(s, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
+}
+
+__global__ __launch_bounds__(1024) void k_tile_sort_large(const int32_t *__restrict__ large_list,
+                                                          const int32_t *__restrict__ tile_ranges,
+                                                          const uint64_t *__restrict__ keys,
+                                                          int32_t *__restrict__ flatten_ids,
+                                                          int64_t *__restrict__ isect_ids) {
+    extern __shared__ uint64_t s_large[];
+    const int tile = large_list[blockIdx.x];
+    const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+    sort_segment_lds<1024>(s_large, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
+}
+
+// XL tiles: sort runs of kLargeCap in place ...
+__global__ __launch_bounds__(1024) void k_xl_chunk_sort(const int32_t *__restrict__ xl_list,
+                                                        const int32_t *__restrict__ tile_ranges,
+                                                        uint64_t *__restrict__ keys) {
+    extern __shared__ uint64_t s_large[];
+    const int tile = xl_list[blockIdx.y];
+    const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+    const int c0 = blockIdx.x * kLargeCap;
+    if (c0 >= n) return;
+    const int cn = min(kLargeCap, n - c0);
+    sort_segment_lds<1024>(s_large, keys, start + c0, cn, tile, nullptr, nullptr, keys);
+}
+
+// ... then merge neighbouring sorted runs of length L.  Keys inside a tile are distinct
+// (the Gaussian index is part of the key), so rank = own position + lower_bound in partner.
+__global__ __launch_bounds__(256) void k_xl_merge(const int32_t *__restrict__ xl_list,
+                                                  const int32_t *__restrict__ tile_ranges,
+                                                  const uint64_t *__restrict__ src,
+                                                  uint64_t *__restrict__ dst, int L) {
+    const int tile = xl_list[blockIdx.y];
+    const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint64_t key = src[start + e];
+    const int run = e / L, pos = e - run * L;
+    const int pair_base = (run & ~1) * L;
+    const int pb = (run ^ 1) * L;            // partner run begin
+    int cnt = 0;
+    if (pb < n) {
+        const int pn = min(L, n - pb);
+        int lo = 0, hi = pn;                 // lower_bound(partner, key)
+        const uint64_t *p = src + start + pb;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (p[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        cnt = lo;
+    }
+    dst[start + pair_base + pos + cnt] = key;
+}
+
+__global__ __launch_bounds__(256) void k_xl_extract(const int32_t *__restrict__ xl_list,
+                                                    const int32_t *__restrict__ tile_ranges,
+                                                    const uint64_t *__restrict__ src,
+                                                    int32_t *__restrict__ flatten_ids,
+                                                    int64_t *__restrict__ isect_ids) {
+    const int tile = xl_list[blockIdx.y];
+    const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint64_t k = src[start + e];
+    flatten_ids[start + e] = (int32_t)(uint32_t)k;
+    if (isect_ids) isect_ids[start + e] = ((int64_t)tile << 32) | (int64_t)(k >> 32);
+}
+
+__global__ __launch_bounds__(256) void k_offset_encode(int64_t M, const int64_t *__restrict__ ids,
+                                                       int T, int32_t *__restrict__ offsets) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M) return;
+    const int cur = (int)(ids[idx] >> 32);
+    if (idx == 0)
+        for (int t = 0; t <= cur && t < T; ++t) offsets[t] = 0;
+    else {
+        const int prev = (int)(ids[idx - 1] >> 32);
+        for (int t = prev + 1; t <= cur && t < T; ++t) offsets[t] = (int32_t)idx;
+    }
+    if (idx == M - 1)
+        for (int t = cur + 1; t < T; ++t) offsets[t] = (int32_t)M;
+}
+
+// ---- host side ----------------------------------------------------------------------
+struct Plan {
+    int G;
+    int64_t chunk;
+    int T, T_local;
+    size_t lds_bytes;
+    size_t off_hist, off_count, off_large, off_xl, total;
+};
+
+bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
+    p.T = tw * th;
+    p.T_local = (row_end - row_begin) * tw;
+    p.lds_bytes = (size_t)p.T_local * 4;
+    int64_t G = ms::ceil_div(N > 0 ? N : 1, 2048);
+    G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
+    if (p.lds_bytes > 64 * 1024 && G > 256) G = 256;
+    p.chunk = ms::ceil_div(N > 0 ? N : 1, G);
+    p.G = (int)ms::ceil_div(N > 0 ? N : 1, p.chunk);
+    // workspace carve-up is sized for the FULL grid so one buffer serves any band
+    size_t o = 0;
+    p.off_hist = o;   o += ms::align_up((size_t)kMaxG * p.T * 4, 256);
+    p.off_count = o;  o += ms::align_up((size_t)p.T * 4, 256);
+    p.off_large = o;  o += ms::align_up((size_t)p.T * 4, 256);
+    p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
+    p.total = o;
+    return p.lds_bytes <= kMaxLds;
+}
+
+int check_grid(int tile_size, int tw, int th, int row_begin, int row_end) {
+    MS_REQUIRE(tile_size > 0 && tw > 0 && th > 0, MS_ERR_INVALID_ARG, "isect: bad tile grid");
+    MS_REQUIRE((int64_t)tw * th < (1ll << 30), MS_ERR_TOO_LARGE, "isect: tile grid too large");
+    MS_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= th, MS_ERR_INVALID_ARG,
+               "isect: bad row band [%d,%d) of %d", row_begin, row_end, th);
+    return MS_OK;
+}
+
+// raise a kernel's dynamic-LDS ceiling to the full 160 KB once per process
+template <class K>
+int allow_big_lds(K kernel) {
+    static const void *seen[8];
+    static int n_seen = 0;
+    const void *f = reinterpret_cast<const void *>(kernel);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i] == f) return MS_OK;
+    MS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    if (n_seen < 8) seen[n_seen++] = f;
+    return MS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h) {
+    Plan p;
+    if (tile_w <= 0 || tile_h <= 0 || (int64_t)tile_w * tile_h >= (1ll << 30)) return 0;
+    make_plan(N, tile_w, tile_h, 0, tile_h, p);
+    return p.total;
+}
+
+extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32_t *radii,
+                                    int tile_size, int tile_w, int tile_h, int row_begin,
+                                    int row_end, void *workspace, size_t workspace_bytes,
+                                    int32_t *tiles_per_gauss, int32_t *tile_ranges,
+                                    int64_t *isect_info, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(N >= 0, MS_ERR_INVALID_ARG, "isect_count: N < 0");
+    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
+    MS_REQUIRE(workspace && tile_ranges && isect_info && (N == 0 || (means2d && radii)),
+               MS_ERR_INVALID_ARG, "isect_count: null pointer");
+    MS_REQUIRE(((uintptr_t)means2d & 7) == 0 && ((uintptr_t)radii & 7) == 0, MS_ERR_INVALID_ARG,
+               "isect_count: means2d/radii must be 8-byte aligned");
+    Plan p;
+    const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
+    MS_REQUIRE(fits, MS_ERR_TOO_LARGE,
+               "isect_count: band of %d tiles needs %zu B of LDS (max %zu); bin in row bands",
+               p.T_local, p.lds_bytes, kMaxLds);
+    MS_REQUIRE(workspace_bytes >= p.total, MS_ERR_WORKSPACE, "isect_count: workspace %zu < %zu",
+               workspace_bytes, p.total);
+    char *ws = (char *)workspace;
+    uint32_t *hist = (uint32_t *)(ws + p.off_hist);
+    uint32_t *count = (uint32_t *)(ws + p.off_count);
+    int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
+    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+
+    if (p.T_local > 0) {
+        if (p.lds_bytes > 48 * 1024)
+            if (int rc = allow_big_lds(k_isect_hist)) return rc;
+        hipLaunchKernelGGL(k_isect_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d,
+                           radii, g, p.chunk, hist, tiles_per_gauss);
+        MS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0,
+                           stream, p.G, p.T_local, hist, count);
+        MS_LAUNCH_CHECK();
+    } else if (tiles_per_gauss && N > 0) {
+        MS_HIP(hipMemsetAsync(tiles_per_gauss, 0, (size_t)N * 4, stream));
+    }
+    hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, large,
+                       xl, isect_info);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
+                                   const float *depths, int tile_size, int tile_w, int tile_h,
+                                   int row_begin, int row_end, void *workspace,
+                                   size_t workspace_bytes, const int32_t *tile_ranges,
+                                   const int64_t *host_info, uint64_t *sort_keys,
+                                   uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
+                                   void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(N >= 0 && host_info, MS_ERR_INVALID_ARG, "isect_emit: bad N / host_info");
+    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
+    const int64_t M = host_info[0], max_count = host_info[1], n_large = host_info[2], n_xl = host_info[3];
+    MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE,
+               "isect_emit: %lld intersections do not fit int32 indices", (long long)M);
+    if (M == 0) return MS_OK;
+    MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
+               MS_ERR_INVALID_ARG, "isect_emit: null pointer");
+    MS_REQUIRE(n_xl == 0 || sort_tmp, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
+    Plan p;
+    const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
+    MS_REQUIRE(fits, MS_ERR_TOO_LARGE, "isect_emit: band too large for LDS");
+    MS_REQUIRE(workspace_bytes >= p.total, MS_ERR_WORKSPACE, "isect_emit: workspace %zu < %zu",
+               workspace_bytes, p.total);
+    char *ws = (char *)workspace;
+    const uint32_t *hist = (const uint32_t *)(ws + p.off_hist);
+    const int32_t *large = (const int32_t *)(ws + p.off_large), *xl = (const int32_t *)(ws + p.off_xl);
+    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+
+    if (p.lds_bytes > 48 * 1024)
+        if (int rc = allow_big_lds(k_isect_scatter)) return rc;
+    hipLaunchKernelGGL(k_isect_scatter, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d,
+                       radii, depths, g, p.chunk, hist, tile_ranges, M, sort_keys);
+    MS_LAUNCH_CHECK();
+
+    hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
+                       flatten_ids, isect_ids);
+    MS_LAUNCH_CHECK();
+    const size_t large_lds = (size_t)kLargeCap * 8;
+    if (n_large > 0) {
+        if (int rc = allow_big_lds(k_tile_sort_large)) return rc;
+        hipLaunchKernelGGL(k_tile_sort_large, dim3((unsigned)n_large), dim3(1024), large_lds, stream,
+                           large, tile_ranges, sort_keys, flatten_ids, isect_ids);
+        MS_LAUNCH_CHECK();
+    }
+    if (n_xl > 0) {
+        if (int rc = allow_big_lds(k_xl_chunk_sort)) return rc;
+        const unsigned chunks = (unsigned)ms::ceil_div(max_count, kLargeCap);
+        hipLaunchKernelGGL(k_xl_chunk_sort, dim3(chunks, (unsigned)n_xl), dim3(1024), large_lds, stream,
+                           xl, tile_ranges, sort_keys);
+        MS_LAUNCH_CHECK();
+        uint64_t *src = sort_keys, *dst = sort_tmp;
+        const unsigned eblocks = (unsigned)ms::ceil_div(max_count, 256);
+        for (int64_t L = kLargeCap; L < max_count; L <<= 1) {
+            hipLaunchKernelGGL(k_xl_merge, dim3(eblocks, (unsigned)n_xl), dim3(256), 0, stream, xl,
+                               tile_ranges, src, dst, (int)L);
+            MS_LAUNCH_CHECK();
+            uint64_t *t = src; src = dst; dst = t;
+        }
+        hipLaunchKernelGGL(k_xl_extract, dim3(eblocks, (unsigned)n_xl), dim3(256), 0, stream, xl,
+                           tile_ranges, src, flatten_ids, isect_ids);
+        MS_LAUNCH_CHECK();
+    }
+    return MS_OK;
+}
+
+extern "C" int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_w,
+                                      int tile_h, int32_t *offsets, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(M >= 0 && tile_w > 0 && tile_h > 0 && offsets, MS_ERR_INVALID_ARG,
+               "offset_encode: bad argument");
+    MS_REQUIRE(M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "offset_encode: M does not fit int32");
+    const int T = tile_w * tile_h;
+    if (M == 0) {
+        MS_HIP(hipMemsetAsync(offsets, 0, (size_t)T * 4, stream));
+        return MS_OK;
+    }
+    MS_REQUIRE(isect_ids_sorted, MS_ERR_INVALID_ARG, "offset_encode: null ids");
+    hipLaunchKernelGGL(k_offset_encode, dim3((unsigned)ms::ceil_div(M, 256)), dim3(256), 0, stream, M,
+                       isect_ids_sorted, T, offsets);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}

@@ -1,0 +1,57 @@
+"""Build libmojosplat_hip.so for gfx950 with hipcc (in-tree, no torch, no cmake).
+
+    python -m mojosplat_amd.csrc.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels with the tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["api.hip", "project.hip", "binning.hip", "rasterize.hip", "rasterize_bwd.hip",
+           "project_bwd.hip", "pipeline.hip"]
+HEADERS = ["ms_common.hpp", os.path.join("..", "..", "include", "mojosplat_hip.h")]
+LIB = os.path.join(HERE, "libmojosplat_hip.so")
+ARCH = "gfx950"
+
+
+def _sources():
+    return [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = _sources() + [os.path.join(HERE, h) for h in HEADERS] + \
+        [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in _sources():
+        obj = os.path.splitext(src)[0] + ".o"
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+               "-Wall", "-Wno-unused-function"]
+        if verbose:
+            cmd += ["-Rpass-analysis=kernel-resource-usage"]
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed for: {failed}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

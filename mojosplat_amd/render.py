@@ -1,0 +1,64 @@
+"""Orchestrator: project -> bin/sort -> rasterise.
+
+Drop-in for ``mojosplat.render.render_gaussians`` (reference mojosplat/render.py:11-103): same
+signature and checks -- non-CUDA inputs and a background/colour channel mismatch raise
+ValueError (render.py:44-46, 57-58), opacities must be (N,) (render.py:60), an empty
+intersection list returns a ZEROS image, not the background (render.py:73-76), ``sh_degree``
+only slices channels (render.py:82-87).  The reference default backend is "mojo"
+(render.py:23); here it is "hip".
+"""
+from typing import Optional
+
+import torch
+
+from .binning import bin_gaussians_to_tiles
+from .projection import project_gaussians
+from .rasterization import rasterize_gaussians
+from .utils import Camera
+
+TILE_SIZE = 16
+
+
+@torch.no_grad()
+def render_gaussians(
+    means3d: torch.Tensor,    # (N, 3) world coordinates
+    scales: torch.Tensor,     # (N, 3) log-space scales
+    quats: torch.Tensor,      # (N, 4) w, x, y, z
+    opacities: torch.Tensor,  # (N,) activated opacities
+    features: torch.Tensor,   # (N, C) colours
+    camera: Camera,
+    sh_degree: Optional[int] = None,
+    background_color: Optional[torch.Tensor] = None,
+    tile_size: int = TILE_SIZE,
+    backend: str = "hip",
+) -> torch.Tensor:
+    required = [means3d, scales, quats, opacities, features]
+    if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in required):
+        raise ValueError("All input gaussian tensors must be CUDA tensors.")
+
+    num_channels = features.shape[-1]
+    if background_color is None:
+        bg = torch.zeros(num_channels, device=means3d.device, dtype=features.dtype)
+    elif not isinstance(background_color, torch.Tensor):
+        bg = torch.tensor(background_color, device=means3d.device, dtype=features.dtype)
+    else:
+        bg = background_color.to(device=means3d.device, dtype=features.dtype)
+    if bg.shape[0] != num_channels:
+        raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color "
+                         f"channels ({num_channels})")
+    assert opacities.shape == (means3d.shape[0],)
+
+    means2d, conics, depths, radii = project_gaussians(means3d, scales, quats, opacities, camera,
+                                                       backend=backend)
+    sorted_ids, tile_ranges = bin_gaussians_to_tiles(means2d, radii, depths, camera.H, camera.W,
+                                                     tile_size, backend=backend)
+    if sorted_ids.numel() == 0:
+        return torch.zeros(camera.H, camera.W, num_channels, device=means3d.device,
+                           dtype=features.dtype)
+
+    colors = features
+    if sh_degree is not None and features.shape[-1] > 3:
+        colors = features[..., :3]  # same placeholder as the reference (render.py:82-87)
+
+    return rasterize_gaussians(means2d, conics, colors, opacities, bg, tile_ranges, sorted_ids,
+                               camera, tile_size=tile_size, backend=backend)

@@ -1,0 +1,138 @@
+"""CPU: host-side logic -- the API mirror, the torch backends, error behaviour, and that the
+C-ABI library loads and exports every symbol include/mojosplat_hip.h declares (no compute)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mojosplat_amd as ms
+import oracle
+from helpers import (camera_from_golden, golden_files, load_golden, np_, oracle_project, proj_scene,
+                     raster_scene, simple_camera)
+from mojosplat_amd import _hip
+from mojosplat_amd.scenes import randscene_v1
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_camera_matches_reference_layout():
+    R = torch.tensor([[0.0, 1, 0], [1, 0, 0], [0, 0, -1]])
+    T = torch.tensor([1.0, 2.0, 3.0])
+    cam = ms.Camera(R=R, T=T, H=48, W=64, fx=10.0, fy=11.0, cx=32.0, cy=24.0)
+    assert cam.near == 0.1 and cam.far == 100.0
+    assert torch.equal(cam.view_matrix[:3, :3], R) and torch.equal(cam.view_matrix[:3, 3], T)
+    assert torch.equal(cam.view_matrix[3], torch.tensor([0.0, 0, 0, 1]))
+    assert torch.equal(cam.Ks, torch.tensor([[10.0, 0, 32], [0, 11, 24], [0, 0, 1]]))
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_torch_projection_backend_matches_reference_goldens(path):
+    d, c = load_golden(path)
+    cam = camera_from_golden(d, c)
+    t = lambda k: torch.from_numpy(d[k])
+    m2, con, dep, rad = ms.project_gaussians(t("means3d"), t("scales"), t("quats"), t("opacities"),
+                                             cam, backend="torch")
+    assert m2.dtype == torch.float32 and rad.dtype == torch.int32
+    assert m2.shape == (len(d["means3d"]), 2) and con.shape[1] == 3 and rad.shape[1] == 2
+    vis = d["vis_index"]
+    assert np.array_equal(np_(rad), d["ref_radii"])
+    np.testing.assert_allclose(np_(m2)[vis], d["ref_means2d"][vis], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(np_(dep)[vis], d["ref_depths"][vis], rtol=1e-5, atol=1e-5)
+    scale = np.abs(d["ref_conics"][vis]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(np_(con)[vis] - d["ref_conics"][vis]) / scale) < 1e-4
+
+
+def test_config1_plumbing_cpu_torch_backend():
+    """BASELINE config 1: 1k Gaussians, 256x256, backend='torch' on CPU tensors."""
+    sc, cam = randscene_v1(1000, 256, 256, ell=-2.0)
+    m2, con, dep, rad = ms.project_gaussians(sc["means3d"], sc["scales"], sc["quats"],
+                                             sc["opacities"], cam, backend="torch")
+    ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, 256, 256, 16, backend="torch")
+    assert ids.dtype == torch.int32 and ranges.shape == (16, 16, 2) and ids.numel() > 0
+    oi, orng = oracle.bin_tiles(np_(m2), np_(rad), np_(dep), 256, 256, 16)
+    assert np.array_equal(oi, np_(ids)) and np.array_equal(orng, np_(ranges))
+
+
+@pytest.mark.parametrize("ts", [8, 16, 32])
+def test_torch_binning_equals_oracle_with_ties_and_culled(ts):
+    means3d, scales, quats, opac = proj_scene(400, seed=5)
+    cam = simple_camera(T=(0, 0, 5.0), H=96, W=80)
+    m2, con, dep, rad = oracle_project(oracle, means3d, scales, quats, opac, cam)
+    dep = np.round(dep, 1)  # force depth ties
+    ids, ranges = ms.bin_gaussians_to_tiles(torch.from_numpy(m2), torch.from_numpy(rad),
+                                            torch.from_numpy(dep), 96, 80, ts, backend="torch")
+    oi, orng = oracle.bin_tiles(m2, rad, dep, 96, 80, ts)
+    assert np.array_equal(oi, np_(ids)) and np.array_equal(orng, np_(ranges))
+
+
+def test_torch_binning_row_band():
+    from mojosplat_amd.binning import bin_gaussians_to_tiles_torch
+    means3d, scales, quats, opac = proj_scene(300, seed=9)
+    cam = simple_camera(T=(0, 0, 5.0), H=128, W=64)
+    m2, con, dep, rad = oracle_project(oracle, means3d, scales, quats, opac, cam)
+    ids, ranges = bin_gaussians_to_tiles_torch(torch.from_numpy(m2), torch.from_numpy(rad),
+                                               torch.from_numpy(dep), 16, 4, 8, row_range=(2, 5))
+    oi, orng = oracle.bin_tiles(m2, rad, dep, 128, 64, 16, row_begin=2, row_end=5)
+    assert np.array_equal(oi, np_(ids)) and np.array_equal(orng, np_(ranges))
+
+
+def test_invalid_backend_errors():
+    sc, cam = randscene_v1(8, 64, 64)
+    with pytest.raises(ValueError, match="Invalid backend"):
+        ms.project_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], cam, backend="nope")
+    with pytest.raises(ValueError, match="Invalid backend"):
+        ms.bin_gaussians_to_tiles(torch.zeros(1, 2), torch.ones(1, 2, dtype=torch.int32),
+                                  torch.ones(1), 64, 64, 16, backend="nope")
+    with pytest.raises(ValueError, match="Invalid backend"):
+        ms.rasterize_gaussians(torch.zeros(1, 2), torch.zeros(1, 3), torch.zeros(1, 3), torch.zeros(1),
+                               torch.zeros(3), torch.zeros(4, 4, 2), torch.zeros(0), cam, backend="nope")
+    for b in ("gsplat", "mojo"):
+        with pytest.raises(RuntimeError, match="third-party"):
+            ms.project_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], cam, backend=b)
+
+
+def test_render_rejects_cpu_tensors_like_the_reference():
+    sc, cam = randscene_v1(8, 64, 64)
+    with pytest.raises(ValueError, match="CUDA"):
+        ms.render_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"], cam)
+
+
+def test_hip_backend_never_falls_back_on_cpu():
+    """backend='hip' with CPU tensors / no GPU must fail loudly, not route to torch."""
+    sc, cam = randscene_v1(8, 64, 64)
+    with pytest.raises((ValueError, _hip.HipBackendError)):
+        ms.project_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], cam, backend="hip")
+    with pytest.raises((ValueError, _hip.HipBackendError)):
+        ms.bin_gaussians_to_tiles(torch.zeros(1, 2), torch.ones(1, 2, dtype=torch.int32), torch.ones(1),
+                                  64, 64, 16, backend="hip")
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "mojosplat_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "gsplat_oracle" not in src, f
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mojosplat_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", header))
+    assert {"ms_project_gaussians_fwd", "ms_isect_tiles_count", "ms_isect_tiles_emit",
+            "ms_rasterize_to_pixels_3dgs_fwd", "ms_version"} <= declared
+    if not os.path.exists(_hip.library_path()):
+        from mojosplat_amd.csrc import build
+        build.build()
+    import ctypes
+    L = ctypes.CDLL(_hip.library_path())
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    Lt = _hip.load()
+    assert Lt.ms_version() == _hip.ABI_VERSION
+    assert Lt.ms_last_error_string() is not None
+    assert Lt.ms_isect_workspace_bytes(1000, 120, 68) > 0
