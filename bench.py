@@ -1,0 +1,197 @@
+"""Headline benchmark: frames/s of the forward render path on synthetic random-Gaussian scenes.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one `render_gaussians(..., backend="hip")` forward (project -> bin/sort -> rasterise)
+of the whole frame, inputs resident in HBM.  N=1 workload = BASELINE config 3's forward
+(1M Gaussians, 1920x1080, the config the metric is quoted on).  N>1 = the SAME frame rendered
+as tile-row bands, one band per rank, + an RCCL all-gather of the framebuffer (strong scaling:
+total work per step is fixed).  Rank 0 prints ONE JSON line.
+
+`roofline` prices the dominant kernel (the tile rasteriser) with SURVEY.md 8(d)'s algorithmic
+bytes (40 B/intersection + 8 B/tile + 12 B/pixel) over its average duration measured with HIP
+events on the launch stream inside the timed region.  `cpu_baseline` times the scalar C oracle
+(1 core) on ONE frame of the same workload on this box's host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (N, W, H, ell, fp16 colours)
+    "cfg2": (100_000, 1920, 1080, -4.0, False),
+    "cfg3": (1_000_000, 1920, 1080, -4.0, False),
+    "cfg3-heavy": (1_000_000, 1920, 1080, -3.0, False),
+    "cfg4": (6_000_000, 1600, 1063, -4.0, True),
+    "cfg5": (5_000_000, 3840, 2160, -4.0, False),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mojosplat_amd as ms
+    from mojosplat_amd import _hip, render as render_mod
+    from mojosplat_amd.distributed import render_gaussians_sharded
+    from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
+
+    _hip.lib()  # hard failure if the HIP library is missing: nothing below has a CPU fallback
+    N, W, H, ell, fp16 = WORKLOADS[args.workload]
+    sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=dev)
+    if fp16:
+        sc["features"] = sc["features"].half()
+    bg = torch.tensor(BACKGROUND_V1, device=dev)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+
+    # one untimed pass through the per-stage API for the workload's statistics (N, M, T)
+    m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+    ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, H, W, 16, backend="hip")
+    M, T = int(ids.numel()), int(ranges.shape[0] * ranges.shape[1])
+    del m2, con, dep, rad, ids, ranges
+
+    if world == 1:
+        def step():
+            return ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    else:
+        def step():
+            return render_gaussians_sharded(*g, cam, background_color=bg)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+
+    # stage boundaries -> HIP events on the launch stream (torch's current stream IS the stream
+    # every ms_* call is enqueued on), recorded inside the timed region
+    marks = []
+    stage_events = []
+
+    def hook(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((name, ev))
+
+    if world == 1:
+        render_mod._STAGE_HOOK = hook
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if marks:
+            stage_events.append(list(marks))
+            marks.clear()
+    barrier()
+    dt = time.perf_counter() - t0
+    render_mod._STAGE_HOOK = None
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    fps = args.steps / dt
+
+    stage_us = {}
+    if stage_events:
+        acc = {}
+        for evs in stage_events:
+            for (n0, e0), (n1, e1) in zip(evs[:-1], evs[1:]):
+                acc.setdefault(n1, []).append(e0.elapsed_time(e1) * 1e3)
+        stage_us = {k: sum(v) / len(v) for k, v in acc.items()}
+
+    out = None
+    if rank == 0:
+        b_raster = (40 - (6 if fp16 else 0)) * M + 8 * T + 12 * H * W
+        b_frame = 96 * N + (84 - (6 if fp16 else 0)) * M + 12 * T + 12 * H * W
+        roofline = None
+        if "raster" in stage_us:
+            ach = b_raster / (stage_us["raster"] * 1e-6) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("rasterize_fwd_bytes")
+            roofline = {"bound": "hbm", "kernel": "k_rasterize_fwd", "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "algorithmic_bytes": b_raster,
+                        "avg_kernel_us": round(stage_us["raster"], 1),
+                        "alpha_evals": 256 * M,
+                        "frame": {"algorithmic_bytes": b_frame,
+                                  "achieved": round(b_frame / (ms_per_step * 1e-3) / 1e9, 1),
+                                  "frac": round(b_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "stage_us": {k: round(v, 1) for k, v in stage_us.items()}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(sc, cam, W, H, BACKGROUND_V1, args.workload)
+        out = {
+            "metric": "frames/sec at 1M Gaussians 1920x1080 fwd; achieved HBM GB/s vs peak",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: randscene-v1 N={N} {W}x{H} ell={ell} seed=42 forward",
+                       "gaussians": N, "intersections": M, "tiles": T, "tile_size": 16,
+                       "colour_dtype": "f16" if fp16 else "f32",
+                       "parallelism": "single GPU" if world == 1 else f"{world} tile-row bands + RCCL all-gather"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, cam, W, H, bg, workload):
+    """The scalar C oracle (kind 'port', 1 core) on a bounded sample of the same workload:
+    the first `n` Gaussians of the scene, chosen so the run stays around 10-30 s, scaled to
+    frames/s of that sample (stated in `sample`)."""
+    import numpy as np
+
+    import oracle
+    cpu = {k: v.float().cpu().numpy() for k, v in sc.items()}
+    vm = cam.view_matrix.cpu().numpy()
+    n = min(len(cpu["means3d"]), 1_000_000)
+    args = tuple(cpu[k][:n] for k in ("means3d", "scales", "quats", "opacities", "features"))
+    t0 = time.perf_counter()
+    _, aux = oracle.render_fwd(*args, vm, cam.fx, cam.fy, cam.cx, cam.cy, W, H,
+                               background=np.array(bg, np.float32))
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"1 frame of {workload} restricted to its first {n} Gaussians "
+                      f"(M={aux['M']}), oracle/gsplat_oracle.c, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

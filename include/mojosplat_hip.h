@@ -127,11 +127,14 @@ int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_
  *        flatten_ids i32[M].
  *   out: render_colors f32[H,W,CDIM]; render_alphas f32[H,W] or NULL; last_ids i32[H,W]
  *        or NULL (index into flatten_ids of the last contributing intersection).
+ *   Only tiles in rows [tile_row_begin, tile_row_end) are rendered (0, tile_h = whole image;
+ *   a band for multi-GPU sharding); output pointers always address the FULL image.
  * ------------------------------------------------------------------------------------- */
 int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float *means2d,
                                     const float *conics, const void *colors, int color_dtype,
                                     int CDIM, const float *opacities, const float *backgrounds,
-                                    int W, int H, int tile_size, const int32_t *tile_ranges,
+                                    int W, int H, int tile_size, int tile_row_begin,
+                                    int tile_row_end, const int32_t *tile_ranges,
                                     const int32_t *flatten_ids, float *render_colors,
                                     float *render_alphas, int32_t *last_ids, void *stream);
 

@@ -34,13 +34,9 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     "ms_isect_offset_encode": (c_int, [c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ms_rasterize_to_pixels_3dgs_fwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
-                                                c_int, c_void_p, c_void_p, c_int, c_int, c_int,
-                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                c_void_p]),
-}
-
-# entry points added after ABI v1's first cut; bound when present
-_OPTIONAL = {
+                                                c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p]),
     "ms_rasterize_to_pixels_3dgs_bwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -49,6 +45,10 @@ _OPTIONAL = {
                                          c_float, c_float, c_float, c_float, c_int, c_int, c_float,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
+}
+
+# entry points added after ABI v1's first cut; bound when present
+_OPTIONAL = {
     "ms_render_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
 }
 

@@ -1,0 +1,121 @@
+"""Differentiable wrappers around the HIP stages.
+
+The reference pipeline is inference-only (``@torch.no_grad()`` at mojosplat/render.py:11,
+"backward pass" listed as future work at README.md:145).  These ``torch.autograd.Function``s
+expose the gfx950 backward kernels so the same three stages can sit inside a training loop:
+
+    means2d, conics, depths, radii = project_gaussians_autograd(...)
+    ids, ranges = bin_gaussians_to_tiles(means2d.detach(), radii, depths.detach(), ...)
+    image = rasterize_gaussians_autograd(means2d, conics, colors, opacities, bg, ranges, ids, cam)
+
+Binning is index work and carries no gradient.
+"""
+import torch
+
+from . import _hip
+from .binning import bin_gaussians_to_tiles_hip
+from .projection import EPS2D, project_gaussians_hip
+from .rasterization import rasterize_gaussians_hip
+from .utils import Camera
+
+
+class _ProjectHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, quats, opacities, camera):
+        means3d, scales, quats = _hip.f32c(means3d), _hip.f32c(scales), _hip.f32c(quats)
+        out = project_gaussians_hip(means3d, scales, quats, opacities, camera)
+        means2d, conics, depths, radii = out
+        ctx.camera = camera
+        ctx.save_for_backward(means3d, scales, quats, radii)
+        ctx.mark_non_differentiable(radii)
+        return means2d, conics, depths, radii
+
+    @staticmethod
+    def backward(ctx, v_means2d, v_conics, v_depths, _v_radii):
+        means3d, scales, quats, radii = ctx.saved_tensors
+        cam = ctx.camera
+        L = _hip.lib()
+        N, dev = means3d.shape[0], means3d.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        v_means2d = _hip.f32c(v_means2d) if v_means2d is not None else z(N, 2)
+        v_conics = _hip.f32c(v_conics) if v_conics is not None else z(N, 3)
+        v_depths = _hip.f32c(v_depths) if v_depths is not None else None
+        v_means3d = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        vm = cam._viewmat_f32().to(dev)
+        with torch.cuda.device(dev):
+            _hip.check(L.ms_project_gaussians_bwd(
+                N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(vm), cam.fx,
+                cam.fy, cam.cx, cam.cy, cam.W, cam.H, EPS2D, _hip.ptr(radii), _hip.ptr(v_means2d),
+                _hip.ptr(v_conics), _hip.ptr(v_depths), _hip.ptr(v_means3d), _hip.ptr(v_scales),
+                _hip.ptr(v_quats), _hip.stream(dev)), "ms_project_gaussians_bwd")
+        return v_means3d, v_scales, v_quats, None, None
+
+
+class _RasterizeHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, background, tile_ranges, flatten_ids,
+                camera, tile_size):
+        means2d, conics = _hip.f32c(means2d), _hip.f32c(conics)
+        colors, opacities = _hip.f32c(colors), _hip.f32c(opacities.reshape(-1))
+        bg = None if background is None else _hip.f32c(background.reshape(-1))
+        ranges = tile_ranges.to(torch.int32).contiguous()
+        ids = flatten_ids.reshape(-1).to(torch.int32).contiguous()
+        img, alphas, last = rasterize_gaussians_hip(means2d, conics, colors, opacities, bg, ranges,
+                                                    ids, camera, tile_size, return_aux=True)
+        ctx.camera, ctx.tile_size = camera, tile_size
+        ctx.save_for_backward(means2d, conics, colors, opacities, bg, ranges, ids, alphas, last)
+        return img
+
+    @staticmethod
+    def backward(ctx, v_img):
+        means2d, conics, colors, opacities, bg, ranges, ids, alphas, last = ctx.saved_tensors
+        cam, ts = ctx.camera, ctx.tile_size
+        L = _hip.lib()
+        N, C = colors.shape
+        dev = means2d.device
+        v_img = _hip.f32c(v_img)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        v_means2d, v_conics, v_colors, v_opac = z(N, 2), z(N, 3), z(N, C), z(N)
+        with torch.cuda.device(dev):
+            _hip.check(L.ms_rasterize_to_pixels_3dgs_bwd(
+                N, ids.numel(), _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(colors), C,
+                _hip.ptr(opacities), _hip.ptr(bg), cam.W, cam.H, ts, _hip.ptr(ranges), _hip.ptr(ids),
+                _hip.ptr(alphas), _hip.ptr(last), _hip.ptr(v_img), None, _hip.ptr(v_means2d),
+                _hip.ptr(v_conics), _hip.ptr(v_colors), _hip.ptr(v_opac), _hip.stream(dev)),
+                "ms_rasterize_to_pixels_3dgs_bwd")
+        v_bg = None
+        if bg is not None and ctx.needs_input_grad[4]:
+            v_bg = ((1.0 - alphas)[..., None] * v_img).sum(dim=(0, 1))
+        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None
+
+
+def project_gaussians_autograd(means3d, scales, quats, opacities, camera: Camera):
+    return _ProjectHip.apply(means3d, scales, quats, opacities, camera)
+
+
+def rasterize_gaussians_autograd(means2d, conics, colors, opacities, background, tile_ranges,
+                                 flatten_ids, camera: Camera, tile_size: int = 16):
+    return _RasterizeHip.apply(means2d, conics, colors, opacities, background, tile_ranges,
+                               flatten_ids, camera, tile_size)
+
+
+def render_gaussians_trainable(means3d, scales, quats, opacities, features, camera: Camera,
+                               background_color=None, tile_size: int = 16):
+    """Differentiable twin of ``render_gaussians(backend="hip")``: grads for means3d, scales
+    (log-space), quats, opacities and colours (BASELINE config 3)."""
+    _hip.require_cuda(means3d, scales, quats, opacities, features, what="gaussian tensor")
+    C = features.shape[-1]
+    dev = means3d.device
+    bg = torch.zeros(C, device=dev) if background_color is None else \
+        torch.as_tensor(background_color, dtype=torch.float32, device=dev)
+    means2d, conics, depths, radii = project_gaussians_autograd(means3d, scales, quats, opacities, camera)
+    th, tw = -(-camera.H // tile_size), -(-camera.W // tile_size)
+    with torch.no_grad():
+        ids, ranges = bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size, tw, th)
+    if ids.numel() == 0:
+        # same zeros image as the inference path (reference render.py:73-76), grad-connected
+        return (means3d.sum() + features.sum()) * 0 + torch.zeros(camera.H, camera.W, C, device=dev)
+    return rasterize_gaussians_autograd(means2d, conics, features, opacities, bg, ranges, ids,
+                                        camera, tile_size)

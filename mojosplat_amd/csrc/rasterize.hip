@@ -30,7 +30,7 @@ struct RasterArgs {
     float *render_colors;
     float *render_alphas;
     int32_t *last_ids;
-    int W, H, ts, tw, nsx, nsub, cdim;
+    int W, H, ts, tw, nsx, nsub, cdim, tile0;
 };
 
 __device__ __forceinline__ float load_color(const float *p) { return *p; }
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void k_rasterize_fwd(RasterArgs A) {
     __shared__ float2 s_con[256];      // conic.b, conic.c
     __shared__ float s_rgb[256 * CP];
 
-    const int tile = blockIdx.x / A.nsub, sub = blockIdx.x - tile * A.nsub;
+    const int bt = blockIdx.x / A.nsub, sub = blockIdx.x - bt * A.nsub;
+    const int tile = A.tile0 + bt;
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -127,7 +128,8 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
                                                const float *conics, const void *colors,
                                                int color_dtype, int CDIM, const float *opacities,
                                                const float *backgrounds, int W, int H,
-                                               int tile_size, const int32_t *tile_ranges,
+                                               int tile_size, int tile_row_begin,
+                                               int tile_row_end, const int32_t *tile_ranges,
                                                const int32_t *flatten_ids, float *render_colors,
                                                float *render_alphas, int32_t *last_ids,
                                                void *stream) {
@@ -150,8 +152,14 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
     A.nsx = (tile_size + 15) / 16;
     A.nsub = A.nsx * A.nsx;
     A.cdim = CDIM;
-    const int64_t blocks = (int64_t)A.tw * th * A.nsub;
+    MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th,
+               MS_ERR_INVALID_ARG, "rasterize_fwd: bad tile row band [%d,%d) of %d", tile_row_begin,
+               tile_row_end, th);
+    A.tile0 = tile_row_begin * A.tw;
+    const int band_tiles = (tile_row_end - tile_row_begin) * A.tw;
+    if (band_tiles == 0) return MS_OK;
+    const int64_t blocks = (int64_t)band_tiles * A.nsub;
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
-    if (color_dtype == MS_COLOR_F16) return launch_fwd<__half>(A, A.tw * th, (hipStream_t)stream);
-    return launch_fwd<float>(A, A.tw * th, (hipStream_t)stream);
+    if (color_dtype == MS_COLOR_F16) return launch_fwd<__half>(A, band_tiles, (hipStream_t)stream);
+    return launch_fwd<float>(A, band_tiles, (hipStream_t)stream);
 }

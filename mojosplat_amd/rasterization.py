@@ -52,11 +52,12 @@ def _squeeze_batch(t: Tensor, nd: int) -> Tensor:
 
 def rasterize_gaussians_hip(means2d, conics, colors, opacities, background_color, tile_ranges,
                             sorted_gaussian_indices, camera: Camera, tile_size: int = 16,
-                            return_aux: bool = False):
+                            return_aux: bool = False, row_range=None, out=None):
     """-> image (H, W, C) f32 [, alphas (H, W) f32, last_ids (H, W) i32 when return_aux].
 
     Colours may be fp32 or fp16 (fp32 accumulation either way); the output dtype is fp32,
-    the dtype of means2d, as in the reference wrapper (rasterization.py:167)."""
+    the dtype of means2d, as in the reference wrapper (rasterization.py:167).
+    row_range=(r0, r1) renders only tile rows [r0, r1) (multi-GPU bands) into `out`."""
     _hip.require_cuda(means2d, conics, colors, opacities, tile_ranges, sorted_gaussian_indices,
                       what="rasteriser input")
     L = _hip.lib()
@@ -86,13 +87,19 @@ def rasterize_gaussians_hip(means2d, conics, colors, opacities, background_color
     if tuple(ranges.shape) != (th, tw, 2):
         raise ValueError(f"tile_ranges shape {tuple(ranges.shape)} != {(th, tw, 2)}")
     assert means2d.shape == (N, 2) and conics.shape == (N, 3) and op.shape == (N,)
-    img = torch.empty((H, W, C), dtype=torch.float32, device=dev)
+    r0, r1 = (0, th) if row_range is None else row_range
+    if out is not None:  # caller-owned framebuffer (may be padded below row H), e.g. a gather buffer
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= H
+        assert tuple(out.shape[1:]) == (W, C) and out.device == dev
+        img = out
+    else:
+        img = torch.empty((H, W, C), dtype=torch.float32, device=dev)
     alphas = torch.empty((H, W), dtype=torch.float32, device=dev) if return_aux else None
     last = torch.empty((H, W), dtype=torch.int32, device=dev) if return_aux else None
     with torch.cuda.device(dev):
         _hip.check(L.ms_rasterize_to_pixels_3dgs_fwd(
             N, M, _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(colors), cdt, C, _hip.ptr(op),
-            _hip.ptr(bg), W, H, tile_size, _hip.ptr(ranges), _hip.ptr(ids), _hip.ptr(img),
+            _hip.ptr(bg), W, H, tile_size, r0, r1, _hip.ptr(ranges), _hip.ptr(ids), _hip.ptr(img),
             _hip.ptr(alphas), _hip.ptr(last), _hip.stream(dev)),
             "ms_rasterize_to_pixels_3dgs_fwd")
     if return_aux:

@@ -18,6 +18,14 @@ from .utils import Camera
 
 TILE_SIZE = 16
 
+# bench.py installs a callable here to drop HIP events at the stage boundaries; None = no cost
+_STAGE_HOOK = None
+
+
+def _mark(name):
+    if _STAGE_HOOK is not None:
+        _STAGE_HOOK(name)
+
 
 @torch.no_grad()
 def render_gaussians(
@@ -48,10 +56,13 @@ def render_gaussians(
                          f"channels ({num_channels})")
     assert opacities.shape == (means3d.shape[0],)
 
+    _mark("start")
     means2d, conics, depths, radii = project_gaussians(means3d, scales, quats, opacities, camera,
                                                        backend=backend)
+    _mark("project")
     sorted_ids, tile_ranges = bin_gaussians_to_tiles(means2d, radii, depths, camera.H, camera.W,
                                                      tile_size, backend=backend)
+    _mark("bin")
     if sorted_ids.numel() == 0:
         return torch.zeros(camera.H, camera.W, num_channels, device=means3d.device,
                            dtype=features.dtype)
@@ -59,6 +70,9 @@ def render_gaussians(
     colors = features
     if sh_degree is not None and features.shape[-1] > 3:
         colors = features[..., :3]  # same placeholder as the reference (render.py:82-87)
+        bg = bg[:3]
 
-    return rasterize_gaussians(means2d, conics, colors, opacities, bg, tile_ranges, sorted_ids,
-                               camera, tile_size=tile_size, backend=backend)
+    img = rasterize_gaussians(means2d, conics, colors, opacities, bg, tile_ranges, sorted_ids,
+                              camera, tile_size=tile_size, backend=backend)
+    _mark("raster")
+    return img

@@ -1,0 +1,140 @@
+"""GPU: backward kernels against autograd through the float64 torch restatement
+(oracle/torch_oracle.py) and against finite differences.
+
+Backward parity is unpinned against the reference (it has no backward: render.py:11); the
+bar here is agreement with the differentiable restatement of the SAME forward:
+|g_hip - g_ref| <= 2e-3 * max|g_ref| + 1e-6 per tensor (fp32 kernels, atomics order varies).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import np_, oracle_project, proj_scene, raster_scene, simple_camera
+from mojosplat_amd.autograd import (project_gaussians_autograd, rasterize_gaussians_autograd,
+                                    render_gaussians_trainable)
+from mojosplat_amd.scenes import randscene_v1
+from oracle import torch_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_grad_close(name, got, ref, rel=2e-3):
+    got, ref = np_(got).astype(np.float64), np_(ref).astype(np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= rel * scale + 1e-6, f"{name}: max err {err:.3g} vs scale {scale:.3g}"
+
+
+def _cam_args(cam):
+    return (cam.view_matrix.double().cpu(), cam.fx, cam.fy, cam.cx, cam.cy, cam.W, cam.H)
+
+
+@pytest.mark.parametrize("N,T", [(64, (0, 0, 5.0)), (300, (0.4, -0.3, 6.0))])
+def test_projection_backward_vs_autograd(device, N, T):
+    means3d, scales, quats, opac = proj_scene(N, seed=N)
+    quats = quats * 1.7                                   # un-normalised on purpose
+    cam = simple_camera(device, T=T, H=48, W=48, f=40.0)  # narrow FOV: the tx/ty clamp is active
+    leaves = [t.to(device).requires_grad_(True) for t in (means3d, scales, quats)]
+    m2, con, dep, rad = project_gaussians_autograd(*leaves, opac.to(device), cam)
+    vis = (rad > 0).all(1)
+    assert vis.sum() > N // 4
+    g = torch.Generator().manual_seed(1)
+    wm, wc, wd = torch.randn(N, 2, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, generator=g)
+    loss = (m2 * wm.to(device)).sum() + (con * wc.to(device)).sum() + (dep * wd.to(device)).sum()
+    loss.backward()
+
+    ref_leaves = [t.double().requires_grad_(True) for t in (means3d, scales, quats)]
+    rm2, rcon, rdep = torch_oracle.project(*ref_leaves, *_cam_args(cam))
+    v = vis.cpu()
+    rloss = ((rm2 * wm)[v]).sum() + ((rcon * wc)[v]).sum() + ((rdep * wd)[v]).sum()
+    rloss.backward()
+    for name, a, b in zip(("means3d", "scales", "quats"), leaves, ref_leaves):
+        assert (a.grad[~vis] == 0).all()
+        assert_grad_close(name, a.grad, b.grad, rel=1e-3)
+
+
+@pytest.mark.parametrize("N,bg", [(5, None), (60, (0.3, 0.5, 0.7)), (250, (0.1, 0.1, 0.1))])
+def test_raster_backward_vs_autograd(device, N, bg):
+    means3d, ls, quats, opac, colors = raster_scene(N, seed=N + 7)
+    cam = simple_camera()
+    m2, con, dep, rad = oracle_project(oracle, means3d, ls, quats, opac, cam)
+    ids, ranges = oracle.bin_tiles(m2, rad, dep, 64, 64, 16)
+    assert ids.size > 0
+    g = torch.Generator().manual_seed(3)
+    v_img = torch.rand(64, 64, 3, generator=g)
+    bgt = None if bg is None else torch.tensor(bg)
+
+    dcam = simple_camera(device)
+    to = lambda a: torch.from_numpy(a).to(device)
+    leaves = [to(m2).requires_grad_(True), to(con).requires_grad_(True),
+              colors.to(device).requires_grad_(True), opac.to(device).requires_grad_(True)]
+    bgd = None if bgt is None else bgt.to(device).requires_grad_(True)
+    img = rasterize_gaussians_autograd(*leaves, bgd, to(ranges), to(ids), dcam)
+    (img * v_img.to(device)).sum().backward()
+
+    rl = [torch.from_numpy(m2).double().requires_grad_(True), torch.from_numpy(con).double().requires_grad_(True),
+          colors.double().requires_grad_(True), opac.double().requires_grad_(True)]
+    rbg = None if bgt is None else bgt.double().requires_grad_(True)
+    rimg, _ = torch_oracle.rasterize(*rl, rbg, torch.from_numpy(ranges), torch.from_numpy(ids), 64, 64, 16)
+    (rimg * v_img.double()).sum().backward()
+    np.testing.assert_allclose(np_(img), np_(rimg), atol=1e-4)
+    for name, a, b in zip(("means2d", "conics", "colors", "opacities"), leaves, rl):
+        assert_grad_close(name, a.grad, b.grad)
+    if bgt is not None:
+        assert_grad_close("background", bgd.grad, rbg.grad)
+
+
+def test_raster_backward_repeatable_within_atomic_noise(device):
+    means3d, ls, quats, opac, colors = raster_scene(200, seed=5)
+    cam = simple_camera()
+    m2, con, dep, rad = oracle_project(oracle, means3d, ls, quats, opac, cam)
+    ids, ranges = oracle.bin_tiles(m2, rad, dep, 64, 64, 16)
+    to = lambda a: torch.from_numpy(a).to(device)
+    grads = []
+    for _ in range(2):
+        leaf = to(m2).requires_grad_(True)
+        img = rasterize_gaussians_autograd(leaf, to(con), colors.to(device), opac.to(device), None, to(ranges),
+                                           to(ids), simple_camera(device))
+        img.sum().backward()
+        grads.append(leaf.grad.clone())
+    assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6)
+
+
+def test_end_to_end_gradients_and_finite_difference(device):
+    """config 3 in miniature: grads for means/scales/quats/opacity/rgb through the whole path,
+    checked against autograd of the restatement and one finite-difference probe."""
+    sc, cam = randscene_v1(400, 96, 64, ell=-2.5, seed=11, device=device)
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    leaves = [sc[k].clone().requires_grad_(True) for k in names]
+    bg = torch.tensor([0.1, 0.1, 0.1], device=device)
+    g = torch.Generator().manual_seed(43)
+    v_img = torch.rand(64, 96, 3, generator=g).to(device)
+    img = render_gaussians_trainable(*leaves, cam, background_color=bg)
+    loss = (img * v_img).sum()
+    loss.backward()
+
+    # reference: same visibility + binning (from the HIP forward), float64 autograd
+    with torch.no_grad():
+        m2h, conh, deph, radh = project_gaussians_autograd(*[l.detach() for l in leaves[:4]], cam)
+    from mojosplat_amd.binning import bin_gaussians_to_tiles_hip
+    ids, ranges = bin_gaussians_to_tiles_hip(m2h, radh, deph, 16, 6, 4)
+    rl = [l.detach().double().cpu().requires_grad_(True) for l in leaves]
+    rm2, rcon, rdep = torch_oracle.project(rl[0], rl[1], rl[2], *_cam_args(cam))
+    rimg, _ = torch_oracle.rasterize(rm2, rcon, rl[4], rl[3], bg.double().cpu(), ranges.cpu(), ids.cpu(), 64, 96, 16)
+    np.testing.assert_allclose(np_(img), np_(rimg), atol=2e-4)
+    (rimg * v_img.double().cpu()).sum().backward()
+    for name, a, b in zip(names, leaves, rl):
+        assert_grad_close(name, a.grad, b.grad, rel=5e-3)
+
+    # finite difference along a random direction of the colours (exactly linear path)
+    d = torch.randn_like(leaves[4])
+    eps = 1e-2
+    with torch.no_grad():
+        lp = (render_gaussians_trainable(*[l.detach() for l in leaves[:4]], leaves[4].detach() + eps * d, cam,
+                                         background_color=bg) * v_img).sum()
+        lm = (render_gaussians_trainable(*[l.detach() for l in leaves[:4]], leaves[4].detach() - eps * d, cam,
+                                         background_color=bg) * v_img).sum()
+    fd = ((lp - lm) / (2 * eps)).item()
+    an = (leaves[4].grad * d).sum().item()
+    assert abs(fd - an) <= 2e-3 * max(1.0, abs(an))

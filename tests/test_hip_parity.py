@@ -121,10 +121,9 @@ def test_projection_100k_statistics(device):
 
 # --------------------------------------------------------------------------------- binning
 def _bin_case(device, m2, rad, dep, H, W, ts, **kw):
-    ids, ranges = bin_gaussians_to_tiles_hip(
+    return bin_gaussians_to_tiles_hip(
         torch.from_numpy(m2).to(device), torch.from_numpy(rad).to(device), torch.from_numpy(dep).to(device),
         ts, -(-W // ts), -(-H // ts), **kw)
-    return ids, ranges
 
 
 @pytest.mark.parametrize("ts", [8, 16, 32])

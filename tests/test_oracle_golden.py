@@ -158,3 +158,29 @@ def test_binning_structure_and_edge_cases():
     dep = np.array([2.0, 1.0, 2.0, 1.5], np.float32)
     ids, _ = oracle.bin_tiles(m2, rad, dep, 16, 16, 16)
     assert ids.tolist() == [3, 0, 2]
+
+
+def test_differentiable_restatement_matches_c_oracle():
+    """oracle/torch_oracle.py (gradient oracle) reproduces the C oracle's forward."""
+    import torch
+    from oracle import torch_oracle
+    d, cam = load_golden([p for p in golden_files() if "raster_scene_n200" in p][0])
+    m2, con, dep, rad = oracle.project_fwd(d["means3d"], d["scales"], d["quats"], d["opacities"], d["viewmat"],
+                                           cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["W"], cam["H"],
+                                           near=cam["near"], far=cam["far"])
+    t = lambda a: torch.from_numpy(np.asarray(a)).double()
+    tm2, tcon, tdep = torch_oracle.project(t(d["means3d"]), t(d["scales"]), t(d["quats"]), t(d["viewmat"]),
+                                           cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["W"], cam["H"])
+    vis = (rad > 0).all(1)
+    np.testing.assert_allclose(tm2.numpy()[vis], m2[vis], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(tdep.numpy()[vis], dep[vis], rtol=1e-6)
+    scale = np.abs(con[vis]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(tcon.numpy()[vis] - con[vis]) / scale) < 2e-5
+    ids, ranges = oracle.bin_tiles(m2, rad, dep, cam["H"], cam["W"], 16)
+    bg = np.array([0.2, 0.3, 0.4], np.float32)
+    img, alphas, _ = oracle.rasterize_fwd(m2, con, d["colors"], d["opacities"], bg, ranges, ids, cam["H"], cam["W"], 16)
+    timg, talpha = torch_oracle.rasterize(t(m2), t(con), t(d["colors"]), t(d["opacities"]), t(bg),
+                                          torch.from_numpy(ranges), torch.from_numpy(ids), cam["H"], cam["W"], 16)
+    diff = np.abs(timg.numpy() - img).max(-1)
+    assert np.mean(diff > 1e-4) < 2e-3 and np.median(diff) < 1e-6
+    assert np.abs(talpha.numpy() - alphas).max() < 5e-3
