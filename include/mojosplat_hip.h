@@ -87,19 +87,19 @@ int ms_project_gaussians_fwd(int64_t N, const float *means3d, const float *scale
  *   out: tile_ranges i32[tile_h,tile_w,2] = [start,end) into the sorted intersection list
  *        (tiles outside the band get empty ranges);
  *        tiles_per_gauss i32[N] or NULL;
- *        isect_info i64[4] (device): {M, largest per-tile count, #tiles needing the
- *        large-tile sort, #tiles needing the merge fallback}.  Copy it to the host to
- *        size flatten_ids and to drive ms_isect_tiles_emit.
+ *        isect_info i64[8] (device): {M, largest per-tile count, #tiles in the medium /
+ *        large / merge-fallback sort classes, 0, 0, 0}.  Copy it to the host to size
+ *        flatten_ids and to drive ms_isect_tiles_emit.
  *
  * ms_isect_tiles_emit: scatter (depth,id) keys into their tile segments and depth-sort
  * every segment.  Order inside a tile: ascending (float bits of depth, Gaussian index) --
  * identical to a stable radix sort of (tile<<32 | depth_bits) keys emitted in Gaussian
  * order, i.e. gsplat.isect_tiles(sort=True).
  *   in : as above plus depths f32[N]; the SAME workspace the count call filled;
- *        host_info = the 4 values of isect_info as read by the host; M = host_info[0].
+ *        host_info = the 8 values of isect_info as read by the host; M = host_info[0].
  *   out: flatten_ids i32[M]; isect_ids i64[M] or NULL (sorted keys (tile<<32)|depth_bits).
  *        sort_keys u64[M] and sort_tmp u64[M or 0] are caller-allocated scratch
- *        (sort_tmp is only touched when host_info[3] > 0).
+ *        (sort_tmp is only touched when host_info[4] > 0).
  * ------------------------------------------------------------------------------------- */
 size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h);
 

@@ -46,7 +46,7 @@ def bin_gaussians_to_tiles(
 
 # --------------------------------------------------------------------------- hip backend
 _workspaces = {}   # device -> grow-only uint8 scratch (histograms, work lists)
-_pinned = {}       # device -> pinned i64[4] for the one size hand-off
+_pinned = {}       # device -> pinned i64[8] for the one size hand-off
 
 
 def _workspace(dev, nbytes: int) -> Tensor:
@@ -60,7 +60,7 @@ def _workspace(dev, nbytes: int) -> Tensor:
 def _pinned_info(dev) -> Tensor:
     p = _pinned.get(dev)
     if p is None:
-        p = torch.empty(4, dtype=torch.int64).pin_memory()
+        p = torch.empty(8, dtype=torch.int64).pin_memory()
         _pinned[dev] = p
     return p
 
@@ -84,7 +84,7 @@ def bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size: int, tile_widt
     ws_bytes = L.ms_isect_workspace_bytes(N, tile_width, tile_height)
     ws = _workspace(dev, ws_bytes)
     tile_ranges = torch.empty((tile_height, tile_width, 2), dtype=torch.int32, device=dev)
-    info = torch.empty(4, dtype=torch.int64, device=dev)
+    info = torch.empty(8, dtype=torch.int64, device=dev)
     tpg = torch.empty(N, dtype=torch.int32, device=dev) if return_tiles_per_gauss else None
     with torch.cuda.device(dev):
         st = _hip.stream(dev)
@@ -95,7 +95,8 @@ def bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size: int, tile_widt
         host = _pinned_info(dev)
         host.copy_(info, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
-        M, _, _, n_xl = (int(v) for v in host.tolist())
+        vals = host.tolist()
+        M, n_xl = int(vals[0]), int(vals[4])
         if M > 0x7FFFFFFF:
             raise _hip.HipBackendError(f"{M} intersections do not fit int32 indices")
         flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
@@ -103,7 +104,7 @@ def bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size: int, tile_widt
         if M > 0:
             keys = torch.empty(M, dtype=torch.int64, device=dev)
             tmp = torch.empty(M, dtype=torch.int64, device=dev) if n_xl > 0 else None
-            host_info = (ctypes.c_int64 * 4)(*host.tolist())
+            host_info = (ctypes.c_int64 * 8)(*vals)
             _hip.check(L.ms_isect_tiles_emit(
                 N, _hip.ptr(means2d), _hip.ptr(radii), _hip.ptr(depths), tile_size, tile_width,
                 tile_height, r0, r1, _hip.ptr(ws), ws.numel(), _hip.ptr(tile_ranges), host_info,

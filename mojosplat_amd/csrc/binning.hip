@@ -17,8 +17,8 @@
 //   k_tile_scan_wg    per tile: exclusive prefix over the G partial counts (16 waves split G)
 //   k_tile_scan_total one workgroup: exclusive scan over tiles -> tile_ranges, M, work lists
 //   k_isect_scatter   same chunks; LDS cursors hand out slots inside each tile segment
-//   k_tile_sort_small one workgroup per tile with <= 2048 entries (16 KB LDS)
-//   k_tile_sort_large work list of tiles with <= 16384 entries (128 KB LDS)
+//   k_tile_sort_small one 256-thread workgroup per tile with <= 1024 entries (12 KB LDS)
+//   k_tile_sort_list  work lists of tiles with <= 4096 (48 KB LDS) and <= 16384 entries (144 KB)
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
 #include "ms_common.hpp"
 
@@ -26,8 +26,7 @@ namespace {
 
 constexpr int kHistThreads = 1024;
 constexpr int kMaxG = 512;
-constexpr int kSmallCap = 2048;    // entries sorted by a 256-thread workgroup in 16 KB LDS
-constexpr int kLargeCap = 16384;   // entries sorted by a 1024-thread workgroup in 128 KB LDS
+constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 4096, kLargeCapDecl = 16384;  // per-tile sort classes
 constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
 constexpr size_t kMaxLds = 160 * 1024;
 
@@ -152,16 +151,17 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
 // the band count 0), tile_ranges, totals and the work lists of over-sized tiles.
 __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t *__restrict__ tile_count,
                                                           int32_t *__restrict__ tile_ranges,
+                                                          int32_t *__restrict__ medium_list,
                                                           int32_t *__restrict__ large_list,
                                                           int32_t *__restrict__ xl_list,
                                                           int64_t *__restrict__ info) {
     __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned int s_nlarge, s_nxl, s_max;
+    __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max;
     const int T = g.tw * g.th;
     const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
     const int K = (T + 1023) / 1024;
     const int t0 = threadIdx.x * K, t1 = min(T, t0 + K);
-    if (threadIdx.x == 0) { s_nlarge = 0; s_nxl = 0; s_max = 0; }
+    if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; }
     unsigned long long sum = 0;
     for (int t = t0; t < t1; ++t)
         if (t >= band0 && t < band1) sum += tile_count[t - band0];
@@ -191,16 +191,19 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
         tile_ranges[2 * t + 1] = (int32_t)min(e, 0x7fffffffull);
         run = e;
         lmax = max(lmax, c);
-        if (c > (unsigned)kLargeCap) xl_list[atomicAdd(&s_nxl, 1u)] = t;
-        else if (c > (unsigned)kSmallCap) large_list[atomicAdd(&s_nlarge, 1u)] = t;
+        if (c > (unsigned)kLargeCapDecl) xl_list[atomicAdd(&s_nxl, 1u)] = t;
+        else if (c > (unsigned)kMediumCapDecl) large_list[atomicAdd(&s_nlarge, 1u)] = t;
+        else if (c > (unsigned)kSmallCapDecl) medium_list[atomicAdd(&s_nmedium, 1u)] = t;
     }
     atomicMax(&s_max, lmax);
     __syncthreads();
     if (threadIdx.x == 0) {
         info[0] = (int64_t)grand;
         info[1] = (int64_t)s_max;
-        info[2] = (int64_t)s_nlarge;
-        info[3] = (int64_t)s_nxl;
+        info[2] = (int64_t)s_nmedium;
+        info[3] = (int64_t)s_nlarge;
+        info[4] = (int64_t)s_nxl;
+        info[5] = info[6] = info[7] = 0;
     }
 }
 
@@ -223,7 +226,16 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     });
 }
 
-// ---- LDS bitonic sort of 64-bit keys -------------------------------------------------
+// ---- per-tile sort in LDS -------------------------------------------------------------
+// Keys are (depth_bits << 32 | gaussian); inside a tile they are distinct.
+//
+// Main path: ONE counting pass on the depth bits.  (depth_bits - min) >> shift maps the tile's
+// depth span order-preservingly onto B ~ n buckets (float bits are monotone in depth for the
+// positive depths that survive projection); an LDS histogram + scan + scatter puts every key
+// into its bucket, and each bucket -- 0..3 keys typically -- is finished by one lane with an
+// insertion sort on the full 64-bit key.  ~6 barriers per tile instead of the O(log^2 n) of a
+// bitonic network.  If some bucket is crowded (many identical depths) the tile falls back to
+// the bitonic network below, which is oblivious to the key distribution.
 template <int THREADS>
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t *s, int P) {
     for (int k = 2; k <= P; k <<= 1) {
@@ -246,57 +258,173 @@ __device__ __forceinline__ int next_pow2(int n) {
     return p;
 }
 
-template <int THREADS>
-__device__ __forceinline__ void sort_segment_lds(uint64_t *s, const uint64_t *__restrict__ keys_in,
+constexpr int kMaxBuckets = 4096;
+constexpr int kBucketFallback = 48;  // a bucket this crowded sends the tile to the bitonic path
+
+template <int THREADS, int E>
+struct SortCfg {
+    static constexpr int CAP = THREADS * E;
+    static constexpr int NB = CAP < kMaxBuckets ? CAP : kMaxBuckets;
+    static constexpr size_t LDS = (size_t)CAP * 8 + (size_t)NB * 4 + 64 * 4;
+};
+
+template <int THREADS, int E>
+__device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint64_t *__restrict__ keys_in,
                                                  int start, int n, int tile,
                                                  int32_t *__restrict__ flatten_ids,
                                                  int64_t *__restrict__ isect_ids,
                                                  uint64_t *__restrict__ keys_out) {
-    const int P = max(2, next_pow2(n));
-    for (int i = threadIdx.x; i < P; i += THREADS) s[i] = i < n ? keys_in[start + i] : ~0ull;
+    using Cfg = SortCfg<THREADS, E>;
+    constexpr int NW = THREADS / 64;
+    uint64_t *s_out = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + Cfg::CAP);
+    uint32_t *s_red = s_cnt + Cfg::NB;  // 64 words of reduction scratch
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    // 1. keys -> registers; min / max of the depth bits
+    uint64_t k[E];
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * THREADS + tid;
+        k[e] = i < n ? keys_in[start + i] : ~0ull;
+        if (i < n) {
+            const uint32_t hi = (uint32_t)(k[e] >> 32);
+            kmin = min(kmin, hi);
+            kmax = max(kmax, hi);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
+    }
+    if (lane == 0) { s_red[w] = kmin; s_red[16 + w] = kmax; }
+    const int B = min(Cfg::NB, max(64, next_pow2(n)));
+    for (int b = tid; b < B; b += THREADS) s_cnt[b] = 0;
     __syncthreads();
-    bitonic_sort_lds<THREADS>(s, P);
-    for (int i = threadIdx.x; i < n; i += THREADS) {
-        const uint64_t k = s[i];
-        if (flatten_ids) flatten_ids[start + i] = (int32_t)(uint32_t)k;
-        if (isect_ids) isect_ids[start + i] = ((int64_t)tile << 32) | (int64_t)(k >> 32);
-        if (keys_out) keys_out[start + i] = k;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) { kmin = min(kmin, s_red[ww]); kmax = max(kmax, s_red[16 + ww]); }
+    const uint32_t span = kmax - kmin;
+    const int bits = span ? 32 - __clz(span) : 0;
+    const int shift = max(0, bits - (31 - __clz(B)));
+
+    // 2. histogram
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (e * THREADS + tid < n) atomicAdd(&s_cnt[((uint32_t)(k[e] >> 32) - kmin) >> shift], 1u);
+    __syncthreads();
+
+    // 3. exclusive scan of the B counters (each lane owns `per` consecutive ones)
+    const int per = (B + THREADS - 1) / THREADS;   // <= NB / THREADS, a power of two or 1
+    uint32_t local[Cfg::NB / THREADS > 0 ? Cfg::NB / THREADS : 1];
+    uint32_t sum = 0, cmax = 0;
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(local) / 4); ++q) {
+        const int b = tid * per + q;
+        local[q] = (q < per && b < B) ? s_cnt[b] : 0u;
+        sum += local[q];
+        cmax = max(cmax, local[q]);
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d));
+    __syncthreads();  // s_red reuse
+    if (lane == 63) s_red[w] = incl;
+    if (lane == 0) s_red[16 + w] = cmax;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    cmax = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+        if (ww < w) run += s_red[ww];
+        cmax = max(cmax, s_red[16 + ww]);
+    }
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(local) / 4); ++q) {
+        const int b = tid * per + q;
+        if (q < per && b < B) { s_cnt[b] = run; run += local[q]; }
+    }
+    __syncthreads();
+
+    // 4. scatter into buckets (s_cnt[b] becomes the END of bucket b)
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (e * THREADS + tid < n) {
+            const uint32_t pos = atomicAdd(&s_cnt[((uint32_t)(k[e] >> 32) - kmin) >> shift], 1u);
+            s_out[pos] = k[e];
+        }
+    __syncthreads();
+
+    // 5. finish: insertion sort per bucket, or the oblivious network when a bucket is crowded
+    if (cmax <= (uint32_t)kBucketFallback) {
+        for (int b = tid; b < B; b += THREADS) {
+            const int beg = b ? (int)s_cnt[b - 1] : 0, end = (int)s_cnt[b];
+            for (int i = beg + 1; i < end; ++i) {
+                const uint64_t v = s_out[i];
+                int j = i - 1;
+                while (j >= beg && s_out[j] > v) { s_out[j + 1] = s_out[j]; --j; }
+                s_out[j + 1] = v;
+            }
+        }
+    } else {
+        const int P = max(2, next_pow2(n));
+        for (int i = n + tid; i < P; i += THREADS) s_out[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_lds<THREADS>(s_out, P);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += THREADS) {
+        const uint64_t v = s_out[i];
+        if (flatten_ids) flatten_ids[start + i] = (int32_t)(uint32_t)v;
+        if (isect_ids) isect_ids[start + i] = ((int64_t)tile << 32) | (int64_t)(v >> 32);
+        if (keys_out) keys_out[start + i] = v;
     }
 }
+
+constexpr int kSmallCap = SortCfg<256, 4>::CAP;     // 1024: one 256-thread workgroup, 12 KB LDS
+constexpr int kMediumCap = SortCfg<1024, 4>::CAP;   // 4096: 1024 threads, 48 KB LDS
+constexpr int kLargeCap = SortCfg<1024, 16>::CAP;   // 16384: 1024 threads, 144 KB LDS
 
 __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restrict__ tile_ranges,
                                                          const uint64_t *__restrict__ keys,
                                                          int32_t *__restrict__ flatten_ids,
                                                          int64_t *__restrict__ isect_ids) {
-    __shared__ uint64_t s[kSmallCap];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SortCfg<256, 4>::LDS];
     const int tile = blockIdx.x;
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
     if (n <= 0 || n > kSmallCap) return;
-    sort_segment_lds<256>(s, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
+    sort_segment_lds<256, 4>(smem, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
 }
 
-__global__ __launch_bounds__(1024) void k_tile_sort_large(const int32_t *__restrict__ large_list,
-                                                          const int32_t *__restrict__ tile_ranges,
-                                                          const uint64_t *__restrict__ keys,
-                                                          int32_t *__restrict__ flatten_ids,
-                                                          int64_t *__restrict__ isect_ids) {
-    extern __shared__ uint64_t s_large[];
-    const int tile = large_list[blockIdx.x];
+template <int E>
+__global__ __launch_bounds__(1024) void k_tile_sort_list(const int32_t *__restrict__ list,
+                                                         const int32_t *__restrict__ tile_ranges,
+                                                         const uint64_t *__restrict__ keys,
+                                                         int32_t *__restrict__ flatten_ids,
+                                                         int64_t *__restrict__ isect_ids) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    const int tile = list[blockIdx.x];
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
-    sort_segment_lds<1024>(s_large, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
+    sort_segment_lds<1024, E>(smem_dyn, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
 }
 
 // XL tiles: sort runs of kLargeCap in place ...
 __global__ __launch_bounds__(1024) void k_xl_chunk_sort(const int32_t *__restrict__ xl_list,
                                                         const int32_t *__restrict__ tile_ranges,
                                                         uint64_t *__restrict__ keys) {
-    extern __shared__ uint64_t s_large[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     const int tile = xl_list[blockIdx.y];
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
     const int c0 = blockIdx.x * kLargeCap;
     if (c0 >= n) return;
     const int cn = min(kLargeCap, n - c0);
-    sort_segment_lds<1024>(s_large, keys, start + c0, cn, tile, nullptr, nullptr, keys);
+    sort_segment_lds<1024, 16>(smem_dyn, keys, start + c0, cn, tile, nullptr, nullptr, keys);
 }
 
 // ... then merge neighbouring sorted runs of length L.  Keys inside a tile are distinct
@@ -362,7 +490,7 @@ struct Plan {
     int64_t chunk;
     int T, T_local;
     size_t lds_bytes;
-    size_t off_hist, off_count, off_large, off_xl, total;
+    size_t off_hist, off_count, off_medium, off_large, off_xl, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -378,6 +506,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     size_t o = 0;
     p.off_hist = o;   o += ms::align_up((size_t)kMaxG * p.T * 4, 256);
     p.off_count = o;  o += ms::align_up((size_t)p.T * 4, 256);
+    p.off_medium = o; o += ms::align_up((size_t)p.T * 4, 256);
     p.off_large = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
     p.total = o;
@@ -436,6 +565,7 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
     char *ws = (char *)workspace;
     uint32_t *hist = (uint32_t *)(ws + p.off_hist);
     uint32_t *count = (uint32_t *)(ws + p.off_count);
+    int32_t *medium = (int32_t *)(ws + p.off_medium);
     int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
 
@@ -451,8 +581,8 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
     } else if (tiles_per_gauss && N > 0) {
         MS_HIP(hipMemsetAsync(tiles_per_gauss, 0, (size_t)N * 4, stream));
     }
-    hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, large,
-                       xl, isect_info);
+    hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium,
+                       large, xl, isect_info);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -467,7 +597,8 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
     hipStream_t stream = (hipStream_t)stream_;
     MS_REQUIRE(N >= 0 && host_info, MS_ERR_INVALID_ARG, "isect_emit: bad N / host_info");
     if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
-    const int64_t M = host_info[0], max_count = host_info[1], n_large = host_info[2], n_xl = host_info[3];
+    const int64_t M = host_info[0], max_count = host_info[1], n_medium = host_info[2],
+                  n_large = host_info[3], n_xl = host_info[4];
     MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE,
                "isect_emit: %lld intersections do not fit int32 indices", (long long)M);
     if (M == 0) return MS_OK;
@@ -481,6 +612,7 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
                workspace_bytes, p.total);
     char *ws = (char *)workspace;
     const uint32_t *hist = (const uint32_t *)(ws + p.off_hist);
+    const int32_t *medium = (const int32_t *)(ws + p.off_medium);
     const int32_t *large = (const int32_t *)(ws + p.off_large), *xl = (const int32_t *)(ws + p.off_xl);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
 
@@ -493,10 +625,18 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
     hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
                        flatten_ids, isect_ids);
     MS_LAUNCH_CHECK();
-    const size_t large_lds = (size_t)kLargeCap * 8;
+    static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
+                  "sort class thresholds out of sync");
+    const size_t medium_lds = SortCfg<1024, 4>::LDS, large_lds = SortCfg<1024, 16>::LDS;
+    if (n_medium > 0) {
+        if (int rc = allow_big_lds(k_tile_sort_list<4>)) return rc;
+        hipLaunchKernelGGL(k_tile_sort_list<4>, dim3((unsigned)n_medium), dim3(1024), medium_lds, stream,
+                           medium, tile_ranges, sort_keys, flatten_ids, isect_ids);
+        MS_LAUNCH_CHECK();
+    }
     if (n_large > 0) {
-        if (int rc = allow_big_lds(k_tile_sort_large)) return rc;
-        hipLaunchKernelGGL(k_tile_sort_large, dim3((unsigned)n_large), dim3(1024), large_lds, stream,
+        if (int rc = allow_big_lds(k_tile_sort_list<16>)) return rc;
+        hipLaunchKernelGGL(k_tile_sort_list<16>, dim3((unsigned)n_large), dim3(1024), large_lds, stream,
                            large, tile_ranges, sort_keys, flatten_ids, isect_ids);
         MS_LAUNCH_CHECK();
     }

@@ -38,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in _sources():
         obj = os.path.splitext(src)[0] + ".o"
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
             print(" ".join(cmd))
