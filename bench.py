@@ -94,15 +94,22 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    # stage boundaries -> HIP events on the launch stream (torch's current stream IS the stream
-    # every ms_* call is enqueued on), recorded inside the timed region
-    marks = []
+    # stage boundaries -> HIP events recorded by ms_render_fwd on the launch stream (torch's
+    # current stream, whose handle is what every ms_* call is given), inside the timed region
     stage_events = []
+    pool = []
+    if world == 1:  # created (and recorded once, so the hipEvent_t exists) outside the timed region
+        for _ in range(args.steps):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            for e in evs:
+                e.record()
+            pool.append(evs)
+        torch.cuda.synchronize()
 
-    def hook(name):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        marks.append((name, ev))
+    def hook():
+        evs = pool.pop()
+        stage_events.append(evs)
+        return evs
 
     if world == 1:
         render_mod._STAGE_HOOK = hook
@@ -110,9 +117,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if marks:
-            stage_events.append(list(marks))
-            marks.clear()
     barrier()
     dt = time.perf_counter() - t0
     render_mod._STAGE_HOOK = None
@@ -126,10 +130,11 @@ def main():
 
     stage_us = {}
     if stage_events:
-        acc = {}
+        names = ("project", "bin", "raster")
+        acc = {n: [] for n in names}
         for evs in stage_events:
-            for (n0, e0), (n1, e1) in zip(evs[:-1], evs[1:]):
-                acc.setdefault(n1, []).append(e0.elapsed_time(e1) * 1e3)
+            for i, n in enumerate(names):
+                acc[n].append(evs[i].elapsed_time(evs[i + 1]) * 1e3)
         stage_us = {k: sum(v) / len(v) for k, v in acc.items()}
 
     out = None

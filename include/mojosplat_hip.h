@@ -24,8 +24,9 @@
  *     including scratch; the library never allocates device memory and keeps no state;
  *   - all pointers are DEVICE pointers unless a parameter says "host"; tensors are
  *     contiguous row-major with the layouts written next to each parameter;
- *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); nothing
- *     here synchronises, so calls can be captured into a hipGraph;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); the per-stage
+ *     entry points never synchronise, so they can be captured into a hipGraph (the one
+ *     exception, ms_render_fwd, says so below);
  *   - every function returns 0 on success or a non-zero ms_status; no C++ exception
  *     crosses this boundary.  ms_last_error_string() describes the last failure on the
  *     calling thread.
@@ -162,6 +163,33 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
                              const int32_t *radii, const float *v_means2d,
                              const float *v_conics, const float *v_depths, float *v_means3d,
                              float *v_scales, float *v_quats, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Whole forward path in one call: replaces the three stage calls that
+ * render_gaussians makes (mojosplat/render.py:63-101) when the caller does not need the
+ * intermediates.  Projection outputs, tile ranges and the sorted list live in caller-owned
+ * scratch:
+ *   workspace  : ms_render_workspace_bytes(N, tile_w, tile_h) bytes, fixed per (N, image);
+ *   isect_buf  : ms_render_isect_bytes(M, merge) bytes, data dependent.  If it is too small
+ *                the call returns MS_ERR_WORKSPACE with host_info[5] = bytes needed and all
+ *                M-independent work done; grow the buffer and call again with resume = 1.
+ *   host_info  : HOST memory (pinned), i64[8]; receives isect_info (see
+ *                ms_isect_tiles_count).  This call performs ONE hipStreamSynchronize to read
+ *                it -- the only synchronising entry point of the library.
+ *   stage_events: NULL, or 4 hipEvent_t recorded on `stream` at: start, after projection,
+ *                after binning, after rasterisation (for in-situ kernel timing).
+ * M == 0 yields a ZERO image (reference render.py:73-76), otherwise
+ * render_colors f32[H,W,CDIM] = composited colours + T * background.
+ * ------------------------------------------------------------------------------------- */
+size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h);
+size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch);
+int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                  const float *quats, const float *opacities, const void *colors, int color_dtype,
+                  int CDIM, const float *viewmat, float fx, float fy, float cx, float cy, int W,
+                  int H, float eps2d, float near_plane, float far_plane, int tile_size,
+                  const float *backgrounds, void *workspace, size_t workspace_bytes,
+                  void *isect_buf, size_t isect_bytes, int64_t *host_info, int resume,
+                  float *render_colors, void **stage_events, void *stream);
 
 #ifdef __cplusplus
 }

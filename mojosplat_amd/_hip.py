@@ -41,6 +41,12 @@ _SIGNATURES = {
                                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ms_render_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "ms_render_isect_bytes": (c_size_t, [c_int64, c_int]),
+    "ms_render_fwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_void_p, c_float, c_float, c_float, c_float, c_int, c_int, c_float, c_float,
+                              c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p,
+                              c_int, c_void_p, c_void_p, c_void_p]),
     "ms_project_gaussians_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                          c_float, c_float, c_float, c_float, c_int, c_int, c_float,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -48,9 +54,7 @@ _SIGNATURES = {
 }
 
 # entry points added after ABI v1's first cut; bound when present
-_OPTIONAL = {
-    "ms_render_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-}
+_OPTIONAL = {}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1,0 +1,110 @@
+// ms_render_fwd: the whole device side of render_gaussians (reference mojosplat/render.py:63-101:
+// project -> bin/sort -> rasterise) behind ONE C call, so a frame costs one host->library
+// transition instead of five and no Python runs between the kernels.
+//
+// The only host<->device hand-off is the intersection count M (and the per-class tile counts)
+// between the counting and the emitting half of the binning stage -- the same place
+// gsplat.isect_tiles has its own (reference call site mojosplat/binning.py:73-82).  Everything
+// else is enqueued back to back on the caller's stream.
+#include "ms_common.hpp"
+
+namespace {
+
+struct WsLayout {
+    size_t off_isect, isect_bytes, off_means2d, off_conics, off_depths, off_radii, off_ranges, off_info, total;
+};
+
+WsLayout ws_layout(int64_t N, int tw, int th) {
+    WsLayout L;
+    size_t o = 0;
+    const size_t n = (size_t)(N > 0 ? N : 1), T = (size_t)tw * th;
+    L.off_isect = o;   L.isect_bytes = ms_isect_workspace_bytes(N, tw, th); o += ms::align_up(L.isect_bytes, 256);
+    L.off_means2d = o; o += ms::align_up(n * 8, 256);
+    L.off_conics = o;  o += ms::align_up(n * 12, 256);
+    L.off_depths = o;  o += ms::align_up(n * 4, 256);
+    L.off_radii = o;   o += ms::align_up(n * 8, 256);
+    L.off_ranges = o;  o += ms::align_up(T * 8, 256);
+    L.off_info = o;    o += 256;
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h) {
+    if (tile_w <= 0 || tile_h <= 0 || (int64_t)tile_w * tile_h >= (1ll << 30)) return 0;
+    return ws_layout(N, tile_w, tile_h).total;
+}
+
+extern "C" size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch) {
+    const size_t m = (size_t)(M > 0 ? M : 1);
+    return ms::align_up(m * 8, 256) * (with_merge_scratch ? 2 : 1) + ms::align_up(m * 4, 256);
+}
+
+extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                             const float *quats, const float *opacities, const void *colors,
+                             int color_dtype, int CDIM, const float *viewmat, float fx, float fy,
+                             float cx, float cy, int W, int H, float eps2d, float near_plane,
+                             float far_plane, int tile_size, const float *backgrounds,
+                             void *workspace, size_t workspace_bytes, void *isect_buf,
+                             size_t isect_bytes, int64_t *host_info, int resume,
+                             float *render_colors, void **stage_events, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "render_fwd: bad sizes");
+    MS_REQUIRE(workspace && host_info && render_colors, MS_ERR_INVALID_ARG, "render_fwd: null pointer");
+    const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+    const WsLayout L = ws_layout(N, tw, th);
+    MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_fwd: workspace %zu < %zu", workspace_bytes,
+               L.total);
+    char *ws = (char *)workspace;
+    float *means2d = (float *)(ws + L.off_means2d), *conics = (float *)(ws + L.off_conics);
+    float *depths = (float *)(ws + L.off_depths);
+    int32_t *radii = (int32_t *)(ws + L.off_radii), *ranges = (int32_t *)(ws + L.off_ranges);
+    int64_t *info = (int64_t *)(ws + L.off_info);
+    auto mark = [&](int i) {
+        if (stage_events && stage_events[i]) (void)hipEventRecord((hipEvent_t)stage_events[i], stream);
+    };
+
+    if (!resume) {
+        mark(0);
+        if (int rc = ms_project_gaussians_fwd(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
+                                              cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, means2d, conics,
+                                              depths, radii, stream))
+            return rc;
+        mark(1);
+        if (int rc = ms_isect_tiles_count(N, means2d, radii, tile_size, tw, th, 0, th, ws + L.off_isect,
+                                          L.isect_bytes, nullptr, ranges, info, stream))
+            return rc;
+        MS_HIP(hipMemcpyAsync(host_info, info, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        MS_HIP(hipStreamSynchronize(stream));  // the one size hand-off of a frame
+    }
+    const int64_t M = host_info[0], n_xl = host_info[4];
+    MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld intersections do not fit int32",
+               (long long)M);
+    if (M == 0) {  // the reference returns a zeros image here, not the background (render.py:73-76)
+        MS_HIP(hipMemsetAsync(render_colors, 0, (size_t)H * W * CDIM * sizeof(float), stream));
+        mark(2);
+        mark(3);
+        return MS_OK;
+    }
+    const size_t need = ms_render_isect_bytes(M, n_xl > 0);
+    host_info[5] = (int64_t)need;
+    MS_REQUIRE(isect_buf && isect_bytes >= need, MS_ERR_WORKSPACE,
+               "render_fwd: intersection buffer %zu < %zu (grow it and call again with resume=1)", isect_bytes,
+               need);
+    char *ib = (char *)isect_buf;
+    const size_t key_bytes = ms::align_up((size_t)M * 8, 256);
+    uint64_t *keys = (uint64_t *)ib;
+    uint64_t *tmp = n_xl > 0 ? (uint64_t *)(ib + key_bytes) : nullptr;
+    int32_t *ids = (int32_t *)(ib + key_bytes * (n_xl > 0 ? 2 : 1));
+    if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, 0, th, ws + L.off_isect,
+                                     L.isect_bytes, ranges, host_info, keys, tmp, ids, nullptr, stream))
+        return rc;
+    mark(2);
+    if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, M, means2d, conics, colors, color_dtype, CDIM, opacities,
+                                                 backgrounds, W, H, tile_size, 0, th, ranges, ids, render_colors,
+                                                 nullptr, nullptr, stream))
+        return rc;
+    mark(3);
+    return MS_OK;
+}

@@ -6,27 +6,37 @@
 // alpha = min(0.999, o exp(-sigma)); skip if sigma < 0 or alpha < 1/255; stop BEFORE adding
 // when T(1-alpha) <= 1e-4; out = pix + T * background.
 //
-// MI355X mapping (v2).  The v1 kernel (256 threads per 16x16 block, one pixel per lane, like
-// the reference's launch at rasterization.mojo:219-220) was bound by LDS *broadcast* reads:
-// every wave re-reads every staged Gaussian, 48 LDS cycles per (tile, Gaussian) against 24
-// VALU cycles.  Here ONE wave64 owns a whole 16x16 block and every lane carries four pixels
-// (the same lane position in each of the four 8x8 quads), so a staged Gaussian is read from
-// LDS once per block (12 cycles) and the exp2/blend work of four pixels shares it.
-//   * staging: 64 intersections per batch, one per lane; the lane that stages a Gaussian also
-//     folds log2(e) into its conic, takes log2(opacity), and computes which of the four quads
-//     the alpha >= 1/255 ellipse can touch (exact bounding box of that ellipse + slack) -> a
-//     4-bit mask stored with the record;
-//   * inner loop: the mask is wave-uniform (readfirstlane -> scalar branch), so quads the
-//     Gaussian cannot reach cost nothing; v_exp_f32 is exp2, so alpha = exp2(q + log2 o);
+// MI355X mapping.  Measured history of this kernel on BASELINE config 3 (profiles/):
+//   v1  256 threads per 16x16 block, one pixel per lane (the reference's launch shape,
+//       rasterization.mojo:219-220): 368 us, bound by LDS *broadcast* reads -- each of the four
+//       waves re-reads every staged Gaussian, 48 LDS cycles per (tile, Gaussian);
+//   v2  one wave64 per block, four pixels per lane, per-entry quad mask + scalar branches: 237 us,
+//       VALU issue only 40 % busy (ten scalar branches per entry);
+//   v3  (this file) per-quad ballot masks and a branch-free blend: 200 us at 80 % VALU busy --
+//       a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
+//       = 4.1), so ~96 M instructions over 1024 SIMDs at 2.3 GHz are 164 us of pure issue time.
+//
+//   * ONE wave64 owns a 16x16 block; every lane carries four pixels (the same lane position in
+//     each of the four 8x8 quads), so a staged Gaussian is read from LDS once per block;
+//   * staging: 64 intersections per batch, one per lane.  The staging lane folds log2(e) into
+//     the conic, takes log2(opacity), and tests which quads the alpha >= 1/255 ellipse can reach
+//     (exact bounding box of that ellipse + slack).  The wave then votes: B[q] = ballot(entry
+//     reaches quad q) -- a wave-uniform 64-bit mask per quad, no LDS;
+//   * compositing: each quad walks ITS set bits in order with scalar s_ff1 (front-to-back per
+//     pixel is preserved: the four quads are disjoint pixel sets).  Culled (quad, entry) pairs
+//     cost nothing; one scalar branch per evaluation (the loop); v_exp_f32 is exp2, so
+//     log2(alpha) comes out of one FMA chain; blend/stop are selects, and a finished pixel
+//     raises its own alpha threshold to +inf, which folds "still live" into the 1/255 compare;
 //   * colours sit in LDS with the geometry (the reference gathers them from global memory in
-//     the per-pixel loop, rasterization.mojo:154-155) and are only read when some lane of the
-//     wave actually blends;
-//   * the next batch's gather (ids -> means/conics/opacity/colour, 36 B per intersection) is
-//     issued into registers before the current batch is composited; the wave leaves the list
-//     as soon as all 256 pixels are saturated (checked per batch of 64);
-//   * blockIdx -> tile mapping hands each XCD a contiguous run of tiles so that neighbouring
-//     tiles, which share most of their Gaussians, gather through the same L2.
+//     the per-pixel loop, rasterization.mojo:154-155);
+//   * the next batch's gather (36 B per intersection from 4 arrays) and the ids of the batch
+//     after it are in flight while the current batch is composited; a quad whose 64 pixels are
+//     saturated is skipped, and the wave leaves when all four are (checked per batch);
+//   * blockIdx -> tile: each XCD (blocks are dealt round-robin over the 8) gets runs of 8
+//     consecutive tiles (neighbours share most of their Gaussians -> same L2), interleaved over
+//     the whole image so the heavy centre of a frame is spread over all XCDs.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "ms_common.hpp"
 
@@ -63,37 +73,54 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return ((k >> 3) << 6) | (xcd << 3) | (k & 7);
 }
 
-// CP = compile-time channel capacity (>= runtime cdim); CS = LDS stride of a colour record
-template <int CP, typename ColorT>
-__global__ __launch_bounds__(64) void k_rasterize_fwd(RasterArgs A) {
-    constexpr int CS = (CP == 3) ? 4 : CP;
-    __shared__ float4 s_a[kBatch + 1];        // mean.x, mean.y, a', b'
-    __shared__ float4 s_b[kBatch + 1];        // c', log2(opacity), quad mask (bits), -
-    __shared__ float s_col[kBatch * CS];
+// ---- the kernel ------------------------------------------------------------------------------
+// CP = compile-time channel capacity (>= runtime cdim).
+// The staging lanes vote: B[q] = ballot(entry reaches quad q) -- a wave-uniform 64-bit mask per
+// quad.  Each quad then walks ITS set bits in order (front-to-back per pixel is preserved: the
+// four quads are disjoint pixel sets), so culled (quad, entry) pairs cost nothing, there is one
+// scalar branch per evaluation (the loop), and blend/stop are selects.  A finished pixel
+// raises its own alpha threshold to +inf, which folds the "still live" test into the
+// alpha >= 1/255 compare.
+// Waves are fully independent (one 16x16 block each, private LDS slice); WPB of them share a
+// workgroup only to fill the CU's wave slots -- there is no workgroup barrier anywhere.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
-    const int item = xcd_remap(blockIdx.x, A.nblocks);
+template <int CP, typename ColorT, bool AUX, int WPB>
+__global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(RasterArgs A) {
+    constexpr int CS = (CP == 3) ? 4 : CP;       // CP == 3: r,g ride in s_b; b alone at a 16-B stride (same LDS index as s_a/s_b)
+    __shared__ float4 s_a_all[WPB][kBatch];      // mean.x, mean.y, a', b'
+    __shared__ float4 s_b_all[WPB][kBatch];      // c', log2(opacity), (r, g | -, -)
+    __shared__ float s_col_all[WPB][kBatch * CS];
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *s_a = s_a_all[wib], *s_b = s_b_all[wib];
+    float *s_col = s_col_all[wib];
+
+    const int vbid = blockIdx.x * WPB + wib;
+    if (vbid >= A.nblocks) return;
+    const int item = xcd_remap(vbid, A.nblocks);
     const int bt = item / A.nsub, sub = item - bt * A.nsub;
     const int tile = A.tile0 + bt;
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int lx = lane & 7, ly = lane >> 3;
-    const int bx = tile_x * A.ts + sub_x * 16, by = tile_y * A.ts + sub_y * 16;  // block origin (pixels)
-    const int ox = sub_x * 16 + lx, oy = sub_y * 16 + ly;                        // offset inside the tile (quad 0)
+    const int bx = tile_x * A.ts + sub_x * 16, by = tile_y * A.ts + sub_y * 16;
+    const int ox = sub_x * 16 + lx, oy = sub_y * 16 + ly;
+    const float px0 = (float)(bx + lx) + 0.5f, py0 = (float)(by + ly) + 0.5f;
 
-    // pixel q of this lane: quad (q&1, q>>1)
-    float px[2], py[2];
-    px[0] = (float)(bx + lx) + 0.5f;      px[1] = px[0] + 8.0f;
-    py[0] = (float)(by + ly) + 0.5f;      py[1] = py[0] + 8.0f;
-    bool inside[4];
-    float T[4];            // > 0: transmittance of a live pixel; < 0: -(transmittance) of a finished one
-    float pix[4][CP];
+    constexpr float kInf = __builtin_huge_valf();
+    float T[4], thr[4], pix[4][CP];
     int last[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int X = bx + lx + (q & 1) * 8, Y = by + ly + (q >> 1) * 8;
-        inside[q] = (ox + (q & 1) * 8) < A.ts && (oy + (q >> 1) * 8) < A.ts && X < A.W && Y < A.H;
-        T[q] = inside[q] ? 1.0f : -1.0f;
+        const bool in = (ox + (q & 1) * 8) < A.ts && (oy + (q >> 1) * 8) < A.ts && X < A.W && Y < A.H;
+        T[q] = 1.0f;
+        thr[q] = in ? ms::kAlphaThreshold : kInf;
         last[q] = 0;
 #pragma unroll
         for (int k = 0; k < CP; ++k) pix[q][k] = 0.f;
@@ -101,13 +128,11 @@ __global__ __launch_bounds__(64) void k_rasterize_fwd(RasterArgs A) {
 
     const int start = A.tile_ranges[2 * tile], end = A.tile_ranges[2 * tile + 1];
     const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
-    // quad rectangles (pixel-centre extents) for the staging-time culling test
-    const float qx_lo[2] = {(float)bx + 0.5f, (float)bx + 8.5f}, qy_lo[2] = {(float)by + 0.5f, (float)by + 8.5f};
+    const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
 
-    // registers for the batch being gathered
     float r_mx = 0.f, r_my = 0.f, r_ca = 0.f, r_cb = 0.f, r_cc = 0.f, r_op = 0.f;
     float r_col[CP];
-    int r_g = 0;  // Gaussian id of the batch after the one being gathered (ids run one batch ahead)
+    int r_g = 0;
     auto fetch_id = [&](int b0) {
         const int idx = b0 + lane;
         r_g = idx < end ? A.flatten_ids[idx] : 0;
@@ -131,101 +156,116 @@ __global__ __launch_bounds__(64) void k_rasterize_fwd(RasterArgs A) {
         fetch_id(start + kBatch);
     }
     for (int b0 = start; b0 < end; b0 += kBatch) {
-        __syncthreads();  // single-wave workgroup: orders LDS reads of the previous batch
-        if (b0 + lane < end) {
-            // which quads can the alpha >= 1/255 ellipse reach?  sigma <= ln(255 o) =: smax;
-            // its bounding box is mean +- sqrt(2 smax cov_xx|yy), cov = conic^-1.
-            int mask = 0;
+        // --- stage this batch: record -> LDS, reach of the alpha >= 1/255 ellipse -> quad votes
+        int mask = 0;
+        if (b0 + lane < end && r_op >= ms::kAlphaThreshold) {
             const float det = r_ca * r_cc - r_cb * r_cb;
-            if (r_op >= ms::kAlphaThreshold) {
-                if (det > 0.f && r_ca > 0.f && r_cc > 0.f) {
-                    const float smax2 = 2.0f * __logf(r_op * 255.0f) * 1.0001f + 1e-4f;
-                    const float inv = 1.0f / det;
-                    const float hx = sqrtf(smax2 * r_cc * inv) * 1.0001f + 0.01f;
-                    const float hy = sqrtf(smax2 * r_ca * inv) * 1.0001f + 0.01f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float xl = qx_lo[q & 1], yl = qy_lo[q >> 1];
-                        const bool hit = (r_mx + hx >= xl) && (r_mx - hx <= xl + 7.0f) && (r_my + hy >= yl) &&
-                                         (r_my - hy <= yl + 7.0f);
-                        mask |= hit ? (1 << q) : 0;
-                    }
-                } else {
-                    mask = 0xf;  // not positive definite: no bound, evaluate everywhere
-                }
+            if (det > 0.f && r_ca > 0.f && r_cc > 0.f) {
+                // sigma <= ln(255 o): bounding box mean +- sqrt(2 ln(255 o) cov_xx|yy), cov = conic^-1
+                const float smax2 = 2.0f * __logf(r_op * 255.0f) * 1.0001f + 1e-4f;
+                const float inv = 1.0f / det;
+                const float hx = sqrtf(smax2 * r_cc * inv) * 1.0001f + 0.01f;
+                const float hy = sqrtf(smax2 * r_ca * inv) * 1.0001f + 0.01f;
+                const bool x0 = (r_mx + hx >= fbx) && (r_mx - hx <= fbx + 7.0f);
+                const bool x1 = (r_mx + hx >= fbx + 8.0f) && (r_mx - hx <= fbx + 15.0f);
+                const bool y0 = (r_my + hy >= fby) && (r_my - hy <= fby + 7.0f);
+                const bool y1 = (r_my + hy >= fby + 8.0f) && (r_my - hy <= fby + 15.0f);
+                mask = (x0 && y0 ? 1 : 0) | (x1 && y0 ? 2 : 0) | (x0 && y1 ? 4 : 0) | (x1 && y1 ? 8 : 0);
+            } else {
+                mask = 0xf;  // not positive definite: no bound, evaluate everywhere
             }
-            s_a[lane] = make_float4(r_mx, r_my, -0.5f * kLog2e * r_ca, -kLog2e * r_cb);
-            s_b[lane] = make_float4(-0.5f * kLog2e * r_cc, __log2f(r_op), __int_as_float(mask), 0.f);
-#pragma unroll
-            for (int k = 0; k < CP; ++k) s_col[lane * CS + k] = r_col[k];
         }
-        __syncthreads();
-        if (b0 + kBatch < end) {  // both in flight while this batch is composited
+        unsigned long long B[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) B[q] = __ballot((mask >> q) & 1);
+
+        wave_lds_sync();  // LDS reads of the previous batch are complete
+        if (mask) {
+            s_a[lane] = make_float4(r_mx, r_my, -0.5f * kLog2e * r_ca, -kLog2e * r_cb);
+            if constexpr (CP == 3) {
+                s_b[lane] = make_float4(-0.5f * kLog2e * r_cc, __log2f(r_op), r_col[0], r_col[1]);
+                s_col[lane * CS] = r_col[2];
+            } else {
+                s_b[lane] = make_float4(-0.5f * kLog2e * r_cc, __log2f(r_op), 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < CP; ++k) s_col[lane * CS + k] = r_col[k];
+            }
+        }
+        wave_lds_sync();
+        if (b0 + kBatch < end) {  // next batch's data and the one after's ids fly during compositing
             gather(b0 + kBatch);
             fetch_id(b0 + 2 * kBatch);
         }
 
-        const int bs = min(kBatch, end - b0);
-        float4 na = s_a[0], nb = s_b[0];
-        for (int t = 0; t < bs; ++t) {
-            const float4 ra = na, rb = nb;
-            na = s_a[t + 1];  // next record in flight while this one is composited (slot bs is slack)
-            nb = s_b[t + 1];
-            const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(rb.z));
-            if (mask == 0) continue;
-            float col[CP];
-            if constexpr (CS == 4 && CP == 3) {
-                const float4 c = reinterpret_cast<const float4 *>(s_col)[t];
-                col[0] = c.x; col[1] = c.y; col[2] = c.z;
-            } else {
+        bool any_live = false;
 #pragma unroll
-                for (int k = 0; k < CP; ++k) col[k] = s_col[t * CS + k];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!(mask & (1 << q))) continue;  // wave-uniform
-                const float dx = ra.x - px[q & 1], dy = ra.y - py[q >> 1];
-                const float pw = dx * (ra.z * dx + ra.w * dy) + rb.x * dy * dy;  // = -sigma*log2(e)
-                const float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(pw + rb.y));
-                const bool hit = T[q] > 0.f && pw <= 0.f && alpha >= ms::kAlphaThreshold;
-                if (!__any(hit)) continue;
-                const float next_T = T[q] * (1.0f - alpha);
-                const bool stop = hit && next_T <= ms::kTransmittanceStop;
-                const bool add = hit && !stop;
+        for (int q = 0; q < 4; ++q) {
+            if (!__any(thr[q] < kInf)) continue;  // every pixel of this quad is finished (or outside)
+            const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
+            unsigned long long m = B[q];
+            while (m) {
+                const int t = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float4 ra = s_a[t];
+                const float4 rb = s_b[t];
+                const float dx = ra.x - px, dy = ra.y - py;
+                // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
+                const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
+                const float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
+                const bool hit = la <= rb.y && alpha >= thr[q];          // sigma >= 0 and alpha >= 1/255, live
+                const float next_T = fmaf(-alpha, T[q], T[q]);           // T (1 - alpha)
+                const bool add = hit && next_T > ms::kTransmittanceStop;
                 const float vis = add ? alpha * T[q] : 0.f;
+                if constexpr (CP == 3) {
+                    pix[q][0] += rb.z * vis;
+                    pix[q][1] += rb.w * vis;
+                    pix[q][2] += s_col[t * CS] * vis;
+                } else {
 #pragma unroll
-                for (int k = 0; k < CP; ++k) pix[q][k] += col[k] * vis;
-                last[q] = add ? b0 + t : last[q];
-                T[q] = add ? next_T : (stop ? -T[q] : T[q]);
+                    for (int k = 0; k < CP; ++k) pix[q][k] += s_col[t * CS + k] * vis;
+                }
+                if constexpr (AUX) last[q] = add ? b0 + t : last[q];
+                T[q] = add ? next_T : T[q];
+                thr[q] = (hit && !add) ? kInf : thr[q];  // stop BEFORE adding: the pixel is finished
             }
+            any_live = any_live || __any(thr[q] < kInf);
         }
-        const bool live = T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f;
-        if (!__any(live)) break;
+        if (!any_live) break;
     }
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (!inside[q]) continue;
         const int X = bx + lx + (q & 1) * 8, Y = by + ly + (q >> 1) * 8;
+        const bool in = (ox + (q & 1) * 8) < A.ts && (oy + (q >> 1) * 8) < A.ts && X < A.W && Y < A.H;
+        if (!in) continue;
         const size_t p = (size_t)Y * A.W + X;
-        const float Tq = fabsf(T[q]);
 #pragma unroll
         for (int k = 0; k < CP; ++k)
             if (k < A.cdim)
-                A.render_colors[p * A.cdim + k] = pix[q][k] + (A.backgrounds ? Tq * A.backgrounds[k] : 0.f);
-        if (A.render_alphas) A.render_alphas[p] = 1.0f - Tq;
-        if (A.last_ids) A.last_ids[p] = last[q];
+                A.render_colors[p * A.cdim + k] = pix[q][k] + (A.backgrounds ? T[q] * A.backgrounds[k] : 0.f);
+        if constexpr (AUX) {
+            if (A.render_alphas) A.render_alphas[p] = 1.0f - T[q];
+            if (A.last_ids) A.last_ids[p] = last[q];
+        }
     }
+}
+
+template <int CP, typename ColorT>
+void launch_cp(const RasterArgs &A, hipStream_t stream) {
+    const dim3 grid((unsigned)A.nblocks), block(64);
+    if (A.render_alphas || A.last_ids)
+        hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, true, 1>), grid, block, 0, stream, A);
+    else
+        hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 1>), grid, block, 0, stream, A);
 }
 
 template <typename ColorT>
 int launch_fwd(const RasterArgs &A, hipStream_t stream) {
-    const dim3 grid((unsigned)A.nblocks), block(64);
-    if (A.cdim == 3) hipLaunchKernelGGL((k_rasterize_fwd<3, ColorT>), grid, block, 0, stream, A);
-    else if (A.cdim <= 4) hipLaunchKernelGGL((k_rasterize_fwd<4, ColorT>), grid, block, 0, stream, A);
-    else if (A.cdim <= 8) hipLaunchKernelGGL((k_rasterize_fwd<8, ColorT>), grid, block, 0, stream, A);
-    else if (A.cdim <= 16) hipLaunchKernelGGL((k_rasterize_fwd<16, ColorT>), grid, block, 0, stream, A);
-    else hipLaunchKernelGGL((k_rasterize_fwd<32, ColorT>), grid, block, 0, stream, A);
+    if (A.cdim == 3) launch_cp<3, ColorT>(A, stream);
+    else if (A.cdim <= 4) launch_cp<4, ColorT>(A, stream);
+    else if (A.cdim <= 8) launch_cp<8, ColorT>(A, stream);
+    else if (A.cdim <= 16) launch_cp<16, ColorT>(A, stream);
+    else launch_cp<32, ColorT>(A, stream);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }

@@ -18,13 +18,10 @@ from .utils import Camera
 
 TILE_SIZE = 16
 
-# bench.py installs a callable here to drop HIP events at the stage boundaries; None = no cost
+# bench.py installs a callable here that returns 4 (already recorded once) torch.cuda.Event
+# objects per frame; ms_render_fwd re-records them on the launch stream at: start, after
+# projection, after binning, after rasterisation.  None = no events.
 _STAGE_HOOK = None
-
-
-def _mark(name):
-    if _STAGE_HOOK is not None:
-        _STAGE_HOOK(name)
 
 
 @torch.no_grad()
@@ -56,13 +53,22 @@ def render_gaussians(
                          f"channels ({num_channels})")
     assert opacities.shape == (means3d.shape[0],)
 
-    _mark("start")
+    if backend == "hip":
+        # one library call for the whole frame (ms_render_fwd); same stages, same results as the
+        # three calls below, without Python between the kernels
+        from ._fused import render_fwd_hip
+        colors = features
+        if sh_degree is not None and features.shape[-1] > 3:
+            colors, bg = features[..., :3], bg[:3]  # the reference's placeholder (render.py:82-87)
+        evs = _STAGE_HOOK() if _STAGE_HOOK is not None else None
+        img, _ = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
+                                stage_events=evs)
+        return img
+
     means2d, conics, depths, radii = project_gaussians(means3d, scales, quats, opacities, camera,
                                                        backend=backend)
-    _mark("project")
     sorted_ids, tile_ranges = bin_gaussians_to_tiles(means2d, radii, depths, camera.H, camera.W,
                                                      tile_size, backend=backend)
-    _mark("bin")
     if sorted_ids.numel() == 0:
         return torch.zeros(camera.H, camera.W, num_channels, device=means3d.device,
                            dtype=features.dtype)
@@ -72,7 +78,5 @@ def render_gaussians(
         colors = features[..., :3]  # same placeholder as the reference (render.py:82-87)
         bg = bg[:3]
 
-    img = rasterize_gaussians(means2d, conics, colors, opacities, bg, tile_ranges, sorted_ids,
-                              camera, tile_size=tile_size, backend=backend)
-    _mark("raster")
-    return img
+    return rasterize_gaussians(means2d, conics, colors, opacities, bg, tile_ranges, sorted_ids,
+                               camera, tile_size=tile_size, backend=backend)
