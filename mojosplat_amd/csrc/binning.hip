@@ -232,8 +232,8 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
 // Main path: ONE counting pass on the depth bits.  (depth_bits - min) >> shift maps the tile's
 // depth span order-preservingly onto B ~ n buckets (float bits are monotone in depth for the
 // positive depths that survive projection); an LDS histogram + scan + scatter puts every key
-// into its bucket, and each bucket -- 0..3 keys typically -- is finished by one lane with an
-// insertion sort on the full 64-bit key.  ~6 barriers per tile instead of the O(log^2 n) of a
+// into its bucket, and inside a bucket -- 0..3 keys typically -- every key counts the keys
+// smaller than itself (full 64-bit compare) and moves to that rank.  ~6 barriers per tile instead of the O(log^2 n) of a
 // bitonic network.  If some bucket is crowded (many identical depths) the tile falls back to
 // the bitonic network below, which is oblivious to the key distribution.
 template <int THREADS>
@@ -258,13 +258,13 @@ __device__ __forceinline__ int next_pow2(int n) {
     return p;
 }
 
-constexpr int kMaxBuckets = 4096;
+constexpr int kMaxBuckets = 4096;  // bucket-array cap for classes beyond 4096 keys
 constexpr int kBucketFallback = 48;  // a bucket this crowded sends the tile to the bitonic path
 
 template <int THREADS, int E>
 struct SortCfg {
     static constexpr int CAP = THREADS * E;
-    static constexpr int NB = CAP < kMaxBuckets ? CAP : kMaxBuckets;
+    static constexpr int NB = CAP <= kMaxBuckets ? 2 * CAP : kMaxBuckets;  // ~2 buckets per key
     static constexpr size_t LDS = (size_t)CAP * 8 + (size_t)NB * 4 + 64 * 4;
 };
 
@@ -300,7 +300,7 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
         kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
     }
     if (lane == 0) { s_red[w] = kmin; s_red[16 + w] = kmax; }
-    const int B = min(Cfg::NB, max(64, next_pow2(n)));
+    const int B = min(Cfg::NB, max(64, 2 * next_pow2(n)));
     for (int b = tid; b < B; b += THREADS) s_cnt[b] = 0;
     __syncthreads();
 #pragma unroll
@@ -361,17 +361,27 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
         }
     __syncthreads();
 
-    // 5. finish: insertion sort per bucket, or the oblivious network when a bucket is crowded
+    // 5. finish.  Every key ranks itself inside its bucket (reads only: k independent LDS loads
+    //    for a bucket of k keys, no divergent dependent chains), barrier, then drops into place.
+    //    Keys are distinct, so ranks are a permutation.  A crowded bucket (many identical depths)
+    //    sends the tile to the oblivious network instead.
     if (cmax <= (uint32_t)kBucketFallback) {
-        for (int b = tid; b < B; b += THREADS) {
-            const int beg = b ? (int)s_cnt[b - 1] : 0, end = (int)s_cnt[b];
-            for (int i = beg + 1; i < end; ++i) {
-                const uint64_t v = s_out[i];
-                int j = i - 1;
-                while (j >= beg && s_out[j] > v) { s_out[j + 1] = s_out[j]; --j; }
-                s_out[j + 1] = v;
+        int dest[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            dest[e] = -1;
+            if (e * THREADS + tid < n) {
+                const uint32_t b = ((uint32_t)(k[e] >> 32) - kmin) >> shift;
+                const int beg = b ? (int)s_cnt[b - 1] : 0, end = (int)s_cnt[b];
+                int r = 0;
+                for (int j = beg; j < end; ++j) r += s_out[j] < k[e] ? 1 : 0;
+                dest[e] = beg + r;
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (dest[e] >= 0) s_out[dest[e]] = k[e];
     } else {
         const int P = max(2, next_pow2(n));
         for (int i = n + tid; i < P; i += THREADS) s_out[i] = ~0ull;
