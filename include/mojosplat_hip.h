@@ -174,8 +174,12 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  *                the call returns MS_ERR_WORKSPACE with host_info[5] = bytes needed and all
  *                M-independent work done; grow the buffer and call again with resume = 1.
  *   host_info  : HOST memory (pinned), i64[8]; receives isect_info (see
- *                ms_isect_tiles_count).  This call performs ONE hipStreamSynchronize to read
- *                it -- the only synchronising entry point of the library.
+ *                ms_isect_tiles_count).  This is the only entry point that waits on the
+ *                device: with sync_event == NULL one hipStreamSynchronize between count and
+ *                emit; with a hipEvent_t in sync_event and an isect_buf sized by an earlier
+ *                frame, emit + rasterise are enqueued speculatively against the buffer's
+ *                capacity BEFORE the wait, so the GPU never idles (an overflowing frame is
+ *                detected and redone on the exact path).
  *   stage_events: NULL, or 4 hipEvent_t recorded on `stream` at: start, after projection,
  *                after binning, after rasterisation (for in-situ kernel timing).
  * M == 0 yields a ZERO image (reference render.py:73-76), otherwise
@@ -189,7 +193,19 @@ int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scal
                   int H, float eps2d, float near_plane, float far_plane, int tile_size,
                   const float *backgrounds, void *workspace, size_t workspace_bytes,
                   void *isect_buf, size_t isect_bytes, int64_t *host_info, int resume,
-                  float *render_colors, void **stage_events, void *stream);
+                  float *render_colors, void **stage_events, void *sync_event, void *stream);
+
+/* ms_isect_tiles_emit without the host knowing M: `isect_info_dev` is the DEVICE record written
+ * by ms_isect_tiles_count, `capacity` the number of entries sort_keys / flatten_ids can hold.
+ * Every kernel clamps to the capacity; the caller must afterwards check (from its own copy of
+ * the record) that M <= capacity and that no tile is in the merge-fallback class, and redo the
+ * frame with ms_isect_tiles_emit otherwise.  Used by ms_render_fwd for sync-free frames. */
+int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, const int32_t *radii,
+                                    const float *depths, int tile_size, int tile_w, int tile_h,
+                                    int row_begin, int row_end, void *workspace,
+                                    size_t workspace_bytes, const int32_t *tile_ranges,
+                                    const int64_t *isect_info_dev, int64_t capacity,
+                                    uint64_t *sort_keys, int32_t *flatten_ids, void *stream);
 
 #ifdef __cplusplus
 }

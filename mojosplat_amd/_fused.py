@@ -20,7 +20,10 @@ _state = {}  # device -> dict(ws, isect, host)
 def _dev_state(dev):
     st = _state.get(dev)
     if st is None:
-        st = dict(ws=None, isect=None, host=torch.zeros(8, dtype=torch.int64).pin_memory())
+        ev = torch.cuda.Event()
+        with torch.cuda.device(dev):
+            ev.record()  # materialises the hipEvent_t the library re-records for its size hand-off
+        st = dict(ws=None, isect=None, host=torch.zeros(8, dtype=torch.int64).pin_memory(), ev=ev)
         _state[dev] = st
     return st
 
@@ -71,7 +74,8 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
             _hip.ptr(vm), camera.fx, camera.fy, camera.cx, camera.cy, W, H, EPS2D, camera.near, camera.far,
             tile_size, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
             0 if isect is None else isect.numel(), ctypes.c_void_p(host.data_ptr()), resume, _hip.ptr(img),
-            evs, _hip.stream(dev))
+            evs, ctypes.c_void_p(st["ev"].cuda_event) if st.get("speculate", True) else None,
+            _hip.stream(dev))
 
     with torch.cuda.device(dev):
         rc = call(0)
@@ -81,4 +85,7 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
                 isect = _grow(st, "isect", need, dev, slack=1.25)
                 rc = call(1)
         _hip.check(rc, "ms_render_fwd")
+    # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
+    # on the exact path); do not speculate on the next frame of such a scene
+    st["speculate"] = int(host[4]) == 0
     return img, int(host[0])

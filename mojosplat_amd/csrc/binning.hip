@@ -404,11 +404,11 @@ constexpr int kLargeCap = SortCfg<1024, 16>::CAP;   // 16384: 1024 threads, 144 
 __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restrict__ tile_ranges,
                                                          const uint64_t *__restrict__ keys,
                                                          int32_t *__restrict__ flatten_ids,
-                                                         int64_t *__restrict__ isect_ids) {
+                                                         int64_t *__restrict__ isect_ids, int64_t cap) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SortCfg<256, 4>::LDS];
     const int tile = blockIdx.x;
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
-    if (n <= 0 || n > kSmallCap) return;
+    if (n <= 0 || n > kSmallCap || (int64_t)start + n > cap) return;  // beyond cap: speculative overflow
     sort_segment_lds<256, 4>(smem, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
 }
 
@@ -417,11 +417,20 @@ __global__ __launch_bounds__(1024) void k_tile_sort_list(const int32_t *__restri
                                                          const int32_t *__restrict__ tile_ranges,
                                                          const uint64_t *__restrict__ keys,
                                                          int32_t *__restrict__ flatten_ids,
-                                                         int64_t *__restrict__ isect_ids) {
+                                                         int64_t *__restrict__ isect_ids,
+                                                         const int64_t *__restrict__ n_list_dev,
+                                                         int n_list_host, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    const int tile = list[blockIdx.x];
-    const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
-    sort_segment_lds<1024, E>(smem_dyn, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
+    // the list length is either known to the host or read from the count pass's device record
+    // (sync-free frames launch a fixed grid and stride over the list)
+    const int n_list = n_list_dev ? (int)*n_list_dev : n_list_host;
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const int tile = list[li];
+        const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+        if ((int64_t)start + n <= cap)
+            sort_segment_lds<1024, E>(smem_dyn, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
+        __syncthreads();  // LDS is reused by the next list entry
+    }
 }
 
 // XL tiles: sort runs of kLargeCap in place ...
@@ -597,24 +606,14 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
     return MS_OK;
 }
 
-extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
-                                   const float *depths, int tile_size, int tile_w, int tile_h,
-                                   int row_begin, int row_end, void *workspace,
-                                   size_t workspace_bytes, const int32_t *tile_ranges,
-                                   const int64_t *host_info, uint64_t *sort_keys,
-                                   uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
-                                   void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    MS_REQUIRE(N >= 0 && host_info, MS_ERR_INVALID_ARG, "isect_emit: bad N / host_info");
-    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
-    const int64_t M = host_info[0], max_count = host_info[1], n_medium = host_info[2],
-                  n_large = host_info[3], n_xl = host_info[4];
-    MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE,
-               "isect_emit: %lld intersections do not fit int32 indices", (long long)M);
-    if (M == 0) return MS_OK;
-    MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
-               MS_ERR_INVALID_ARG, "isect_emit: null pointer");
-    MS_REQUIRE(n_xl == 0 || sort_tmp, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
+namespace {
+// Shared by the exact emit (host knows M and the class counts) and the speculative one (it does
+// not: `info_dev` is the count pass's device record, `cap` the capacity of the key/id buffers).
+int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
+              int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
+              const int32_t *tile_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
+              uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
+              hipStream_t stream) {
     Plan p;
     const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
     MS_REQUIRE(fits, MS_ERR_TOO_LARGE, "isect_emit: band too large for LDS");
@@ -625,32 +624,37 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
     const int32_t *medium = (const int32_t *)(ws + p.off_medium);
     const int32_t *large = (const int32_t *)(ws + p.off_large), *xl = (const int32_t *)(ws + p.off_xl);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+    const bool spec = info_dev != nullptr;
+    const int64_t max_count = spec ? 0 : host_info[1], n_medium = spec ? 0 : host_info[2],
+                  n_large = spec ? 0 : host_info[3], n_xl = spec ? 0 : host_info[4];
 
     if (p.lds_bytes > 48 * 1024)
         if (int rc = allow_big_lds(k_isect_scatter)) return rc;
     hipLaunchKernelGGL(k_isect_scatter, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d,
-                       radii, depths, g, p.chunk, hist, tile_ranges, M, sort_keys);
+                       radii, depths, g, p.chunk, hist, tile_ranges, cap, sort_keys);
     MS_LAUNCH_CHECK();
 
     hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
-                       flatten_ids, isect_ids);
+                       flatten_ids, isect_ids, cap);
     MS_LAUNCH_CHECK();
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
                   "sort class thresholds out of sync");
     const size_t medium_lds = SortCfg<1024, 4>::LDS, large_lds = SortCfg<1024, 16>::LDS;
-    if (n_medium > 0) {
+    if (spec || n_medium > 0) {
         if (int rc = allow_big_lds(k_tile_sort_list<4>)) return rc;
-        hipLaunchKernelGGL(k_tile_sort_list<4>, dim3((unsigned)n_medium), dim3(1024), medium_lds, stream,
-                           medium, tile_ranges, sort_keys, flatten_ids, isect_ids);
+        const unsigned grid = spec ? 512u : (unsigned)n_medium;
+        hipLaunchKernelGGL(k_tile_sort_list<4>, dim3(grid), dim3(1024), medium_lds, stream, medium, tile_ranges,
+                           sort_keys, flatten_ids, isect_ids, spec ? info_dev + 2 : nullptr, (int)n_medium, cap);
         MS_LAUNCH_CHECK();
     }
-    if (n_large > 0) {
+    if (spec || n_large > 0) {
         if (int rc = allow_big_lds(k_tile_sort_list<16>)) return rc;
-        hipLaunchKernelGGL(k_tile_sort_list<16>, dim3((unsigned)n_large), dim3(1024), large_lds, stream,
-                           large, tile_ranges, sort_keys, flatten_ids, isect_ids);
+        const unsigned grid = spec ? 256u : (unsigned)n_large;
+        hipLaunchKernelGGL(k_tile_sort_list<16>, dim3(grid), dim3(1024), large_lds, stream, large, tile_ranges,
+                           sort_keys, flatten_ids, isect_ids, spec ? info_dev + 3 : nullptr, (int)n_large, cap);
         MS_LAUNCH_CHECK();
     }
-    if (n_xl > 0) {
+    if (n_xl > 0) {  // exact mode only: a speculative frame with XL tiles is redone by the caller
         if (int rc = allow_big_lds(k_xl_chunk_sort)) return rc;
         const unsigned chunks = (unsigned)ms::ceil_div(max_count, kLargeCap);
         hipLaunchKernelGGL(k_xl_chunk_sort, dim3(chunks, (unsigned)n_xl), dim3(1024), large_lds, stream,
@@ -669,6 +673,44 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
         MS_LAUNCH_CHECK();
     }
     return MS_OK;
+}
+}  // namespace
+
+extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
+                                   const float *depths, int tile_size, int tile_w, int tile_h,
+                                   int row_begin, int row_end, void *workspace,
+                                   size_t workspace_bytes, const int32_t *tile_ranges,
+                                   const int64_t *host_info, uint64_t *sort_keys,
+                                   uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
+                                   void *stream_) {
+    MS_REQUIRE(N >= 0 && host_info, MS_ERR_INVALID_ARG, "isect_emit: bad N / host_info");
+    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
+    const int64_t M = host_info[0], n_xl = host_info[4];
+    MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE,
+               "isect_emit: %lld intersections do not fit int32 indices", (long long)M);
+    if (M == 0) return MS_OK;
+    MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
+               MS_ERR_INVALID_ARG, "isect_emit: null pointer");
+    MS_REQUIRE(n_xl == 0 || sort_tmp, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
+    return emit_impl(N, means2d, radii, depths, tile_size, tile_w, tile_h, row_begin, row_end, workspace,
+                     workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp, flatten_ids,
+                     isect_ids, (hipStream_t)stream_);
+}
+
+extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, const int32_t *radii,
+                                               const float *depths, int tile_size, int tile_w, int tile_h,
+                                               int row_begin, int row_end, void *workspace,
+                                               size_t workspace_bytes, const int32_t *tile_ranges,
+                                               const int64_t *isect_info_dev, int64_t capacity,
+                                               uint64_t *sort_keys, int32_t *flatten_ids, void *stream_) {
+    MS_REQUIRE(N >= 0 && isect_info_dev && capacity > 0 && capacity <= 0x7fffffffll, MS_ERR_INVALID_ARG,
+               "isect_emit_speculative: bad N / info / capacity");
+    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
+    MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
+               MS_ERR_INVALID_ARG, "isect_emit_speculative: null pointer");
+    return emit_impl(N, means2d, radii, depths, tile_size, tile_w, tile_h, row_begin, row_end, workspace,
+                     workspace_bytes, tile_ranges, nullptr, isect_info_dev, capacity, sort_keys, nullptr,
+                     flatten_ids, nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_w,

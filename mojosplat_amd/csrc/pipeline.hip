@@ -48,7 +48,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                              float far_plane, int tile_size, const float *backgrounds,
                              void *workspace, size_t workspace_bytes, void *isect_buf,
                              size_t isect_bytes, int64_t *host_info, int resume,
-                             float *render_colors, void **stage_events, void *stream_) {
+                             float *render_colors, void **stage_events, void *sync_event,
+                             void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "render_fwd: bad sizes");
     MS_REQUIRE(workspace && host_info && render_colors, MS_ERR_INVALID_ARG, "render_fwd: null pointer");
@@ -65,6 +66,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         if (stage_events && stage_events[i]) (void)hipEventRecord((hipEvent_t)stage_events[i], stream);
     };
 
+    bool speculated = false;
     if (!resume) {
         mark(0);
         if (int rc = ms_project_gaussians_fwd(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
@@ -76,15 +78,42 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                                           L.isect_bytes, nullptr, ranges, info, stream))
             return rc;
         MS_HIP(hipMemcpyAsync(host_info, info, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-        MS_HIP(hipStreamSynchronize(stream));  // the one size hand-off of a frame
+        // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
+        // sized by an earlier frame), enqueue emit + rasterise against that capacity NOW and only
+        // then wait for the size record -- the GPU never idles on the hand-off.  Every kernel
+        // clamps to `cap`, so an overflowing frame writes nothing out of bounds; it is detected
+        // below and redone on the exact path.
+        const int64_t cap = isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0;
+        if (sync_event && isect_buf && cap > 0) {
+            MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));
+            const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
+            uint64_t *keys = (uint64_t *)isect_buf;
+            int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
+            if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, 0, th,
+                                                         ws + L.off_isect, L.isect_bytes, ranges, info, c, keys,
+                                                         ids, stream))
+                return rc;
+            mark(2);
+            if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, c, means2d, conics, colors, color_dtype, CDIM, opacities,
+                                                         backgrounds, W, H, tile_size, 0, th, ranges, ids,
+                                                         render_colors, nullptr, nullptr, stream))
+                return rc;
+            mark(3);
+            MS_HIP(hipEventSynchronize((hipEvent_t)sync_event));  // long done: it precedes the emit
+            speculated = true;
+            const int64_t Ms = host_info[0];
+            if (Ms > 0 && Ms <= c && host_info[4] == 0) return MS_OK;  // the common case
+            // else: empty scene, overflow or a tile needing the merge path -> exact path below
+        } else {
+            MS_HIP(hipStreamSynchronize(stream));  // the one size hand-off of a frame
+        }
     }
     const int64_t M = host_info[0], n_xl = host_info[4];
     MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld intersections do not fit int32",
                (long long)M);
     if (M == 0) {  // the reference returns a zeros image here, not the background (render.py:73-76)
         MS_HIP(hipMemsetAsync(render_colors, 0, (size_t)H * W * CDIM * sizeof(float), stream));
-        mark(2);
-        mark(3);
+        if (!speculated) { mark(2); mark(3); }
         return MS_OK;
     }
     const size_t need = ms_render_isect_bytes(M, n_xl > 0);
@@ -100,11 +129,11 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, 0, th, ws + L.off_isect,
                                      L.isect_bytes, ranges, host_info, keys, tmp, ids, nullptr, stream))
         return rc;
-    mark(2);
+    if (!speculated) mark(2);
     if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, M, means2d, conics, colors, color_dtype, CDIM, opacities,
                                                  backgrounds, W, H, tile_size, 0, th, ranges, ids, render_colors,
                                                  nullptr, nullptr, stream))
         return rc;
-    mark(3);
+    if (!speculated) mark(3);
     return MS_OK;
 }

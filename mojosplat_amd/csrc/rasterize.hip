@@ -53,7 +53,7 @@ struct RasterArgs {
     float *render_colors;
     float *render_alphas;
     int32_t *last_ids;
-    int W, H, ts, tw, nsx, nsub, cdim, tile0, nblocks;
+    int W, H, ts, tw, nsx, nsub, cdim, tile0, nblocks, max_isects, n_gauss;
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -126,7 +126,9 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
         for (int k = 0; k < CP; ++k) pix[q][k] = 0.f;
     }
 
-    const int start = A.tile_ranges[2 * tile], end = A.tile_ranges[2 * tile + 1];
+    // clamped to the list length the caller vouches for (a sync-free frame passes its buffer capacity)
+    const int end = min(A.tile_ranges[2 * tile + 1], A.max_isects);
+    const int start = min(A.tile_ranges[2 * tile], end);
     const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
     const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
 
@@ -140,7 +142,9 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
     auto gather = [&](int b0) {
         const int idx = b0 + lane;
         if (idx < end) {
-            const int g = r_g;
+            // ids outside [0, N) can only come from a sync-free frame that overflowed its buffer (the
+            // frame is then redone); clamp so that even that frame never reads out of bounds
+            const int g = min(max(r_g, 0), A.n_gauss - 1);
             const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
             r_mx = m.x; r_my = m.y;
             r_ca = A.conics[3 * g]; r_cb = A.conics[3 * g + 1]; r_cc = A.conics[3 * g + 2];
@@ -309,6 +313,9 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
     const int64_t blocks = (int64_t)band_tiles * A.nsub;
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
     A.nblocks = (int)blocks;
+    A.max_isects = (int)M;
+    MS_REQUIRE(N > 0 || M == 0, MS_ERR_INVALID_ARG, "rasterize_fwd: M > 0 with N == 0");
+    A.n_gauss = (int)(N < 0x7fffffffll ? (N > 0 ? N : 1) : 0x7fffffffll);
     if (color_dtype == MS_COLOR_F16) return launch_fwd<__half>(A, (hipStream_t)stream);
     return launch_fwd<float>(A, (hipStream_t)stream);
 }
