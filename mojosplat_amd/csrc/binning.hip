@@ -26,7 +26,7 @@ namespace {
 
 constexpr int kHistThreads = 1024;
 constexpr int kMaxG = 512;
-constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 4096, kLargeCapDecl = 16384;  // per-tile sort classes
+constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
 constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
 constexpr size_t kMaxLds = 160 * 1024;
 
@@ -258,13 +258,13 @@ __device__ __forceinline__ int next_pow2(int n) {
     return p;
 }
 
-constexpr int kMaxBuckets = 4096;  // bucket-array cap for classes beyond 4096 keys
+constexpr int kMaxBuckets = 2048;  // bucket-array cap (8 KB of counters: two 8192-key workgroups fit a CU)
 constexpr int kBucketFallback = 48;  // a bucket this crowded sends the tile to the bitonic path
 
 template <int THREADS, int E>
 struct SortCfg {
     static constexpr int CAP = THREADS * E;
-    static constexpr int NB = CAP <= kMaxBuckets ? 2 * CAP : kMaxBuckets;  // ~2 buckets per key
+    static constexpr int NB = 2 * CAP <= kMaxBuckets ? 2 * CAP : kMaxBuckets;  // ~2 buckets per key while LDS allows
     static constexpr size_t LDS = (size_t)CAP * 8 + (size_t)NB * 4 + 64 * 4;
 };
 
@@ -398,7 +398,7 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
 }
 
 constexpr int kSmallCap = SortCfg<256, 4>::CAP;     // 1024: one 256-thread workgroup, 12 KB LDS
-constexpr int kMediumCap = SortCfg<1024, 4>::CAP;   // 4096: 1024 threads, 48 KB LDS
+constexpr int kMediumCap = SortCfg<1024, 8>::CAP;   // 8192: 1024 threads, 80 KB LDS
 constexpr int kLargeCap = SortCfg<1024, 16>::CAP;   // 16384: 1024 threads, 144 KB LDS
 
 __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restrict__ tile_ranges,
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restri
 }
 
 template <int E>
-__global__ __launch_bounds__(1024) void k_tile_sort_list(const int32_t *__restrict__ list,
+__global__ __launch_bounds__(1024, (E <= 8 ? 8 : 4)) void k_tile_sort_list(const int32_t *__restrict__ list,
                                                          const int32_t *__restrict__ tile_ranges,
                                                          const uint64_t *__restrict__ keys,
                                                          int32_t *__restrict__ flatten_ids,
@@ -639,11 +639,11 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
     MS_LAUNCH_CHECK();
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
                   "sort class thresholds out of sync");
-    const size_t medium_lds = SortCfg<1024, 4>::LDS, large_lds = SortCfg<1024, 16>::LDS;
+    const size_t medium_lds = SortCfg<1024, 8>::LDS, large_lds = SortCfg<1024, 16>::LDS;
     if (spec || n_medium > 0) {
-        if (int rc = allow_big_lds(k_tile_sort_list<4>)) return rc;
-        const unsigned grid = spec ? 512u : (unsigned)n_medium;
-        hipLaunchKernelGGL(k_tile_sort_list<4>, dim3(grid), dim3(1024), medium_lds, stream, medium, tile_ranges,
+        if (int rc = allow_big_lds(k_tile_sort_list<8>)) return rc;
+        const unsigned grid = spec ? (unsigned)min(p.T, 2048) : (unsigned)n_medium;
+        hipLaunchKernelGGL(k_tile_sort_list<8>, dim3(grid), dim3(1024), medium_lds, stream, medium, tile_ranges,
                            sort_keys, flatten_ids, isect_ids, spec ? info_dev + 2 : nullptr, (int)n_medium, cap);
         MS_LAUNCH_CHECK();
     }
