@@ -182,7 +182,9 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  *                detected and redone on the exact path).
  *   stage_events: NULL, or 4 hipEvent_t recorded on `stream` at: start, after projection,
  *                after binning, after rasterisation (for in-situ kernel timing).
- * M == 0 yields a ZERO image (reference render.py:73-76), otherwise
+ * [tile_row_begin, tile_row_end) restricts binning and rasterisation to a band of tile rows
+ * (0, tile_h = whole image); render_colors always addresses the FULL image.
+ * Whole-image calls: M == 0 yields a ZERO image (reference render.py:73-76), otherwise
  * render_colors f32[H,W,CDIM] = composited colours + T * background.
  * ------------------------------------------------------------------------------------- */
 size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h);
@@ -191,7 +193,8 @@ int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scal
                   const float *quats, const float *opacities, const void *colors, int color_dtype,
                   int CDIM, const float *viewmat, float fx, float fy, float cx, float cy, int W,
                   int H, float eps2d, float near_plane, float far_plane, int tile_size,
-                  const float *backgrounds, void *workspace, size_t workspace_bytes,
+                  int tile_row_begin, int tile_row_end, const float *backgrounds, void *workspace,
+                  size_t workspace_bytes,
                   void *isect_buf, size_t isect_bytes, int64_t *host_info, int resume,
                   float *render_colors, void **stage_events, void *sync_event, void *stream);
 

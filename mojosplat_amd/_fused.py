@@ -37,9 +37,11 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 
 
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                   stage_events=None):
+                   stage_events=None, row_range=None, out=None):
     """-> (image (H,W,C) f32, M).  `background` may be None.  stage_events: None or a list of 4
-    torch.cuda.Event that have been recorded once (so their handles exist)."""
+    torch.cuda.Event that have been recorded once (so their handles exist).
+    row_range=(r0, r1) renders only tile rows [r0, r1) into `out` (a caller-owned framebuffer of
+    at least H rows: the multi-GPU gather buffer); M is then the band's intersection count."""
     L = _hip.lib()
     dev = means3d.device
     N = means3d.shape[0]
@@ -63,7 +65,13 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
     ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
     isect = st["isect"]
     host = st["host"]
-    img = torch.empty((H, W, C), dtype=torch.float32, device=dev)
+    r0, r1 = (0, th) if row_range is None else row_range
+    if out is not None:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
+        assert out.shape[0] >= H and tuple(out.shape[1:]) == (W, C)
+        img = out
+    else:
+        img = torch.empty((H, W, C), dtype=torch.float32, device=dev)
     evs = None
     if stage_events is not None:
         evs = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
@@ -72,7 +80,7 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
         return L.ms_render_fwd(
             N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(op), _hip.ptr(colors), cdt, C,
             _hip.ptr(vm), camera.fx, camera.fy, camera.cx, camera.cy, W, H, EPS2D, camera.near, camera.far,
-            tile_size, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
+            tile_size, r0, r1, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
             0 if isect is None else isect.numel(), ctypes.c_void_p(host.data_ptr()), resume, _hip.ptr(img),
             evs, ctypes.c_void_p(st["ev"].cuda_event) if st.get("speculate", True) else None,
             _hip.stream(dev))

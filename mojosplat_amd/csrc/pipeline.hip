@@ -45,8 +45,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                              const float *quats, const float *opacities, const void *colors,
                              int color_dtype, int CDIM, const float *viewmat, float fx, float fy,
                              float cx, float cy, int W, int H, float eps2d, float near_plane,
-                             float far_plane, int tile_size, const float *backgrounds,
-                             void *workspace, size_t workspace_bytes, void *isect_buf,
+                             float far_plane, int tile_size, int tile_row_begin, int tile_row_end,
+                             const float *backgrounds, void *workspace, size_t workspace_bytes, void *isect_buf,
                              size_t isect_bytes, int64_t *host_info, int resume,
                              float *render_colors, void **stage_events, void *sync_event,
                              void *stream_) {
@@ -54,6 +54,9 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "render_fwd: bad sizes");
     MS_REQUIRE(workspace && host_info && render_colors, MS_ERR_INVALID_ARG, "render_fwd: null pointer");
     const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+    MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th, MS_ERR_INVALID_ARG,
+               "render_fwd: bad tile row band [%d,%d) of %d", tile_row_begin, tile_row_end, th);
+    const int r0 = tile_row_begin, r1 = tile_row_end;
     const WsLayout L = ws_layout(N, tw, th);
     MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_fwd: workspace %zu < %zu", workspace_bytes,
                L.total);
@@ -74,7 +77,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                                               depths, radii, stream))
             return rc;
         mark(1);
-        if (int rc = ms_isect_tiles_count(N, means2d, radii, tile_size, tw, th, 0, th, ws + L.off_isect,
+        if (int rc = ms_isect_tiles_count(N, means2d, radii, tile_size, tw, th, r0, r1, ws + L.off_isect,
                                           L.isect_bytes, nullptr, ranges, info, stream))
             return rc;
         MS_HIP(hipMemcpyAsync(host_info, info, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
@@ -89,13 +92,13 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
             uint64_t *keys = (uint64_t *)isect_buf;
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
-            if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, 0, th,
+            if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                          ws + L.off_isect, L.isect_bytes, ranges, info, c, keys,
                                                          ids, stream))
                 return rc;
             mark(2);
             if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, c, means2d, conics, colors, color_dtype, CDIM, opacities,
-                                                         backgrounds, W, H, tile_size, 0, th, ranges, ids,
+                                                         backgrounds, W, H, tile_size, r0, r1, ranges, ids,
                                                          render_colors, nullptr, nullptr, stream))
                 return rc;
             mark(3);
@@ -111,7 +114,9 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     const int64_t M = host_info[0], n_xl = host_info[4];
     MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld intersections do not fit int32",
                (long long)M);
-    if (M == 0) {  // the reference returns a zeros image here, not the background (render.py:73-76)
+    if (M == 0 && r0 == 0 && r1 == th) {
+        // whole-image call: the reference returns a zeros image here, not the background
+        // (render.py:73-76).  A band call leaves that rule to the caller, who knows the other bands.
         MS_HIP(hipMemsetAsync(render_colors, 0, (size_t)H * W * CDIM * sizeof(float), stream));
         if (!speculated) { mark(2); mark(3); }
         return MS_OK;
@@ -126,12 +131,12 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     uint64_t *keys = (uint64_t *)ib;
     uint64_t *tmp = n_xl > 0 ? (uint64_t *)(ib + key_bytes) : nullptr;
     int32_t *ids = (int32_t *)(ib + key_bytes * (n_xl > 0 ? 2 : 1));
-    if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, 0, th, ws + L.off_isect,
+    if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
                                      L.isect_bytes, ranges, host_info, keys, tmp, ids, nullptr, stream))
         return rc;
     if (!speculated) mark(2);
     if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, M, means2d, conics, colors, color_dtype, CDIM, opacities,
-                                                 backgrounds, W, H, tile_size, 0, th, ranges, ids, render_colors,
+                                                 backgrounds, W, H, tile_size, r0, r1, ranges, ids, render_colors,
                                                  nullptr, nullptr, stream))
         return rc;
     if (!speculated) mark(3);

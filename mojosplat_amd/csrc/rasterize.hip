@@ -219,7 +219,10 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
                 const bool hit = la <= rb.y && alpha >= thr[q];          // sigma >= 0 and alpha >= 1/255, live
                 const float next_T = fmaf(-alpha, T[q], T[q]);           // T (1 - alpha)
                 const bool add = hit && next_T > ms::kTransmittanceStop;
-                const float vis = add ? alpha * T[q] : 0.f;
+                // one select (v_cmp / v_cndmask issue at half the FMA rate on gfx950, v_exp at a
+                // quarter): alpha -> 0 for lanes that do not blend, then everything else is FMAs
+                const float a_eff = add ? alpha : 0.f;
+                const float vis = a_eff * T[q];
                 if constexpr (CP == 3) {
                     pix[q][0] += rb.z * vis;
                     pix[q][1] += rb.w * vis;
@@ -229,8 +232,12 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
                     for (int k = 0; k < CP; ++k) pix[q][k] += s_col[t * CS + k] * vis;
                 }
                 if constexpr (AUX) last[q] = add ? b0 + t : last[q];
-                T[q] = add ? next_T : T[q];
-                thr[q] = (hit && !add) ? kInf : thr[q];  // stop BEFORE adding: the pixel is finished
+                T[q] = fmaf(-a_eff, T[q], T[q]);                         // next_T where blended, T elsewhere
+                // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path.
+                if (__ballot(hit && !add)) {
+                    asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
+                    thr[q] = (hit && !add) ? kInf : thr[q];
+                }
             }
             any_live = any_live || __any(thr[q] < kInf);
         }

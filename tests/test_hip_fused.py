@@ -54,3 +54,25 @@ def test_fused_empty_scene_is_zeros_and_fp16_colours(device):
     assert a.dtype == torch.float32
     # render_gaussians casts the background to the colour dtype, like the reference (render.py:52-55)
     assert torch.equal(a, stagewise(sc16, cam, bg.half()))
+
+
+def test_band_calls_assemble_the_full_frame(device):
+    """The multi-GPU decomposition on one GPU: ms_render_fwd per tile-row band into one shared
+    framebuffer == the whole-image call, and the world=1 sharded entry point == render_gaussians."""
+    from mojosplat_amd.distributed import band_plan, render_gaussians_sharded
+    sc, cam = randscene_v1(30_000, 640, 360, ell=-3.0, seed=9, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    ref = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    th = -(-cam.H // 16)
+    for world in (2, 3, 8):
+        rows, bands = band_plan(th, world)
+        frame = torch.full((max(world * rows * 16, cam.H), cam.W, 3), -1.0, device=device)
+        total = 0
+        for band in bands:
+            if band[1] > band[0]:
+                _, m = _fused.render_fwd_hip(*g, cam, bg, 16, row_range=band, out=frame)
+                total += m
+        assert torch.equal(frame[:cam.H], ref)
+        assert (frame[cam.H:] == -1.0).all()      # padding rows are never written
+    assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg), ref)
