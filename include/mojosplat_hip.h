@@ -152,7 +152,10 @@ int ms_rasterize_to_pixels_3dgs_bwd(int64_t N, int64_t M, const float *means2d,
                                     const int32_t *last_ids, const float *v_render_colors,
                                     const float *v_render_alphas, float *v_means2d,
                                     float *v_conics, float *v_colors, float *v_opacities,
-                                    void *stream);
+                                    void *workspace, size_t workspace_bytes, void *stream);
+/* scratch for the packed-gradient path of the backward rasteriser (0 = not needed / not used:
+ * without it, or for CDIM > 4, the call still works through the one-atomic-per-component path) */
+size_t ms_rasterize_bwd_workspace_bytes(int64_t N, int CDIM);
 
 /* Projection backward: gradients of (means2d, conics, depths) w.r.t. means3d, scales
  * (w.r.t. the log-scales when scales_are_log), quats.  Culled Gaussians get zero grads.

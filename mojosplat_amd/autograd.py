@@ -78,13 +78,15 @@ class _RasterizeHip(torch.autograd.Function):
         v_img = _hip.f32c(v_img)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         v_means2d, v_conics, v_colors, v_opac = z(N, 2), z(N, 3), z(N, C), z(N)
+        ws_bytes = L.ms_rasterize_bwd_workspace_bytes(N, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         with torch.cuda.device(dev):
             _hip.check(L.ms_rasterize_to_pixels_3dgs_bwd(
                 N, ids.numel(), _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(colors), C,
                 _hip.ptr(opacities), _hip.ptr(bg), cam.W, cam.H, ts, _hip.ptr(ranges), _hip.ptr(ids),
                 _hip.ptr(alphas), _hip.ptr(last), _hip.ptr(v_img), None, _hip.ptr(v_means2d),
-                _hip.ptr(v_conics), _hip.ptr(v_colors), _hip.ptr(v_opac), _hip.stream(dev)),
-                "ms_rasterize_to_pixels_3dgs_bwd")
+                _hip.ptr(v_conics), _hip.ptr(v_colors), _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes,
+                _hip.stream(dev)), "ms_rasterize_to_pixels_3dgs_bwd")
         v_bg = None
         if bg is not None and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - alphas)[..., None] * v_img).sum(dim=(0, 1))

@@ -178,6 +178,230 @@ __global__ __launch_bounds__(256) void k_rasterize_bwd(RasterBwdArgs A) {
     }
 }
 
+// ---- v2 (CDIM <= 4): one wave64 per 16x16 block, four pixels per lane -------------------------
+// Same block/quad layout, staging and bbox culling as the forward kernel (rasterize.hip), walked
+// back to front.  What differs from v1 above:
+//   * the 4 quads of an entry accumulate into per-lane partial sums first, so there is ONE wave
+//     reduction (9 values) per (tile, Gaussian), not one per (wave, Gaussian);
+//   * conic / mean gradients are linear in five per-lane sums (vs*dx, vs*dy, vs*dx^2, vs*dx*dy,
+//     vs*dy^2), so the lane that holds the totals finishes them with the entry's conic;
+//   * totals go to a 64-byte row per Gaussian in a packed scratch buffer (f32[N][16]): the batch
+//     flush adds 4 whole rows per wave-instruction -- contiguous float atomics run ~17x faster
+//     than one-dword-per-row ones on MI355X (MI355X_MICROARCH.md, Global float atomics);
+//     k_unpack_grads then adds the rows into the caller's four gradient tensors.
+constexpr int kRow = 16;  // floats per packed gradient row: mx my ca cb cc op c0 c1 c2 c3 - - - - - -
+
+struct RasterBwd2Args {
+    RasterBwdArgs a;
+    float *packed;  // f32[N][kRow], zeroed by the caller of the kernel
+    int nblocks, n_gauss;
+};
+
+__device__ __forceinline__ void wave_lds_sync_bwd() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+
+template <int CP>
+__global__ __launch_bounds__(64) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
+    const RasterBwdArgs &A = B2.a;
+    constexpr int NG = 6 + CP;
+    constexpr float kLog2e = 1.4426950408889634f;
+    __shared__ float4 s_a[64];       // mean.x, mean.y, a', b'   (conic pre-scaled by -log2e/2, -log2e)
+    __shared__ float4 s_b[64];       // c', opacity, colour0, colour1
+    __shared__ float4 s_c[64];       // colour2, colour3, Gaussian id (bits), -
+    __shared__ float s_grad[64 * kRow];
+
+    const int item = blockIdx.x;
+    const int tile = item / A.nsub, sub = item - tile * A.nsub;
+    const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
+    const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
+    const int lane = threadIdx.x;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int bx = tile_x * A.ts + sub_x * 16, by = tile_y * A.ts + sub_y * 16;
+    const int ox = sub_x * 16 + lx, oy = sub_y * 16 + ly;
+    const float px0 = (float)(bx + lx) + 0.5f, py0 = (float)(by + ly) + 0.5f;
+    const int start = A.tile_ranges[2 * tile], end = A.tile_ranges[2 * tile + 1];
+    if (end <= start) return;
+
+    float T[4], tb[4], v_out[4][CP], buf[4][CP];
+    int binf[4], qmax[4];
+    int wave_final = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = bx + lx + (q & 1) * 8, Y = by + ly + (q >> 1) * 8;
+        const bool in = (ox + (q & 1) * 8) < A.ts && (oy + (q >> 1) * 8) < A.ts && X < A.W && Y < A.H;
+        const size_t p = in ? (size_t)Y * A.W + X : 0;
+        const float T_final = in ? 1.0f - A.render_alphas[p] : 1.0f;
+        T[q] = T_final;
+        binf[q] = in ? A.last_ids[p] : -1;
+        float bg_dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CP; ++k) {
+            v_out[q][k] = (in && k < A.cdim) ? A.v_render_colors[p * A.cdim + k] : 0.f;
+            buf[q][k] = 0.f;
+            if (A.backgrounds && k < A.cdim) bg_dot += A.backgrounds[k] * v_out[q][k];
+        }
+        const float v_a = (in && A.v_render_alphas) ? A.v_render_alphas[p] : 0.f;
+        tb[q] = T_final * (v_a - bg_dot);
+        qmax[q] = wave_max_i32(binf[q]);
+        wave_final = max(wave_final, qmax[q]);
+    }
+    if (wave_final < start) return;
+    const int hi = min(end - 1, wave_final);  // last intersection anyone in this block blended
+    const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
+
+    for (int b0 = start + ((hi - start) & ~63); b0 >= start; b0 -= 64) {
+        // ---- stage entries b0 .. b0+63 (ascending); walk them from the back
+        const int idx = b0 + lane;
+        int mask = 0, g = 0;
+        float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f, col[4] = {0.f, 0.f, 0.f, 0.f};
+        if (idx <= hi) {
+            g = min(max(A.flatten_ids[idx], 0), B2.n_gauss - 1);
+            const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
+            mx = m.x; my = m.y;
+            ca = A.conics[3 * g]; cb = A.conics[3 * g + 1]; cc = A.conics[3 * g + 2];
+            op = A.opacities[g];
+#pragma unroll
+            for (int k = 0; k < CP; ++k)
+                if (k < A.cdim) col[k] = A.colors[(size_t)g * A.cdim + k];
+            if (op >= ms::kAlphaThreshold) {
+                const float det = ca * cc - cb * cb;
+                if (det > 0.f && ca > 0.f && cc > 0.f) {
+                    const float smax2 = 2.0f * __logf(op * 255.0f) * 1.0001f + 1e-4f;
+                    const float inv = 1.0f / det;
+                    const float hx = sqrtf(smax2 * cc * inv) * 1.0001f + 0.01f;
+                    const float hy = sqrtf(smax2 * ca * inv) * 1.0001f + 0.01f;
+                    const bool x0 = (mx + hx >= fbx) && (mx - hx <= fbx + 7.0f);
+                    const bool x1 = (mx + hx >= fbx + 8.0f) && (mx - hx <= fbx + 15.0f);
+                    const bool y0 = (my + hy >= fby) && (my - hy <= fby + 7.0f);
+                    const bool y1 = (my + hy >= fby + 8.0f) && (my - hy <= fby + 15.0f);
+                    mask = (x0 && y0 ? 1 : 0) | (x1 && y0 ? 2 : 0) | (x0 && y1 ? 4 : 0) | (x1 && y1 ? 8 : 0);
+                } else {
+                    mask = 0xf;
+                }
+            }
+        }
+        unsigned long long Bq[4], U = 0ull;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Bq[q] = __ballot((mask >> q) & 1);
+            // entries behind the last one any pixel of this quad blended cannot matter to it
+            const int lim = qmax[q] - b0;
+            Bq[q] = lim < 0 ? 0ull : (lim >= 63 ? Bq[q] : (Bq[q] & ((2ull << lim) - 1ull)));
+            U |= Bq[q];
+        }
+        wave_lds_sync_bwd();  // the previous batch's flush has read s_grad / s_c
+        if (mask) {
+            s_a[lane] = make_float4(mx, my, -0.5f * kLog2e * ca, -kLog2e * cb);
+            s_b[lane] = make_float4(-0.5f * kLog2e * cc, op, col[0], col[1]);
+            s_c[lane] = make_float4(col[2], col[3], __int_as_float(g), 0.f);
+        }
+        wave_lds_sync_bwd();
+
+        unsigned long long flush = 0ull;
+        while (U) {
+            const int t = 63 - __clzll((long long)U);
+            U &= ~(1ull << t);
+            const int cur = b0 + t;
+            const float4 ra = s_a[t];
+            const float4 rb = s_b[t];
+            const float4 rc = s_c[t];
+            const float cv[4] = {rb.z, rb.w, rc.x, rc.y};
+            float acc[NG];  // Sx Sy S1 S2 S3 op colour[CP]
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = 0.f;
+            unsigned long long anyv = 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!((Bq[q] >> t) & 1ull)) continue;  // wave-uniform
+                const float dx = ra.x - (px0 + (float)((q & 1) * 8)), dy = ra.y - (py0 + (float)((q >> 1) * 8));
+                const float lp = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), rb.x * dy * dy);  // -sigma*log2(e)
+                const float vis = __builtin_amdgcn_exp2f(lp);
+                const float ov = rb.y * vis;
+                const float alpha = fminf(ms::kMaxAlpha, ov);
+                const bool valid = cur <= binf[q] && lp <= 0.f && alpha >= ms::kAlphaThreshold;
+                anyv |= __ballot(valid);
+                if (valid) {
+                    const float ra_ = 1.0f / (1.0f - alpha);
+                    T[q] *= ra_;
+                    const float fac = alpha * T[q];
+                    float v_alpha = tb[q] * ra_;
+#pragma unroll
+                    for (int k = 0; k < CP; ++k) {
+                        acc[6 + k] = fmaf(fac, v_out[q][k], acc[6 + k]);
+                        v_alpha = fmaf(fmaf(cv[k], T[q], -buf[q][k] * ra_), v_out[q][k], v_alpha);
+                        buf[q][k] = fmaf(cv[k], fac, buf[q][k]);
+                    }
+                    if (ov <= ms::kMaxAlpha) {
+                        const float vs = -ov * v_alpha;
+                        const float sx = vs * dx, sy = vs * dy;
+                        acc[0] += sx;
+                        acc[1] += sy;
+                        acc[2] = fmaf(sx, dx, acc[2]);
+                        acc[3] = fmaf(sx, dy, acc[3]);
+                        acc[4] = fmaf(sy, dy, acc[4]);
+                        acc[5] = fmaf(vis, v_alpha, acc[5]);
+                    }
+                }
+            }
+            if (anyv == 0ull) continue;
+            float tot[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) tot[j] = wave_sum_to_lane63(acc[j]);
+            if (lane == 63) {
+                // undo the staging scale: a' = -log2e/2 * ca, b' = -log2e * cb, c' = -log2e/2 * cc
+                const float eca = ra.z * (-2.0f / kLog2e), ecb = ra.w * (-1.0f / kLog2e), ecc = rb.x * (-2.0f / kLog2e);
+                float *row = s_grad + t * kRow;
+                row[0] = eca * tot[0] + ecb * tot[1];
+                row[1] = ecb * tot[0] + ecc * tot[1];
+                row[2] = 0.5f * tot[2];
+                row[3] = tot[3];
+                row[4] = 0.5f * tot[4];
+                row[5] = tot[5];
+#pragma unroll
+                for (int k = 0; k < CP; ++k) row[6 + k] = tot[6 + k];
+            }
+            flush |= 1ull << t;
+        }
+        wave_lds_sync_bwd();
+        // ---- flush: 4 packed rows (4 x 64 B contiguous) per wave instruction
+        const int colm = lane & 15, rsub = lane >> 4;
+        for (int r4 = 0; r4 < 64; r4 += 4) {
+            if (((flush >> r4) & 0xfull) == 0ull) continue;
+            const int r = r4 + rsub;
+            if (((flush >> r) & 1ull) && colm < NG) {
+                const int gid = __float_as_int(s_c[r].z);
+                atomicAdd(B2.packed + (size_t)gid * kRow + colm, s_grad[r * kRow + colm]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_grads(int64_t N, int cdim, const float *__restrict__ packed,
+                                                      float *__restrict__ v_means2d, float *__restrict__ v_conics,
+                                                      float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4 *row = reinterpret_cast<const float4 *>(packed + i * kRow);
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+    v_means2d[2 * i] += r0.x;
+    v_means2d[2 * i + 1] += r0.y;
+    v_conics[3 * i] += r0.z;
+    v_conics[3 * i + 1] += r0.w;
+    v_conics[3 * i + 2] += r1.x;
+    v_opacities[i] += r1.y;
+    const float c[4] = {r1.z, r1.w, r2.x, r2.y};
+    for (int k = 0; k < cdim && k < 4; ++k) v_colors[i * cdim + k] += c[k];
+}
+
 }  // namespace
 
 extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
@@ -185,7 +409,8 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     const float *opacities, const float *backgrounds, int W, int H, int tile_size,
     const int32_t *tile_ranges, const int32_t *flatten_ids, const float *render_alphas,
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
-    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *stream) {
+    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *workspace,
+    size_t workspace_bytes, void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_bwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_bwd: CDIM %d not in 1..32", CDIM);
@@ -210,6 +435,23 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_bwd: too many tiles");
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const size_t packed_bytes = (size_t)N * kRow * sizeof(float);
+    if (CDIM <= 4 && workspace && workspace_bytes >= packed_bytes && N <= 0x7fffffffll) {
+        // v2: packed 64-byte gradient rows (contiguous float atomics), then unpack
+        RasterBwd2Args B2;
+        B2.a = A;
+        B2.packed = (float *)workspace;
+        B2.nblocks = (int)blocks;
+        B2.n_gauss = (int)N;
+        MS_HIP(hipMemsetAsync(workspace, 0, packed_bytes, st));
+        if (CDIM <= 3) hipLaunchKernelGGL(k_rasterize_bwd_v2<3>, grid, dim3(64), 0, st, B2);
+        else hipLaunchKernelGGL(k_rasterize_bwd_v2<4>, grid, dim3(64), 0, st, B2);
+        MS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_unpack_grads, dim3((unsigned)ms::ceil_div(N, 256)), dim3(256), 0, st, N, CDIM,
+                           (const float *)workspace, v_means2d, v_conics, v_colors, v_opacities);
+        MS_LAUNCH_CHECK();
+        return MS_OK;
+    }
     if (CDIM <= 3) hipLaunchKernelGGL(k_rasterize_bwd<3>, grid, block, 0, st, A);
     else if (CDIM <= 4) hipLaunchKernelGGL(k_rasterize_bwd<4>, grid, block, 0, st, A);
     else if (CDIM <= 8) hipLaunchKernelGGL(k_rasterize_bwd<8>, grid, block, 0, st, A);
@@ -217,4 +459,8 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     else hipLaunchKernelGGL(k_rasterize_bwd<32>, grid, block, 0, st, A);
     MS_LAUNCH_CHECK();
     return MS_OK;
+}
+
+extern "C" size_t ms_rasterize_bwd_workspace_bytes(int64_t N, int CDIM) {
+    return (CDIM >= 1 && CDIM <= 4 && N > 0) ? (size_t)N * kRow * sizeof(float) : 0;
 }
