@@ -205,13 +205,17 @@ int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scal
  * by ms_isect_tiles_count, `capacity` the number of entries sort_keys / flatten_ids can hold.
  * Every kernel clamps to the capacity; the caller must afterwards check (from its own copy of
  * the record) that M <= capacity and that no tile is in the merge-fallback class, and redo the
- * frame with ms_isect_tiles_emit otherwise.  Used by ms_render_fwd for sync-free frames. */
+ * frame with ms_isect_tiles_emit otherwise.  prev_info_host (HOST, nullable) is the record of
+ * the previous frame: when its large-class count is 0 the large-class sort is not launched, and
+ * the caller must also redo the frame if this frame's large-class count turns out non-zero.
+ * Used by ms_render_fwd for sync-free frames. */
 int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, const int32_t *radii,
                                     const float *depths, int tile_size, int tile_w, int tile_h,
                                     int row_begin, int row_end, void *workspace,
                                     size_t workspace_bytes, const int32_t *tile_ranges,
                                     const int64_t *isect_info_dev, int64_t capacity,
-                                    uint64_t *sort_keys, int32_t *flatten_ids, void *stream);
+                                    const int64_t *prev_info_host, uint64_t *sort_keys,
+                                    int32_t *flatten_ids, void *stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,8 @@
 //   k_tile_sort_small one 256-thread workgroup per tile with <= 1024 entries (12 KB LDS)
 //   k_tile_sort_list  work lists of tiles with <= 4096 (48 KB LDS) and <= 16384 entries (144 KB)
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
+#include <stdlib.h>
+
 #include "ms_common.hpp"
 
 namespace {
@@ -634,26 +636,33 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                        radii, depths, g, p.chunk, hist, tile_ranges, cap, sort_keys);
     MS_LAUNCH_CHECK();
 
-    hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
-                       flatten_ids, isect_ids, cap);
-    MS_LAUNCH_CHECK();
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
                   "sort class thresholds out of sync");
+    // (Running the size classes on two streams was measured: the fork/join events cost more
+    // than the overlap buys -- bin stage 176 us forked vs 160 us in order.)
+    hipStream_t big = stream;
     const size_t medium_lds = SortCfg<1024, 8>::LDS, large_lds = SortCfg<1024, 16>::LDS;
     if (spec || n_medium > 0) {
         if (int rc = allow_big_lds(k_tile_sort_list<8>)) return rc;
         const unsigned grid = spec ? (unsigned)min(p.T, 2048) : (unsigned)n_medium;
-        hipLaunchKernelGGL(k_tile_sort_list<8>, dim3(grid), dim3(1024), medium_lds, stream, medium, tile_ranges,
+        hipLaunchKernelGGL(k_tile_sort_list<8>, dim3(grid), dim3(1024), medium_lds, big, medium, tile_ranges,
                            sort_keys, flatten_ids, isect_ids, spec ? info_dev + 2 : nullptr, (int)n_medium, cap);
         MS_LAUNCH_CHECK();
     }
-    if (spec || n_large > 0) {
+    // sync-free frames cannot know whether the large class is populated; the previous frame's
+    // record (still in the caller's host_info when it is passed) says whether to bother: a wrong
+    // guess is caught by the caller's post-check like any other speculation failure
+    const bool launch_large = spec ? (host_info == nullptr || host_info[3] > 0) : n_large > 0;
+    if (launch_large) {
         if (int rc = allow_big_lds(k_tile_sort_list<16>)) return rc;
         const unsigned grid = spec ? 256u : (unsigned)n_large;
-        hipLaunchKernelGGL(k_tile_sort_list<16>, dim3(grid), dim3(1024), large_lds, stream, large, tile_ranges,
+        hipLaunchKernelGGL(k_tile_sort_list<16>, dim3(grid), dim3(1024), large_lds, big, large, tile_ranges,
                            sort_keys, flatten_ids, isect_ids, spec ? info_dev + 3 : nullptr, (int)n_large, cap);
         MS_LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
+                       flatten_ids, isect_ids, cap);
+    MS_LAUNCH_CHECK();
     if (n_xl > 0) {  // exact mode only: a speculative frame with XL tiles is redone by the caller
         if (int rc = allow_big_lds(k_xl_chunk_sort)) return rc;
         const unsigned chunks = (unsigned)ms::ceil_div(max_count, kLargeCap);
@@ -702,14 +711,15 @@ extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, 
                                                int row_begin, int row_end, void *workspace,
                                                size_t workspace_bytes, const int32_t *tile_ranges,
                                                const int64_t *isect_info_dev, int64_t capacity,
-                                               uint64_t *sort_keys, int32_t *flatten_ids, void *stream_) {
+                                               const int64_t *prev_info_host, uint64_t *sort_keys,
+                                               int32_t *flatten_ids, void *stream_) {
     MS_REQUIRE(N >= 0 && isect_info_dev && capacity > 0 && capacity <= 0x7fffffffll, MS_ERR_INVALID_ARG,
                "isect_emit_speculative: bad N / info / capacity");
     if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
     MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
                MS_ERR_INVALID_ARG, "isect_emit_speculative: null pointer");
     return emit_impl(N, means2d, radii, depths, tile_size, tile_w, tile_h, row_begin, row_end, workspace,
-                     workspace_bytes, tile_ranges, nullptr, isect_info_dev, capacity, sort_keys, nullptr,
+                     workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity, sort_keys, nullptr,
                      flatten_ids, nullptr, (hipStream_t)stream_);
 }
 

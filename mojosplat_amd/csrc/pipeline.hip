@@ -80,6 +80,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         if (int rc = ms_isect_tiles_count(N, means2d, radii, tile_size, tw, th, r0, r1, ws + L.off_isect,
                                           L.isect_bytes, nullptr, ranges, info, stream))
             return rc;
+        int64_t prev[8];  // the previous frame's record: a hint for what this frame will need
+        for (int k = 0; k < 8; ++k) prev[k] = host_info[k];
         MS_HIP(hipMemcpyAsync(host_info, info, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
         // sized by an earlier frame), enqueue emit + rasterise against that capacity NOW and only
@@ -93,8 +95,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             uint64_t *keys = (uint64_t *)isect_buf;
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
             if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
-                                                         ws + L.off_isect, L.isect_bytes, ranges, info, c, keys,
-                                                         ids, stream))
+                                                         ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
+                                                         keys, ids, stream))
                 return rc;
             mark(2);
             if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, c, means2d, conics, colors, color_dtype, CDIM, opacities,
@@ -105,7 +107,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             MS_HIP(hipEventSynchronize((hipEvent_t)sync_event));  // long done: it precedes the emit
             speculated = true;
             const int64_t Ms = host_info[0];
-            if (Ms > 0 && Ms <= c && host_info[4] == 0) return MS_OK;  // the common case
+            const bool large_ok = host_info[3] == 0 || prev[3] > 0;  // large class sorted iff it was launched
+            if (Ms > 0 && Ms <= c && host_info[4] == 0 && large_ok) return MS_OK;  // the common case
             // else: empty scene, overflow or a tile needing the merge path -> exact path below
         } else {
             MS_HIP(hipStreamSynchronize(stream));  // the one size hand-off of a frame
