@@ -160,6 +160,18 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sc, cam, W, H, BACKGROUND_V1, args.workload)
+        extras = None
+        if world == 1:
+            # not the headline: the same scene through the multi-view entry point (16 cameras per
+            # call, two views in flight on two streams), reported beside the single-call rate
+            cams = [cam] * 16
+            ms.render_gaussians_batch(*g, cams, background_color=bg)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(4):
+                ms.render_gaussians_batch(*g, cams, background_color=bg)
+            torch.cuda.synchronize()
+            extras = {"multi_view_batch16_views_per_s": round(64 / (time.perf_counter() - tb), 1)}
         out = {
             "metric": "frames/sec at 1M Gaussians 1920x1080 fwd; achieved HBM GB/s vs peak",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -169,7 +181,7 @@ def main():
                        "gaussians": N, "intersections": M, "tiles": T, "tile_size": 16,
                        "colour_dtype": "f16" if fp16 else "f32",
                        "parallelism": "single GPU" if world == 1 else f"{world} tile-row bands + RCCL all-gather"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -178,9 +190,9 @@ def main():
 
 
 def cpu_baseline(sc, cam, W, H, bg, workload):
-    """The scalar C oracle (kind 'port', 1 core) on a bounded sample of the same workload:
-    the first `n` Gaussians of the scene, chosen so the run stays around 10-30 s, scaled to
-    frames/s of that sample (stated in `sample`)."""
+    """The scalar C oracle (kind 'port', 1 core) on a bounded sample of the same workload: whole
+    frames of the scene (its first <= 1M Gaussians), repeated until ~10 s of CPU work, reported
+    as frames/s of that sample (stated in `sample`)."""
     import numpy as np
 
     import oracle
@@ -188,13 +200,17 @@ def cpu_baseline(sc, cam, W, H, bg, workload):
     vm = cam.view_matrix.cpu().numpy()
     n = min(len(cpu["means3d"]), 1_000_000)
     args = tuple(cpu[k][:n] for k in ("means3d", "scales", "quats", "opacities", "features"))
-    t0 = time.perf_counter()
-    _, aux = oracle.render_fwd(*args, vm, cam.fx, cam.fy, cam.cx, cam.cy, W, H,
-                               background=np.array(bg, np.float32))
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"1 frame of {workload} restricted to its first {n} Gaussians "
-                      f"(M={aux['M']}), oracle/gsplat_oracle.c, {dt:.1f} s",
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        _, aux = oracle.render_fwd(*args, vm, cam.fx, cam.fy, cam.cx, cam.cy, W, H,
+                                   background=np.array(bg, np.float32))
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or frames >= 8:
+            break
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{frames} frame(s) of {workload} restricted to its first {n} Gaussians "
+                      f"(M={aux['M']}), oracle/gsplat_oracle.c, {dt:.1f} s of CPU work",
             "host_cpus": os.cpu_count()}
 
 

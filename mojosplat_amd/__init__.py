@@ -9,7 +9,7 @@ from .utils import Camera, look_at
 from .projection import project_gaussians
 from .binning import bin_gaussians_to_tiles
 from .rasterization import rasterize_gaussians
-from .render import render_gaussians, TILE_SIZE
+from .render import render_gaussians, render_gaussians_batch, TILE_SIZE
 
 __all__ = ["Camera", "look_at", "project_gaussians", "bin_gaussians_to_tiles",
-           "rasterize_gaussians", "render_gaussians", "TILE_SIZE"]
+           "rasterize_gaussians", "render_gaussians", "render_gaussians_batch", "TILE_SIZE"]

@@ -14,17 +14,17 @@ import torch
 from . import _hip
 from .projection import EPS2D
 
-_state = {}  # device -> dict(ws, isect, host)
+_state = {}  # (device, lane) -> dict(ws, isect, host, ev); lane 0 = the plain single-frame path
 
 
-def _dev_state(dev):
-    st = _state.get(dev)
+def _dev_state(dev, lane=0):
+    st = _state.get((dev, lane))
     if st is None:
         ev = torch.cuda.Event()
         with torch.cuda.device(dev):
             ev.record()  # materialises the hipEvent_t the library re-records for its size hand-off
         st = dict(ws=None, isect=None, host=torch.zeros(8, dtype=torch.int64).pin_memory(), ev=ev)
-        _state[dev] = st
+        _state[(dev, lane)] = st
     return st
 
 
@@ -37,11 +37,13 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 
 
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                   stage_events=None, row_range=None, out=None):
+                   stage_events=None, row_range=None, out=None, lane=0):
     """-> (image (H,W,C) f32, M).  `background` may be None.  stage_events: None or a list of 4
     torch.cuda.Event that have been recorded once (so their handles exist).
     row_range=(r0, r1) renders only tile rows [r0, r1) into `out` (a caller-owned framebuffer of
-    at least H rows: the multi-GPU gather buffer); M is then the band's intersection count."""
+    at least H rows: the multi-GPU gather buffer); M is then the band's intersection count.
+    `lane` selects an independent set of scratch buffers (multi-view batches keep two frames in
+    flight on two streams, each with its own lane)."""
     L = _hip.lib()
     dev = means3d.device
     N = means3d.shape[0]
@@ -61,7 +63,7 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
     if vm.device != dev:
         vm = vm.to(dev)
 
-    st = _dev_state(dev)
+    st = _dev_state(dev, lane)
     ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
     isect = st["isect"]
     host = st["host"]
@@ -97,3 +99,47 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
     # on the exact path); do not speculate on the next frame of such a scene
     st["speculate"] = int(host[4]) == 0
     return img, int(host[0])
+
+
+@torch.no_grad()
+def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, background, tile_size):
+    """Render the same Gaussians from several cameras -> (C, H, W, channels) f32.
+
+    Views are independent, so two are kept in flight: view i+1's projection / counting (memory and
+    latency bound) runs on a second stream beside view i's rasteriser (VALU bound).  Each lane has
+    its own scratch; the caller's stream waits for both lanes before the batch is handed back."""
+    dev = means3d.device
+    H, W = cameras[0].H, cameras[0].W
+    assert all(c.H == H and c.W == W for c in cameras), "all cameras of a batch share one image size"
+    C = colors.shape[1]
+    out = torch.empty((len(cameras), H, W, C), dtype=torch.float32, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    lanes = _lane_streams(dev)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    counts = []
+    for i, cam in enumerate(cameras):
+        lane = 1 + (i % len(lanes))
+        s = lanes[lane - 1]
+        s.wait_event(ready)
+        with torch.cuda.stream(s):
+            _, m = render_fwd_hip(means3d, scales, quats, opacities, colors, cam, background, tile_size,
+                                  out=out[i], lane=lane)
+        counts.append(m)
+    for s in lanes:
+        cur.wait_stream(s)
+    for t in (out, means3d, scales, quats, opacities, colors):
+        for s in lanes:
+            t.record_stream(s)
+    return out, counts
+
+
+_lanes = {}
+
+
+def _lane_streams(dev):
+    ls = _lanes.get(dev)
+    if ls is None:
+        ls = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        _lanes[dev] = ls
+    return ls

@@ -80,3 +80,33 @@ def render_gaussians(
 
     return rasterize_gaussians(means2d, conics, colors, opacities, bg, tile_ranges, sorted_ids,
                                camera, tile_size=tile_size, backend=backend)
+
+
+@torch.no_grad()
+def render_gaussians_batch(means3d, scales, quats, opacities, features, cameras, background_color=None,
+                           tile_size: int = TILE_SIZE, backend: str = "hip") -> torch.Tensor:
+    """Multi-view rendering: the same Gaussians from C cameras -> (C, H, W, channels).
+
+    The reference's kernels carry a camera batch dimension but every wrapper pins C = 1
+    (projection.py:431, rasterization.py:175); this is the batched entry point SURVEY.md
+    section 8(f) row 4 asks for.  Image i equals ``render_gaussians(..., cameras[i])`` bit for
+    bit (including the zeros image for a view with no intersections)."""
+    if backend != "hip":
+        return torch.stack([render_gaussians(means3d, scales, quats, opacities, features, c,
+                                             background_color=background_color, tile_size=tile_size,
+                                             backend=backend) for c in cameras])
+    required = [means3d, scales, quats, opacities, features]
+    if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in required):
+        raise ValueError("All input gaussian tensors must be CUDA tensors.")
+    C = features.shape[-1]
+    if background_color is None:
+        bg = torch.zeros(C, device=means3d.device, dtype=features.dtype)
+    else:
+        bg = torch.as_tensor(background_color, device=means3d.device).to(features.dtype)
+    if bg.shape[0] != C:
+        raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color "
+                         f"channels ({C})")
+    assert opacities.shape == (means3d.shape[0],)
+    from ._fused import render_batch_hip
+    out, _ = render_batch_hip(means3d, scales, quats, opacities, features, list(cameras), bg, tile_size)
+    return out

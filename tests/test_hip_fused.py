@@ -76,3 +76,21 @@ def test_band_calls_assemble_the_full_frame(device):
         assert torch.equal(frame[:cam.H], ref)
         assert (frame[cam.H:] == -1.0).all()      # padding rows are never written
     assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg), ref)
+
+
+def test_multi_view_batch_equals_single_views(device):
+    """C cameras in one call (two views in flight on two streams) == C calls."""
+    from mojosplat_amd.utils import Camera, look_at
+    sc, cam0 = randscene_v1(20_000, 480, 270, ell=-3.0, seed=4, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    cams = []
+    for k in range(5):
+        vm = look_at(torch.tensor([1.5 * k - 3.0, 1.5, 5.0]), torch.zeros(3), torch.tensor([0.0, 1.0, 0.0])).to(device)
+        cams.append(Camera(R=vm[:3, :3].contiguous(), T=vm[:3, 3].contiguous(), H=cam0.H, W=cam0.W, fx=cam0.fx,
+                           fy=cam0.fy, cx=cam0.cx, cy=cam0.cy))
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    batch = ms.render_gaussians_batch(*g, cams, background_color=bg)
+    assert batch.shape == (5, cam0.H, cam0.W, 3)
+    for k, c in enumerate(cams):
+        assert torch.equal(batch[k], ms.render_gaussians(*g, c, background_color=bg, backend="hip"))
+    assert not torch.equal(batch[0], batch[4])
