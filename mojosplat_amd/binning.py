@@ -65,9 +65,52 @@ def _pinned_info(dev) -> Tensor:
     return p
 
 
+MAX_LDS_TILES = 40960  # 160 KB of LDS / 4 B per tile counter (csrc/binning.hip)
+
+
+def lds_row_bands(img_height: int, img_width: int, tile_size: int):
+    """Tile-row bands such that each band's tile count fits the binning kernels' LDS histogram
+    (one band for anything up to 40 960 tiles, i.e. every BASELINE config incl. 3840x2160)."""
+    th, tw = -(-img_height // tile_size), -(-img_width // tile_size)
+    if tw > MAX_LDS_TILES:
+        raise ValueError(f"{tw} tiles per row exceed the binning kernels' LDS budget")
+    rows = max(1, MAX_LDS_TILES // tw)
+    return [(r, min(r + rows, th)) for r in range(0, th, rows)]
+
+
 def bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size: int, tile_width: int,
                                tile_height: int, row_range: Optional[Tuple[int, int]] = None,
                                return_isect_ids: bool = False, return_tiles_per_gauss: bool = False):
+    if row_range is None and tile_width * tile_height > MAX_LDS_TILES:
+        # huge tile grids: bin band by band and splice the lists (bands are disjoint tile-id ranges,
+        # so concatenation in band order IS the global (tile, depth, id) order)
+        parts, off = [], 0
+        ranges = None
+        for band in lds_row_bands(tile_height * tile_size, tile_width * tile_size, tile_size):
+            out = _bin_hip_band(means2d, radii, depths, tile_size, tile_width, tile_height, band,
+                                return_isect_ids, return_tiles_per_gauss)
+            r = out[1]
+            if ranges is None:
+                ranges = torch.zeros_like(r)
+            ranges[band[0]:band[1]] = r[band[0]:band[1]] + off
+            ranges[band[1]:] = off + out[0].numel()       # tiles after this band start where it ends
+            off += out[0].numel()
+            parts.append(out)
+        res = (torch.cat([p[0] for p in parts]), ranges)
+        k = 2
+        if return_isect_ids:
+            res += (torch.cat([p[k] for p in parts]),)
+            k += 1
+        if return_tiles_per_gauss:
+            res += (sum(p[k] for p in parts),)
+        return res
+    return _bin_hip_band(means2d, radii, depths, tile_size, tile_width, tile_height, row_range,
+                         return_isect_ids, return_tiles_per_gauss)
+
+
+def _bin_hip_band(means2d, radii, depths, tile_size: int, tile_width: int, tile_height: int,
+                  row_range: Optional[Tuple[int, int]] = None, return_isect_ids: bool = False,
+                  return_tiles_per_gauss: bool = False):
     """gfx950 binning.  One device->host read (M and the over-sized-tile counts) sits between
     the count and the emit call, where gsplat.isect_tiles has its own (binning.py:73-82).
 

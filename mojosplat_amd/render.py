@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from .binning import bin_gaussians_to_tiles
+from .binning import bin_gaussians_to_tiles, lds_row_bands
 from .projection import project_gaussians
 from .rasterization import rasterize_gaussians
 from .utils import Camera
@@ -61,9 +61,20 @@ def render_gaussians(
         if sh_degree is not None and features.shape[-1] > 3:
             colors, bg = features[..., :3], bg[:3]  # the reference's placeholder (render.py:82-87)
         evs = _STAGE_HOOK() if _STAGE_HOOK is not None else None
-        img, _ = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
-                                stage_events=evs)
-        return img
+        bands = lds_row_bands(camera.H, camera.W, tile_size)
+        if len(bands) == 1:
+            img, _ = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
+                                    stage_events=evs)
+            return img
+        # tile grids beyond the binning kernels' LDS budget (> 40 960 tiles, e.g. 8K x 4K frames) are
+        # rendered as consecutive row bands into one framebuffer
+        img = torch.empty((camera.H, camera.W, colors.shape[-1]), dtype=torch.float32, device=means3d.device)
+        total = 0
+        for band in bands:
+            _, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
+                                  row_range=band, out=img)
+            total += m
+        return img if total > 0 else torch.zeros_like(img)
 
     means2d, conics, depths, radii = project_gaussians(means3d, scales, quats, opacities, camera,
                                                        backend=backend)
