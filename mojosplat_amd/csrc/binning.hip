@@ -261,7 +261,7 @@ __device__ __forceinline__ int next_pow2(int n) {
 }
 
 constexpr int kMaxBuckets = 2048;  // bucket-array cap (8 KB of counters: two 8192-key workgroups fit a CU)
-constexpr int kBucketFallback = 48;  // a bucket this crowded sends the tile to the bitonic path
+constexpr int kBucketFallback = 512;  // a bucket this crowded (identical depths en masse) sends the tile to the bitonic path
 
 template <int THREADS, int E>
 struct SortCfg {
