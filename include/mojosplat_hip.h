@@ -116,6 +116,17 @@ int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
                         uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
                         void *stream);
 
+/* ms_project_gaussians_fwd + ms_isect_tiles_count in ONE pass over the Gaussians (same outputs,
+ * same semantics; the tile grid is derived from W, H, tile_size).  What ms_render_fwd starts a
+ * frame with: the projected means / radii are not re-read and one kernel launch is saved. */
+int ms_project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                           const float *quats, const float *opacities, const float *viewmat, float fx,
+                           float fy, float cx, float cy, int W, int H, float eps2d, float near_plane,
+                           float far_plane, float radius_clip, int tile_size, int row_begin,
+                           int row_end, float *means2d, float *conics, float *depths, int32_t *radii,
+                           void *workspace, size_t workspace_bytes, int32_t *tile_ranges,
+                           int64_t *isect_info, void *stream);
+
 /* gsplat.isect_offset_encode: from SORTED keys (tile<<32|depth_bits) to per-tile start
  * offsets i32[tile_h*tile_w] (empty tiles inherit the next start; trailing tiles get M). */
 int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_w, int tile_h,

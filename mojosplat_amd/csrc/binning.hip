@@ -22,7 +22,7 @@
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
 #include <stdlib.h>
 
-#include "ms_common.hpp"
+#include "project_device.hpp"
 
 namespace {
 
@@ -57,13 +57,41 @@ __device__ __forceinline__ void tile_bbox(float2 m, int2 r, const Grid &g, int &
     y1 = max(y1, y0);
 }
 
-// Walk every (Gaussian, tile) pair of one chunk; F(local_tile, gaussian_index, lane_payload).
+// One step of a chunk walk: every lane of the workgroup brings the tile box of ONE Gaussian
+// (index base + threadIdx.x, n = 0 if it has none); F(local_tile, gaussian_index) is called for
+// every tile of every box.  Small boxes are walked by their own lane, big ones by the whole wave.
+// Must be reached by all lanes of the wave (ballot / shuffles inside).
+template <class F>
+__device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0, int y1, int n, const Grid &g,
+                                           F &&f) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = base + threadIdx.x;
+    const bool big = n > kCoopThreshold;
+    if (n > 0 && !big) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) f((y - g.row_begin) * g.tw + x, i);
+    }
+    unsigned long long bigmask = __ballot(big);
+    while (bigmask) {
+        const int src = __ffsll((long long)bigmask) - 1;
+        bigmask &= bigmask - 1;
+        const int bx0 = __shfl(x0, src), bx1 = __shfl(x1, src);
+        const int by0 = __shfl(y0, src), by1 = __shfl(y1, src);
+        const int64_t bi = base + (threadIdx.x & ~63) + src;
+        const int w = bx1 - bx0, cnt = w * (by1 - by0);
+        for (int k = lane; k < cnt; k += 64) {
+            const int y = by0 + k / w, x = bx0 + k % w;
+            f((y - g.row_begin) * g.tw + x, bi);
+        }
+    }
+}
+
+// Walk every (Gaussian, tile) pair of one chunk; F(local_tile, gaussian_index).
 // Small boxes are walked by their own lane, big ones by the whole wave.
 template <class F>
 __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const float *means2d,
                                                const int32_t *radii, const Grid &g,
                                                int32_t *tiles_per_gauss, F &&f) {
-    const int lane = threadIdx.x & 63;
     for (int64_t base = i0; base < i1; base += kHistThreads) {
         const int64_t i = base + threadIdx.x;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
@@ -76,25 +104,44 @@ __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const flo
             }
             if (tiles_per_gauss) tiles_per_gauss[i] = n;
         }
-        const bool big = n > kCoopThreshold;
-        if (n > 0 && !big) {
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) f((y - g.row_begin) * g.tw + x, i);
-        }
-        unsigned long long bigmask = __ballot(big);
-        while (bigmask) {
-            const int src = __ffsll((long long)bigmask) - 1;
-            bigmask &= bigmask - 1;
-            const int bx0 = __shfl(x0, src), bx1 = __shfl(x1, src);
-            const int by0 = __shfl(y0, src), by1 = __shfl(y1, src);
-            const int64_t bi = base + (threadIdx.x & ~63) + src;
-            const int w = bx1 - bx0, cnt = w * (by1 - by0);
-            for (int k = lane; k < cnt; k += 64) {
-                const int y = by0 + k / w, x = bx0 + k % w;
-                f((y - g.row_begin) * g.tw + x, bi);
+        walk_boxes(base, x0, x1, y0, y1, n, g, f);
+    }
+}
+
+// Fused projection + tile counting (the first two kernels of a frame in one): every lane projects
+// its Gaussian (project_device.hpp), stores the projected record, and counts the tiles of its box
+// in the workgroup's LDS histogram.  Same chunking as k_isect_hist / k_isect_scatter.
+__global__ __launch_bounds__(kHistThreads) void k_project_hist(
+    int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
+    const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
+    ms::ProjParams P, Grid g, int64_t chunk, float *__restrict__ means2d, float *__restrict__ conics,
+    float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t s_cnt[];
+    const int T_local = (g.row_end - g.row_begin) * g.tw;
+    for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
+    for (int64_t base = i0; base < i1; base += kHistThreads) {
+        const int64_t i = base + threadIdx.x;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
+        if (i < i1) {
+            const ms::ProjOut o = ms::project_one(i, means3d, scales, quats, opacities, viewmat, P);
+            reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
+            conics[3 * i] = o.c0;
+            conics[3 * i + 1] = o.c1;
+            conics[3 * i + 2] = o.c2;
+            depths[i] = o.d;
+            reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
+            if (o.r0 > 0 && o.r1 > 0 && T_local > 0) {
+                tile_bbox(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1);
+                n = (x1 - x0) * (y1 - y0);
             }
         }
+        walk_boxes(base, x0, x1, y0, y1, n, g, [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
     }
+    __syncthreads();
+    uint32_t *row = hist + (size_t)blockIdx.x * T_local;
+    for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
 }
 
 __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
@@ -150,7 +197,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
 }
 
 // One workgroup: exclusive scan of the per-tile counts over the FULL grid (tiles outside
-// the band count 0), tile_ranges, totals and the work lists of over-sized tiles.
+// the band count 0), tile_ranges, totals and the work lists of over-sized tiles.  Each wave owns
+// a contiguous run of tiles and walks it 64 tiles at a time (coalesced loads / int2 stores,
+// wave-level scans), so the kernel is three dependent memory round trips long.
 __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t *__restrict__ tile_count,
                                                           int32_t *__restrict__ tile_ranges,
                                                           int32_t *__restrict__ medium_list,
@@ -161,43 +210,52 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
     __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max;
     const int T = g.tw * g.th;
     const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
-    const int K = (T + 1023) / 1024;
-    const int t0 = threadIdx.x * K, t1 = min(T, t0 + K);
-    if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; }
-    unsigned long long sum = 0;
-    for (int t = t0; t < t1; ++t)
-        if (t >= band0 && t < band1) sum += tile_count[t - band0];
-    // block exclusive scan of `sum`
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long incl = sum;
+    const int per_wave = ((T + 15) / 16 + 63) & ~63;   // tiles per wave, a multiple of 64
+    const int w0 = w * per_wave, w1 = min(T, w0 + per_wave);
+    if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; }
+    auto count_of = [&](int t) -> unsigned int {
+        return (t < w1 && t >= band0 && t < band1) ? tile_count[t - band0] : 0u;
+    };
+    // pass 1: this wave's total
+    unsigned long long sum = 0;
+    for (int t = w0 + lane; t < w1; t += 64) sum += count_of(t);
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) s_wave[w] = incl;
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) s_wave[w] = sum;
     __syncthreads();
-    unsigned long long wave_base = 0, grand = 0;
+    unsigned long long run = 0, grand = 0;
 #pragma unroll
     for (int ww = 0; ww < 16; ++ww) {
-        if (ww < w) wave_base += s_wave[ww];
+        if (ww < w) run += s_wave[ww];
         grand += s_wave[ww];
     }
-    unsigned long long run = wave_base + incl - sum;
+    // pass 2: offsets, ranges, classes
     unsigned int lmax = 0;
-    for (int t = t0; t < t1; ++t) {
-        const unsigned int c = (t >= band0 && t < band1) ? tile_count[t - band0] : 0u;
-        // offsets saturate at INT32_MAX; the host rejects M > INT32_MAX before emitting
-        const unsigned long long e = run + c;
-        tile_ranges[2 * t] = (int32_t)min(run, 0x7fffffffull);
-        tile_ranges[2 * t + 1] = (int32_t)min(e, 0x7fffffffull);
-        run = e;
-        lmax = max(lmax, c);
-        if (c > (unsigned)kLargeCapDecl) xl_list[atomicAdd(&s_nxl, 1u)] = t;
-        else if (c > (unsigned)kMediumCapDecl) large_list[atomicAdd(&s_nlarge, 1u)] = t;
-        else if (c > (unsigned)kSmallCapDecl) medium_list[atomicAdd(&s_nmedium, 1u)] = t;
+    for (int tb = w0; tb < w1; tb += 64) {
+        const int t = tb + lane;
+        const unsigned int c = count_of(t);
+        unsigned int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int o = (unsigned int)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (t < w1) {
+            // offsets saturate at INT32_MAX; the host rejects M > INT32_MAX before emitting
+            const unsigned long long b = run + (incl - c), e = run + incl;
+            reinterpret_cast<int2 *>(tile_ranges)[t] =
+                make_int2((int32_t)min(b, 0x7fffffffull), (int32_t)min(e, 0x7fffffffull));
+            lmax = max(lmax, c);
+            if (c > (unsigned)kLargeCapDecl) xl_list[atomicAdd(&s_nxl, 1u)] = t;
+            else if (c > (unsigned)kMediumCapDecl) large_list[atomicAdd(&s_nlarge, 1u)] = t;
+            else if (c > (unsigned)kSmallCapDecl) medium_list[atomicAdd(&s_nmedium, 1u)] = t;
+        }
+        run += (unsigned long long)__shfl((int)incl, 63);  // step total (< 2^31 per 64 tiles by int32 M limit)
     }
-    atomicMax(&s_max, lmax);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (unsigned int)__shfl_xor((int)lmax, d));
+    if (lane == 0) atomicMax(&s_max, lmax);
     __syncthreads();
     if (threadIdx.x == 0) {
         info[0] = (int64_t)grand;
@@ -557,6 +615,22 @@ int allow_big_lds(K kernel) {
 
 }  // namespace
 
+namespace {
+// per-tile prefix over the partial histograms -> tile_ranges, M, work lists
+int count_tail(const Plan &p, const Grid &g, uint32_t *hist, uint32_t *count, int32_t *medium, int32_t *large,
+               int32_t *xl, int32_t *tile_ranges, int64_t *isect_info, hipStream_t stream) {
+    if (p.T_local > 0) {
+        hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
+                           p.G, p.T_local, hist, count);
+        MS_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium, large, xl,
+                       isect_info);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+}  // namespace
+
 extern "C" size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h) {
     Plan p;
     if (tile_w <= 0 || tile_h <= 0 || (int64_t)tile_w * tile_h >= (1ll << 30)) return 0;
@@ -574,8 +648,8 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
     if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
     MS_REQUIRE(workspace && tile_ranges && isect_info && (N == 0 || (means2d && radii)),
                MS_ERR_INVALID_ARG, "isect_count: null pointer");
-    MS_REQUIRE(((uintptr_t)means2d & 7) == 0 && ((uintptr_t)radii & 7) == 0, MS_ERR_INVALID_ARG,
-               "isect_count: means2d/radii must be 8-byte aligned");
+    MS_REQUIRE(((uintptr_t)means2d & 7) == 0 && ((uintptr_t)radii & 7) == 0 && ((uintptr_t)tile_ranges & 7) == 0,
+               MS_ERR_INVALID_ARG, "isect_count: means2d/radii/tile_ranges must be 8-byte aligned");
     Plan p;
     const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
     MS_REQUIRE(fits, MS_ERR_TOO_LARGE,
@@ -596,16 +670,55 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
         hipLaunchKernelGGL(k_isect_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d,
                            radii, g, p.chunk, hist, tiles_per_gauss);
         MS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0,
-                           stream, p.G, p.T_local, hist, count);
-        MS_LAUNCH_CHECK();
     } else if (tiles_per_gauss && N > 0) {
         MS_HIP(hipMemsetAsync(tiles_per_gauss, 0, (size_t)N * 4, stream));
     }
-    hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium,
-                       large, xl, isect_info);
-    MS_LAUNCH_CHECK();
-    return MS_OK;
+    return count_tail(p, g, hist, count, medium, large, xl, tile_ranges, isect_info, stream);
+}
+
+// Projection + tile counting in one pass over the Gaussians (what a frame starts with): the
+// outputs of ms_project_gaussians_fwd AND of ms_isect_tiles_count, without re-reading the
+// projected means / radii and with one kernel launch fewer.
+extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                                      const float *quats, const float *opacities, const float *viewmat,
+                                      float fx, float fy, float cx, float cy, int W, int H, float eps2d,
+                                      float near_plane, float far_plane, float radius_clip, int tile_size,
+                                      int row_begin, int row_end, float *means2d, float *conics, float *depths,
+                                      int32_t *radii, void *workspace, size_t workspace_bytes,
+                                      int32_t *tile_ranges, int64_t *isect_info, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && fx != 0.f && fy != 0.f, MS_ERR_INVALID_ARG,
+               "project_isect_count: bad sizes / camera");
+    const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
+    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
+    MS_REQUIRE(workspace && tile_ranges && isect_info &&
+                   (N == 0 || (means3d && scales && quats && viewmat && means2d && conics && depths && radii)),
+               MS_ERR_INVALID_ARG, "project_isect_count: null pointer");
+    MS_REQUIRE(((uintptr_t)quats & 15) == 0 && ((uintptr_t)means2d & 7) == 0 && ((uintptr_t)radii & 7) == 0 &&
+                   ((uintptr_t)tile_ranges & 7) == 0,
+               MS_ERR_INVALID_ARG, "project_isect_count: quats 16-byte, means2d/radii/tile_ranges 8-byte aligned");
+    Plan p;
+    const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
+    MS_REQUIRE(fits, MS_ERR_TOO_LARGE, "project_isect_count: band of %d tiles needs %zu B of LDS (max %zu)",
+               p.T_local, p.lds_bytes, kMaxLds);
+    MS_REQUIRE(workspace_bytes >= p.total, MS_ERR_WORKSPACE, "project_isect_count: workspace %zu < %zu",
+               workspace_bytes, p.total);
+    char *ws = (char *)workspace;
+    uint32_t *hist = (uint32_t *)(ws + p.off_hist);
+    uint32_t *count = (uint32_t *)(ws + p.off_count);
+    int32_t *medium = (int32_t *)(ws + p.off_medium);
+    int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
+    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+    const ms::ProjParams P = ms::make_proj_params(fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, radius_clip,
+                                                  scales_are_log, opacities != nullptr);
+    if (N > 0) {
+        if (p.lds_bytes > 48 * 1024)
+            if (int rc = allow_big_lds(k_project_hist)) return rc;
+        hipLaunchKernelGGL(k_project_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
+                           quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist);
+        MS_LAUNCH_CHECK();
+    }
+    return count_tail(p, g, hist, count, medium, large, xl, tile_ranges, isect_info, stream);
 }
 
 namespace {

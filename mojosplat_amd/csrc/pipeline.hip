@@ -72,14 +72,13 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     bool speculated = false;
     if (!resume) {
         mark(0);
-        if (int rc = ms_project_gaussians_fwd(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
-                                              cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, means2d, conics,
-                                              depths, radii, stream))
+        // projection + tile counting share one pass over the Gaussians (k_project_hist)
+        if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
+                                            cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, tile_size, r0, r1,
+                                            means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
+                                            ranges, info, stream))
             return rc;
         mark(1);
-        if (int rc = ms_isect_tiles_count(N, means2d, radii, tile_size, tw, th, r0, r1, ws + L.off_isect,
-                                          L.isect_bytes, nullptr, ranges, info, stream))
-            return rc;
         int64_t prev[8];  // the previous frame's record: a hint for what this frame will need
         for (int k = 0; k < 8; ++k) prev[k] = host_info[k];
         MS_HIP(hipMemcpyAsync(host_info, info, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
