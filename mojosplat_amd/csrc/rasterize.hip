@@ -20,7 +20,7 @@
 //     each of the four 8x8 quads), so a staged Gaussian is read from LDS once per block;
 //   * staging: 64 intersections per batch, one per lane.  The staging lane folds log2(e) into
 //     the conic, takes log2(opacity), and tests which quads the alpha >= 1/255 ellipse can reach
-//     (exact bounding box of that ellipse + slack).  The wave then votes: B[q] = ballot(entry
+//     (exact ellipse-vs-rectangle test: clamped 1-D minimisation on the faces nearest the mean).  The wave then votes: B[q] = ballot(entry
 //     reaches quad q) -- a wave-uniform 64-bit mask per quad, no LDS;
 //   * compositing: each quad walks ITS set bits in order with scalar s_ff1 (front-to-back per
 //     pixel is preserved: the four quads are disjoint pixel sets).  Culled (quad, entry) pairs
@@ -165,16 +165,32 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
         if (b0 + lane < end && r_op >= ms::kAlphaThreshold) {
             const float det = r_ca * r_cc - r_cb * r_cb;
             if (det > 0.f && r_ca > 0.f && r_cc > 0.f) {
-                // sigma <= ln(255 o): bounding box mean +- sqrt(2 ln(255 o) cov_xx|yy), cov = conic^-1
-                const float smax2 = 2.0f * __logf(r_op * 255.0f) * 1.0001f + 1e-4f;
-                const float inv = 1.0f / det;
-                const float hx = sqrtf(smax2 * r_cc * inv) * 1.0001f + 0.01f;
-                const float hy = sqrtf(smax2 * r_ca * inv) * 1.0001f + 0.01f;
-                const bool x0 = (r_mx + hx >= fbx) && (r_mx - hx <= fbx + 7.0f);
-                const bool x1 = (r_mx + hx >= fbx + 8.0f) && (r_mx - hx <= fbx + 15.0f);
-                const bool y0 = (r_my + hy >= fby) && (r_my - hy <= fby + 7.0f);
-                const bool y1 = (r_my + hy >= fby + 8.0f) && (r_my - hy <= fby + 15.0f);
-                mask = (x0 && y0 ? 1 : 0) | (x1 && y0 ? 2 : 0) | (x0 && y1 ? 4 : 0) | (x1 && y1 ? 8 : 0);
+                // A quad can blend this Gaussian iff min over the quad's pixel-centre rectangle of
+                // sigma(p - mean) <= ln(255 o).  sigma is a convex quadratic, so the minimum over a box
+                // is 0 if the mean is inside, else it sits on the face(s) nearest the mean: one 1-D
+                // clamped minimisation per such face (exact; tighter than the ellipse's bounding box
+                // for elongated / rotated Gaussians).  Slack keeps the test conservative w.r.t. the
+                // per-pixel alpha >= 1/255 decision.
+                const float smax = __logf(r_op * 255.0f) * 1.0001f + 1e-4f;
+                const float nb_c = -r_cb / r_cc, nb_a = -r_cb / r_ca;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xl = fbx + (float)((q & 1) * 8) - r_mx, xh = xl + 7.0f;   // rectangle - mean
+                    const float yl = fby + (float)((q >> 1) * 8) - r_my, yh = yl + 7.0f;
+                    const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
+                    float best = (in_x && in_y) ? 0.f : 3.0e38f;
+                    if (!in_x) {
+                        const float dx = xl > 0.f ? xl : xh;
+                        const float dy = fminf(fmaxf(nb_c * dx, yl), yh);
+                        best = 0.5f * (r_ca * dx * dx + r_cc * dy * dy) + r_cb * dx * dy;
+                    }
+                    if (!in_y) {
+                        const float dy = yl > 0.f ? yl : yh;
+                        const float dx = fminf(fmaxf(nb_a * dy, xl), xh);
+                        best = fminf(best, 0.5f * (r_ca * dx * dx + r_cc * dy * dy) + r_cb * dx * dy);
+                    }
+                    mask |= (best <= smax) ? (1 << q) : 0;
+                }
             } else {
                 mask = 0xf;  // not positive definite: no bound, evaluate everywhere
             }
