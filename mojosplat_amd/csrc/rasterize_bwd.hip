@@ -275,15 +275,27 @@ __global__ __launch_bounds__(64) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
             if (op >= ms::kAlphaThreshold) {
                 const float det = ca * cc - cb * cb;
                 if (det > 0.f && ca > 0.f && cc > 0.f) {
-                    const float smax2 = 2.0f * __logf(op * 255.0f) * 1.0001f + 1e-4f;
-                    const float inv = 1.0f / det;
-                    const float hx = sqrtf(smax2 * cc * inv) * 1.0001f + 0.01f;
-                    const float hy = sqrtf(smax2 * ca * inv) * 1.0001f + 0.01f;
-                    const bool x0 = (mx + hx >= fbx) && (mx - hx <= fbx + 7.0f);
-                    const bool x1 = (mx + hx >= fbx + 8.0f) && (mx - hx <= fbx + 15.0f);
-                    const bool y0 = (my + hy >= fby) && (my - hy <= fby + 7.0f);
-                    const bool y1 = (my + hy >= fby + 8.0f) && (my - hy <= fby + 15.0f);
-                    mask = (x0 && y0 ? 1 : 0) | (x1 && y0 ? 2 : 0) | (x0 && y1 ? 4 : 0) | (x1 && y1 ? 8 : 0);
+                    // exact ellipse-vs-quad test, as in the forward kernel (rasterize.hip)
+                    const float smax = __logf(op * 255.0f) * 1.0001f + 1e-4f;
+                    const float nb_c = -cb / cc, nb_a = -cb / ca;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xl = fbx + (float)((q & 1) * 8) - mx, xh = xl + 7.0f;
+                        const float yl = fby + (float)((q >> 1) * 8) - my, yh = yl + 7.0f;
+                        const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
+                        float best = (in_x && in_y) ? 0.f : 3.0e38f;
+                        if (!in_x) {
+                            const float dx = xl > 0.f ? xl : xh;
+                            const float dy = fminf(fmaxf(nb_c * dx, yl), yh);
+                            best = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                        }
+                        if (!in_y) {
+                            const float dy = yl > 0.f ? yl : yh;
+                            const float dx = fminf(fmaxf(nb_a * dy, xl), xh);
+                            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
+                        }
+                        mask |= (best <= smax) ? (1 << q) : 0;
+                    }
                 } else {
                     mask = 0xf;
                 }
