@@ -10,15 +10,18 @@
 // traffic per pass), the tile id is resolved by ONE bucket pass whose histograms live in LDS
 // (the tile grid of a 1080p frame is 8 160 counters = 32 KB, a 4K frame 130 KB -- both fit the
 // 160 KB LDS of a CU), and depth order is established inside each tile segment by an LDS
-// bitonic sort on (depth_bits<<32 | gaussian) keys.  No global atomics anywhere: LDS atomics
-// only, so the HBM side sees M x 8 B written once, read once, and M x 4 B of ids written.
+// counting sort on the depth bits of (depth_bits<<32 | gaussian) keys.  No global atomics
+// anywhere: LDS atomics only, so the HBM side sees M x 8 B written once, read once, and M x 4 B
+// of ids written.
 //
 //   k_isect_hist      G workgroups, each histograms a contiguous chunk of Gaussians into LDS
+//   k_project_hist    the same fused with the projection itself (what ms_render_fwd runs)
 //   k_tile_scan_wg    per tile: exclusive prefix over the G partial counts (16 waves split G)
 //   k_tile_scan_total one workgroup: exclusive scan over tiles -> tile_ranges, M, work lists
 //   k_isect_scatter   same chunks; LDS cursors hand out slots inside each tile segment
-//   k_tile_sort_small one 256-thread workgroup per tile with <= 1024 entries (12 KB LDS)
-//   k_tile_sort_list  work lists of tiles with <= 4096 (48 KB LDS) and <= 16384 entries (144 KB)
+//   k_tile_sort_small one 256-thread workgroup per tile with <= 1024 entries (16 KB LDS)
+//   k_tile_sort_list  work lists of tiles with <= 8192 (74 KB LDS, two per CU) and <= 16384
+//                     entries (136 KB); fixed-size persistent grids on sync-free frames
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
 #include <stdlib.h>
 
