@@ -209,8 +209,32 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
+// Sum 8 per-lane values over the 64 lanes with a halving butterfly: at distance 1, 2, 4 each lane
+// keeps half of its values and receives the partner's matching half (DPP quad_perm / row shifts),
+// so after three steps it holds ONE value -- number (lane & 7) -- summed over its group of 8 lanes;
+// three more single-value steps (distance 8, 16, 32) finish.  27 VALU ops instead of 8 x 7 for
+// eight separate reductions.  Returns the wave total of v[lane & 7] in every lane.
+__device__ __forceinline__ float wave_allreduce8(const float (&v)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    auto xchg1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)); };
+    auto xchg2 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)); };
+    float w[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (b0 ? v[2 * i + 1] : v[2 * i]) + xchg1(b0 ? v[2 * i] : v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) x[i] = (b1 ? w[2 * i + 1] : w[2 * i]) + xchg2(b1 ? w[2 * i] : w[2 * i + 1]);
+    const float send = b2 ? x[0] : x[1];
+    int recv = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x104, 0xf, 0x5, true);      // row_shl:4 -> lanes with bit 2 clear
+    recv = __builtin_amdgcn_update_dpp(recv, __float_as_int(send), 0x114, 0xf, 0xa, false);     // row_shr:4 -> lanes with bit 2 set
+    float y = (b2 ? x[1] : x[0]) + __int_as_float(recv);
+    y += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x128, 0xf, 0xf, true));  // row_ror:8
+    y += __shfl_xor(y, 16);
+    y += __shfl_xor(y, 32);
+    return y;
+}
+
 template <int CP>
-__global__ __launch_bounds__(64) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
+__global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
     const RasterBwdArgs &A = B2.a;
     constexpr int NG = 6 + CP;
     constexpr float kLog2e = 1.4426950408889634f;
@@ -365,21 +389,14 @@ __global__ __launch_bounds__(64) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
                 }
             }
             if (anyv == 0ull) continue;
-            float tot[NG];
+            // raw sums Sx Sy S1 S2 S3 op c0 c1 -> lanes 0..7; remaining colour channel(s) -> lane 63
+            const float first8[8] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]};
+            const float y = wave_allreduce8(first8, lane);
+            if (lane < 8) s_grad[t * kRow + lane] = y;
 #pragma unroll
-            for (int j = 0; j < NG; ++j) tot[j] = wave_sum_to_lane63(acc[j]);
-            if (lane == 63) {
-                // undo the staging scale: a' = -log2e/2 * ca, b' = -log2e * cb, c' = -log2e/2 * cc
-                const float eca = ra.z * (-2.0f / kLog2e), ecb = ra.w * (-1.0f / kLog2e), ecc = rb.x * (-2.0f / kLog2e);
-                float *row = s_grad + t * kRow;
-                row[0] = eca * tot[0] + ecb * tot[1];
-                row[1] = ecb * tot[0] + ecc * tot[1];
-                row[2] = 0.5f * tot[2];
-                row[3] = tot[3];
-                row[4] = 0.5f * tot[4];
-                row[5] = tot[5];
-#pragma unroll
-                for (int k = 0; k < CP; ++k) row[6 + k] = tot[6 + k];
+            for (int j = 8; j < NG; ++j) {
+                const float tj = wave_sum_to_lane63(acc[j]);
+                if (lane == 63) s_grad[t * kRow + j] = tj;
             }
             flush |= 1ull << t;
         }
@@ -391,7 +408,18 @@ __global__ __launch_bounds__(64) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
             const int r = r4 + rsub;
             if (((flush >> r) & 1ull) && colm < NG) {
                 const int gid = __float_as_int(s_c[r].z);
-                atomicAdd(B2.packed + (size_t)gid * kRow + colm, s_grad[r * kRow + colm]);
+                const float *raw = s_grad + r * kRow;
+                float val = raw[colm];
+                if (colm < 2) {
+                    // undo the staging scale: a' = -log2e/2 * ca, b' = -log2e * cb, c' = -log2e/2 * cc
+                    const float4 qa = s_a[r];
+                    const float ecb = qa.w * (-1.0f / kLog2e);
+                    const float diag = (colm == 0 ? qa.z : s_b[r].x) * (-2.0f / kLog2e);   // ca for mean.x, cc for mean.y
+                    val = colm == 0 ? diag * raw[0] + ecb * raw[1] : ecb * raw[0] + diag * raw[1];
+                } else if (colm == 2 || colm == 4) {
+                    val *= 0.5f;
+                }
+                atomicAdd(B2.packed + (size_t)gid * kRow + colm, val);
             }
         }
     }
