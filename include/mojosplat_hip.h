@@ -89,8 +89,11 @@ int ms_project_gaussians_fwd(int64_t N, const float *means3d, const float *scale
  *        (tiles outside the band get empty ranges);
  *        tiles_per_gauss i32[N] or NULL;
  *        isect_info i64[8] (device): {M, largest per-tile count, #tiles in the medium /
- *        large / merge-fallback sort classes, 0, 0, 0}.  Copy it to the host to size
- *        flatten_ids and to drive ms_isect_tiles_emit.
+ *        large / merge-fallback sort classes, 0, G_on, 0}.  G_on = number of Gaussians whose
+ *        tile box touches the FULL grid, whatever the band: a band-sharded caller applies
+ *        the reference's frame-level "no intersections -> zeros image" rule
+ *        (mojosplat/render.py:73-76) from it without a collective.  Copy the record to the
+ *        host to size flatten_ids and to drive ms_isect_tiles_emit.
  *
  * ms_isect_tiles_emit: scatter (depth,id) keys into their tile segments and depth-sort
  * every segment.  Order inside a tile: ascending (float bits of depth, Gaussian index) --
@@ -194,6 +197,15 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  *                frame, emit + rasterise are enqueued speculatively against the buffer's
  *                capacity BEFORE the wait, so the GPU never idles (an overflowing frame is
  *                detected and redone on the exact path).
+ *   resume     : which half of the frame to run (enum below).  MS_RENDER_WHOLE = everything;
+ *                MS_RENDER_RESUME = the redo after MS_ERR_WORKSPACE; MS_RENDER_BEGIN enqueues
+ *                the frame (speculatively where it can) and returns WITHOUT waiting, and a
+ *                later MS_RENDER_FINISH call with the same arguments does the wait, the check
+ *                and, if needed, the exact redo -- so a host that renders independent frames
+ *                (several views, or consecutive frames of a pipeline) can enqueue frame k+1
+ *                before it waits for frame k's size record.  Every frame in flight needs its
+ *                own workspace, isect_buf, host_info and sync_event; host_info[7] is the
+ *                library's own slot between BEGIN and FINISH.
  *   stage_events: NULL, or 4 hipEvent_t recorded on `stream` at: start, after projection,
  *                after binning, after rasterisation (for in-situ kernel timing).
  * [tile_row_begin, tile_row_end) restricts binning and rasterisation to a band of tile rows
@@ -201,6 +213,7 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  * Whole-image calls: M == 0 yields a ZERO image (reference render.py:73-76), otherwise
  * render_colors f32[H,W,CDIM] = composited colours + T * background.
  * ------------------------------------------------------------------------------------- */
+enum { MS_RENDER_WHOLE = 0, MS_RENDER_RESUME = 1, MS_RENDER_BEGIN = 2, MS_RENDER_FINISH = 3 };
 size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h);
 size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch);
 int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,

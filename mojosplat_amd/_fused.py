@@ -31,74 +31,119 @@ def _dev_state(dev, lane=0):
 def _grow(st, key, nbytes, dev, slack=1.0):
     buf = st[key]
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # kernels of earlier frames (possibly on a lane stream the allocator does not know this
+            # buffer is used on) may still read the old block: let them drain before it is released
+            torch.cuda.synchronize(dev)
         buf = torch.empty(int(nbytes * slack) + 256, dtype=torch.uint8, device=dev)
         st[key] = buf
     return buf
 
 
+WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
+
+
+class _Frame:
+    """One ms_render_fwd frame: its marshalled arguments and the lane whose scratch it occupies.
+    `run(phase)` makes the library call; `finish()` completes a frame that was only begun."""
+
+    def __init__(self, means3d, scales, quats, opacities, colors, camera, background, tile_size,
+                 stage_events, row_range, out, lane, stream=None):
+        self.L = L = _hip.lib()
+        self.dev = dev = means3d.device
+        N = means3d.shape[0]
+        means3d, scales, quats = _hip.f32c(means3d), _hip.f32c(scales), _hip.f32c(quats)
+        op = _hip.f32c(opacities.reshape(-1))
+        if colors.dtype == torch.float16:
+            cdt, colors = 1, colors.contiguous()
+        else:
+            cdt, colors = 0, _hip.f32c(colors)
+        C = colors.shape[1]
+        assert means3d.shape == (N, 3) and scales.shape == (N, 3) and quats.shape == (N, 4)
+        assert op.shape == (N,) and colors.shape == (N, C)
+        bg = None if background is None else _hip.f32c(background.reshape(-1))
+        H, W = camera.H, camera.W
+        th, tw = -(-H // tile_size), -(-W // tile_size)
+        vm = camera._viewmat_f32()
+        if vm.device != dev:
+            vm = vm.to(dev)
+        self.st = st = _dev_state(dev, lane)
+        assert not st.get("busy"), "a begun frame still occupies this lane: finish it first"
+        ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
+        r0, r1 = (0, th) if row_range is None else row_range
+        if out is not None:
+            assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
+            assert out.shape[0] >= H and tuple(out.shape[1:]) == (W, C)
+            self.img = out
+        else:
+            self.img = torch.empty((H, W, C), dtype=torch.float32, device=dev)
+        evs = None
+        if stage_events is not None:
+            evs = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
+        self.keep = (means3d, scales, quats, op, colors, bg, vm, ws)  # keep the marshalled tensors alive
+        self.head = (N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(op), _hip.ptr(colors),
+                     cdt, C, _hip.ptr(vm), camera.fx, camera.fy, camera.cx, camera.cy, W, H, EPS2D, camera.near,
+                     camera.far, tile_size, r0, r1, _hip.ptr(bg), _hip.ptr(ws), ws.numel())
+        self.tail = (_hip.ptr(self.img), evs,
+                     ctypes.c_void_p(st["ev"].cuda_event) if st.get("speculate", True) else None,
+                     _hip.stream(dev) if stream is None else ctypes.c_void_p(stream))
+        self.host_ptr = ctypes.c_void_p(st["host"].data_ptr())
+
+    def run(self, phase):
+        isect = self.st["isect"]
+        return self.L.ms_render_fwd(*self.head, _hip.ptr(isect), 0 if isect is None else isect.numel(),
+                                    self.host_ptr, phase, *self.tail)
+
+    def begin(self):
+        with _hip.on_device(self.dev):
+            _hip.check(self.run(BEGIN), "ms_render_fwd(begin)")
+        self.st["busy"] = True
+        return self
+
+    def finish(self, phase=FINISH, info=None):
+        """-> (image, M) of the band.  Waits for the frame's size record, redoes the frame on the
+        exact path if the speculation did not hold (growing the intersection buffer if needed)."""
+        st, host = self.st, self.st["host"]
+        with _hip.on_device(self.dev):
+            rc = self.run(phase)
+            if rc == 2:  # MS_ERR_WORKSPACE: the intersection buffer is too small for this frame's M
+                need = int(host[5])
+                if need > 0 and (st["isect"] is None or st["isect"].numel() < need):
+                    _grow(st, "isect", need, self.dev, slack=1.25)
+                    rc = self.run(RESUME)
+            st["busy"] = False
+            _hip.check(rc, "ms_render_fwd")
+        # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
+        # on the exact path); do not speculate on the next frame of such a scene
+        st["speculate"] = int(host[4]) == 0
+        if info is not None:
+            info["on_grid"] = int(host[6])
+        return self.img, int(host[0])
+
+
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                   stage_events=None, row_range=None, out=None, lane=0):
+                   stage_events=None, row_range=None, out=None, lane=0, info=None):
     """-> (image (H,W,C) f32, M).  `background` may be None.  stage_events: None or a list of 4
     torch.cuda.Event that have been recorded once (so their handles exist).
     row_range=(r0, r1) renders only tile rows [r0, r1) into `out` (a caller-owned framebuffer of
     at least H rows: the multi-GPU gather buffer); M is then the band's intersection count.
-    `lane` selects an independent set of scratch buffers (multi-view batches keep two frames in
-    flight on two streams, each with its own lane)."""
-    L = _hip.lib()
-    dev = means3d.device
-    N = means3d.shape[0]
-    means3d, scales, quats = _hip.f32c(means3d), _hip.f32c(scales), _hip.f32c(quats)
-    op = _hip.f32c(opacities.reshape(-1))
-    if colors.dtype == torch.float16:
-        cdt, colors = 1, colors.contiguous()
-    else:
-        cdt, colors = 0, _hip.f32c(colors)
-    C = colors.shape[1]
-    assert means3d.shape == (N, 3) and scales.shape == (N, 3) and quats.shape == (N, 4)
-    assert op.shape == (N,) and colors.shape == (N, C)
-    bg = None if background is None else _hip.f32c(background.reshape(-1))
-    H, W = camera.H, camera.W
-    th, tw = -(-H // tile_size), -(-W // tile_size)
-    vm = camera._viewmat_f32()
-    if vm.device != dev:
-        vm = vm.to(dev)
+    `lane` selects an independent set of scratch buffers (frames in flight at the same time each
+    need their own).  `info`: optional dict, receives `on_grid` = number of Gaussians touching the
+    FULL tile grid (band-independent)."""
+    return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
+                  stage_events, row_range, out, lane).finish(WHOLE, info)
 
-    st = _dev_state(dev, lane)
-    ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
-    isect = st["isect"]
-    host = st["host"]
-    r0, r1 = (0, th) if row_range is None else row_range
-    if out is not None:
-        assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
-        assert out.shape[0] >= H and tuple(out.shape[1:]) == (W, C)
-        img = out
-    else:
-        img = torch.empty((H, W, C), dtype=torch.float32, device=dev)
-    evs = None
-    if stage_events is not None:
-        evs = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
 
-    def call(resume):
-        return L.ms_render_fwd(
-            N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(op), _hip.ptr(colors), cdt, C,
-            _hip.ptr(vm), camera.fx, camera.fy, camera.cx, camera.cy, W, H, EPS2D, camera.near, camera.far,
-            tile_size, r0, r1, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
-            0 if isect is None else isect.numel(), ctypes.c_void_p(host.data_ptr()), resume, _hip.ptr(img),
-            evs, ctypes.c_void_p(st["ev"].cuda_event) if st.get("speculate", True) else None,
-            _hip.stream(dev))
-
-    with torch.cuda.device(dev):
-        rc = call(0)
-        if rc == 2:  # MS_ERR_WORKSPACE: the intersection buffer is too small for this frame's M
-            need = int(host[5])
-            if need > 0 and (isect is None or isect.numel() < need):
-                isect = _grow(st, "isect", need, dev, slack=1.25)
-                rc = call(1)
-        _hip.check(rc, "ms_render_fwd")
-    # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
-    # on the exact path); do not speculate on the next frame of such a scene
-    st["speculate"] = int(host[4]) == 0
-    return img, int(host[0])
+def render_begin_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
+                     row_range=None, out=None, lane=0, stream=None):
+    """Enqueue a frame on the current stream (or on the raw hipStream_t handle `stream`; scratch
+    that a redo has to grow is then allocated on the current stream and must only be used by
+    streams the caller orders after it) WITHOUT waiting for its size record; -> a frame
+    object whose .finish(info=None) -> (image, M) completes it.  The host can begin the next
+    frame (on another lane) before finishing this one, which hides the count -> host -> emit
+    hand-off latency entirely."""
+    return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
+                  None, row_range, out, lane, stream).begin()
 
 
 @torch.no_grad()
@@ -106,8 +151,10 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
     """Render the same Gaussians from several cameras -> (C, H, W, channels) f32.
 
     Views are independent, so two are kept in flight: view i+1's projection / counting (memory and
-    latency bound) runs on a second stream beside view i's rasteriser (VALU bound).  Each lane has
-    its own scratch; the caller's stream waits for both lanes before the batch is handed back."""
+    latency bound) runs on a second stream beside view i's rasteriser (VALU bound), and view i+1 is
+    enqueued (ms_render_fwd BEGIN) before the host waits for view i's size record (FINISH).  Each
+    lane has its own scratch; the caller's stream waits for both lanes before the batch is handed
+    back."""
     dev = means3d.device
     H, W = cameras[0].H, cameras[0].W
     assert all(c.H == H and c.W == W for c in cameras), "all cameras of a batch share one image size"
@@ -117,15 +164,21 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
     lanes = _lane_streams(dev)
     ready = torch.cuda.Event()
     ready.record(cur)
-    counts = []
+    counts, pending = [], None
     for i, cam in enumerate(cameras):
         lane = 1 + (i % len(lanes))
         s = lanes[lane - 1]
         s.wait_event(ready)
         with torch.cuda.stream(s):
-            _, m = render_fwd_hip(means3d, scales, quats, opacities, colors, cam, background, tile_size,
-                                  out=out[i], lane=lane)
-        counts.append(m)
+            frame = render_begin_hip(means3d, scales, quats, opacities, colors, cam, background, tile_size,
+                                     out=out[i], lane=lane)
+        if pending is not None:  # the previous view's record is long written by now
+            with torch.cuda.stream(pending[1]):
+                counts.append(pending[0].finish()[1])
+        pending = (frame, s)
+    if pending is not None:
+        with torch.cuda.stream(pending[1]):
+            counts.append(pending[0].finish()[1])
     for s in lanes:
         cur.wait_stream(s)
     for t in (out, means3d, scales, quats, opacities, colors):

@@ -101,11 +101,17 @@ def load():
 
 def lib():
     """The library, for launching work: additionally requires a visible GPU."""
+    global _gpu_ok
     L = load()
-    if not torch.cuda.is_available():
-        raise HipBackendError("backend='hip' needs a ROCm GPU (torch.cuda.is_available() is False); "
-                              "there is no CPU fallback for this backend")
+    if not _gpu_ok:
+        if not torch.cuda.is_available():
+            raise HipBackendError("backend='hip' needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                  "there is no CPU fallback for this backend")
+        _gpu_ok = True
     return L
+
+
+_gpu_ok = False
 
 
 def check(rc: int, what: str = ""):
@@ -118,8 +124,32 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream(device=None):
+    """hipStream_t of torch's current stream on `device` (what every ms_* call is launched on)."""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else device
+        return c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class on_device:
+    """`with on_device(dev):` -- torch.cuda.device(dev) only when dev is not already current (the
+    context manager costs several microseconds per frame otherwise)."""
+
+    def __init__(self, dev):
+        idx = dev.index if isinstance(dev, torch.device) else dev
+        self.ctx = None if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def require_cuda(*tensors, what="input"):

@@ -65,12 +65,12 @@ def _pinned_info(dev) -> Tensor:
     return p
 
 
-MAX_LDS_TILES = 40960  # 160 KB of LDS / 4 B per tile counter (csrc/binning.hip)
+MAX_LDS_TILES = 40956  # (160 KB of LDS - 16 B) / 4 B per tile counter (csrc/binning.hip make_plan)
 
 
 def lds_row_bands(img_height: int, img_width: int, tile_size: int):
     """Tile-row bands such that each band's tile count fits the binning kernels' LDS histogram
-    (one band for anything up to 40 960 tiles, i.e. every BASELINE config incl. 3840x2160)."""
+    (one band for anything up to ~40.9k tiles, i.e. every BASELINE config incl. 3840x2160)."""
     th, tw = -(-img_height // tile_size), -(-img_width // tile_size)
     if tw > MAX_LDS_TILES:
         raise ValueError(f"{tw} tiles per row exceed the binning kernels' LDS budget")

@@ -46,7 +46,7 @@ __device__ __forceinline__ int clampi(float v, int lo, int hi) {
 }
 
 // gsplat tile bounding box: min inclusive, max exclusive, clamped to the grid, then to the band
-__device__ __forceinline__ void tile_bbox(float2 m, int2 r, const Grid &g, int &x0, int &x1,
+__device__ __forceinline__ bool tile_bbox(float2 m, int2 r, const Grid &g, int &x0, int &x1,
                                           int &y0, int &y1) {
     const float fts = (float)g.ts;
     const float trx = (float)r.x / fts, try_ = (float)r.y / fts;
@@ -55,9 +55,18 @@ __device__ __forceinline__ void tile_bbox(float2 m, int2 r, const Grid &g, int &
     x1 = clampi(ceilf(tx + trx), 0, g.tw);
     y0 = clampi(floorf(ty - try_), 0, g.th);
     y1 = clampi(ceilf(ty + try_), 0, g.th);
+    const bool on_grid = x1 > x0 && y1 > y0;  // before the band clamp: touches some tile of the frame
     y0 = max(y0, g.row_begin);
     y1 = min(y1, g.row_end);
     y1 = max(y1, y0);
+    return on_grid;
+}
+
+// Per-workgroup count of Gaussians whose box touches the full grid (whatever the band): lets a
+// band-sharded caller apply the frame-level "nothing intersects -> zeros image" rule locally.
+__device__ __forceinline__ void count_on_grid(bool on_grid, unsigned int *s_on_grid) {
+    const unsigned long long b = __ballot(on_grid);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(s_on_grid, (unsigned int)__popcll(b));
 }
 
 // One step of a chunk walk: every lane of the workgroup brings the tile box of ONE Gaussian
@@ -94,19 +103,21 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
 template <class F>
 __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const float *means2d,
                                                const int32_t *radii, const Grid &g,
-                                               int32_t *tiles_per_gauss, F &&f) {
+                                               int32_t *tiles_per_gauss, unsigned int *s_on_grid, F &&f) {
     for (int64_t base = i0; base < i1; base += kHistThreads) {
         const int64_t i = base + threadIdx.x;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
+        bool on_grid = false;
         if (i < i1) {
             const int2 r = reinterpret_cast<const int2 *>(radii)[i];
             if (r.x > 0 && r.y > 0) {
                 const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
-                tile_bbox(m, r, g, x0, x1, y0, y1);
+                on_grid = tile_bbox(m, r, g, x0, x1, y0, y1);
                 n = (x1 - x0) * (y1 - y0);
             }
             if (tiles_per_gauss) tiles_per_gauss[i] = n;
         }
+        if (s_on_grid) count_on_grid(on_grid, s_on_grid);
         walk_boxes(base, x0, x1, y0, y1, n, g, f);
     }
 }
@@ -118,15 +129,19 @@ __global__ __launch_bounds__(kHistThreads) void k_project_hist(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     ms::ProjParams P, Grid g, int64_t chunk, float *__restrict__ means2d, float *__restrict__ conics,
-    float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist) {
-    extern __shared__ uint32_t s_cnt[];
+    float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist,
+    uint32_t *__restrict__ wg_on_grid) {
+    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter
     const int T_local = (g.row_end - g.row_begin) * g.tw;
+    unsigned int &s_on_grid = s_cnt[T_local];
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
+    if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
     for (int64_t base = i0; base < i1; base += kHistThreads) {
         const int64_t i = base + threadIdx.x;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
+        bool on_grid = false;
         if (i < i1) {
             const ms::ProjOut o = ms::project_one(i, means3d, scales, quats, opacities, viewmat, P);
             reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
@@ -135,31 +150,37 @@ __global__ __launch_bounds__(kHistThreads) void k_project_hist(
             conics[3 * i + 2] = o.c2;
             depths[i] = o.d;
             reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
-            if (o.r0 > 0 && o.r1 > 0 && T_local > 0) {
-                tile_bbox(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1);
+            if (o.r0 > 0 && o.r1 > 0) {
+                on_grid = tile_bbox(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1);
                 n = (x1 - x0) * (y1 - y0);
             }
         }
+        count_on_grid(on_grid, &s_on_grid);
         walk_boxes(base, x0, x1, y0, y1, n, g, [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
+    if (threadIdx.x == 0) wg_on_grid[blockIdx.x] = s_on_grid;
 }
 
 __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii, Grid g,
-    int64_t chunk, uint32_t *__restrict__ hist, int32_t *__restrict__ tiles_per_gauss) {
-    extern __shared__ uint32_t s_cnt[];
+    int64_t chunk, uint32_t *__restrict__ hist, int32_t *__restrict__ tiles_per_gauss,
+    uint32_t *__restrict__ wg_on_grid) {
+    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter
     const int T_local = (g.row_end - g.row_begin) * g.tw;
+    unsigned int &s_on_grid = s_cnt[T_local];
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
+    if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect(i0, i1, means2d, radii, g, tiles_per_gauss,
+    for_each_isect(i0, i1, means2d, radii, g, tiles_per_gauss, &s_on_grid,
                    [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
+    if (threadIdx.x == 0) wg_on_grid[blockIdx.x] = s_on_grid;
 }
 
 // hist[g][t] -> exclusive prefix over g (in place); tile_count[t] = sum over g.
@@ -208,15 +229,16 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
                                                           int32_t *__restrict__ medium_list,
                                                           int32_t *__restrict__ large_list,
                                                           int32_t *__restrict__ xl_list,
+                                                          const uint32_t *__restrict__ wg_on_grid, int G,
                                                           int64_t *__restrict__ info) {
     __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max;
+    __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
     const int T = g.tw * g.th;
     const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per_wave = ((T + 15) / 16 + 63) & ~63;   // tiles per wave, a multiple of 64
     const int w0 = w * per_wave, w1 = min(T, w0 + per_wave);
-    if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; }
+    if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; }
     auto count_of = [&](int t) -> unsigned int {
         return (t < w1 && t >= band0 && t < band1) ? tile_count[t - band0] : 0u;
     };
@@ -232,6 +254,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
     for (int ww = 0; ww < 16; ++ww) {
         if (ww < w) run += s_wave[ww];
         grand += s_wave[ww];
+    }
+    if ((int)threadIdx.x < G) {  // G <= kMaxG <= blockDim
+        const unsigned int v = wg_on_grid[threadIdx.x];
+        if (v) atomicAdd(&s_on_grid, v);
     }
     // pass 2: offsets, ranges, classes
     unsigned int lmax = 0;
@@ -266,7 +292,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
         info[2] = (int64_t)s_nmedium;
         info[3] = (int64_t)s_nlarge;
         info[4] = (int64_t)s_nxl;
-        info[5] = info[6] = info[7] = 0;
+        info[5] = 0;
+        info[6] = (int64_t)s_on_grid;  // Gaussians whose tile box touches the FULL grid (band-independent)
+        info[7] = 0;
     }
 }
 
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
         s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect(i0, i1, means2d, radii, g, nullptr, [&](int t, int64_t i) {
+    for_each_isect(i0, i1, means2d, radii, g, nullptr, nullptr, [&](int t, int64_t i) {
         const uint32_t slot = atomicAdd(&s_cur[t], 1u);
         const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
         if ((int64_t)slot < M) keys[slot] = key;
@@ -572,13 +600,13 @@ struct Plan {
     int64_t chunk;
     int T, T_local;
     size_t lds_bytes;
-    size_t off_hist, off_count, off_medium, off_large, off_xl, total;
+    size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.T = tw * th;
     p.T_local = (row_end - row_begin) * tw;
-    p.lds_bytes = (size_t)p.T_local * 4;
+    p.lds_bytes = (size_t)p.T_local * 4 + 16;  // + the on-grid counter of the count kernels
     int64_t G = ms::ceil_div(N > 0 ? N : 1, 2048);
     G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
     if (p.lds_bytes > 64 * 1024 && G > 256) G = 256;
@@ -591,6 +619,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_medium = o; o += ms::align_up((size_t)p.T * 4, 256);
     p.off_large = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
+    p.off_on_grid = o; o += ms::align_up((size_t)kMaxG * 4, 256);
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -621,14 +650,15 @@ int allow_big_lds(K kernel) {
 namespace {
 // per-tile prefix over the partial histograms -> tile_ranges, M, work lists
 int count_tail(const Plan &p, const Grid &g, uint32_t *hist, uint32_t *count, int32_t *medium, int32_t *large,
-               int32_t *xl, int32_t *tile_ranges, int64_t *isect_info, hipStream_t stream) {
+               int32_t *xl, const uint32_t *wg_on_grid, int n_wg, int32_t *tile_ranges, int64_t *isect_info,
+               hipStream_t stream) {
     if (p.T_local > 0) {
         hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
                            p.G, p.T_local, hist, count);
         MS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium, large, xl,
-                       isect_info);
+                       wg_on_grid, n_wg, isect_info);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -665,18 +695,22 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
     uint32_t *count = (uint32_t *)(ws + p.off_count);
     int32_t *medium = (int32_t *)(ws + p.off_medium);
     int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
+    uint32_t *on_grid = (uint32_t *)(ws + p.off_on_grid);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
 
     if (p.T_local > 0) {
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(k_isect_hist)) return rc;
         hipLaunchKernelGGL(k_isect_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d,
-                           radii, g, p.chunk, hist, tiles_per_gauss);
+                           radii, g, p.chunk, hist, tiles_per_gauss, on_grid);
         MS_LAUNCH_CHECK();
-    } else if (tiles_per_gauss && N > 0) {
-        MS_HIP(hipMemsetAsync(tiles_per_gauss, 0, (size_t)N * 4, stream));
+    } else if (N > 0) {  // empty band: nothing to histogram, but the frame-level on-grid count is still owed
+        hipLaunchKernelGGL(k_isect_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, g,
+                           p.chunk, hist, tiles_per_gauss, on_grid);
+        MS_LAUNCH_CHECK();
     }
-    return count_tail(p, g, hist, count, medium, large, xl, tile_ranges, isect_info, stream);
+    return count_tail(p, g, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
+                      stream);
 }
 
 // Projection + tile counting in one pass over the Gaussians (what a frame starts with): the
@@ -711,6 +745,7 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
     uint32_t *count = (uint32_t *)(ws + p.off_count);
     int32_t *medium = (int32_t *)(ws + p.off_medium);
     int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
+    uint32_t *on_grid = (uint32_t *)(ws + p.off_on_grid);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
     const ms::ProjParams P = ms::make_proj_params(fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, radius_clip,
                                                   scales_are_log, opacities != nullptr);
@@ -718,10 +753,11 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(k_project_hist)) return rc;
         hipLaunchKernelGGL(k_project_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
-                           quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist);
+                           quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid);
         MS_LAUNCH_CHECK();
     }
-    return count_tail(p, g, hist, count, medium, large, xl, tile_ranges, isect_info, stream);
+    return count_tail(p, g, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
+                      stream);
 }
 
 namespace {

@@ -51,6 +51,9 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                              float *render_colors, void **stage_events, void *sync_event,
                              void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int phase = resume;
+    MS_REQUIRE(phase >= MS_RENDER_WHOLE && phase <= MS_RENDER_FINISH, MS_ERR_INVALID_ARG, "render_fwd: bad phase %d",
+               phase);
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "render_fwd: bad sizes");
     MS_REQUIRE(workspace && host_info && render_colors, MS_ERR_INVALID_ARG, "render_fwd: null pointer");
     const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
@@ -69,8 +72,10 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         if (stage_events && stage_events[i]) (void)hipEventRecord((hipEvent_t)stage_events[i], stream);
     };
 
+    // host_info[7] belongs to the library between the two halves of a frame: bit 0 = emit +
+    // rasterise were enqueued speculatively, bit 1 = the large sort class was among them
     bool speculated = false;
-    if (!resume) {
+    if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);
         // projection + tile counting share one pass over the Gaussians (k_project_hist)
         if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
@@ -81,15 +86,16 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         mark(1);
         int64_t prev[8];  // the previous frame's record: a hint for what this frame will need
         for (int k = 0; k < 8; ++k) prev[k] = host_info[k];
-        MS_HIP(hipMemcpyAsync(host_info, info, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        host_info[7] = 0;
+        MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        if (sync_event) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
         // sized by an earlier frame), enqueue emit + rasterise against that capacity NOW and only
         // then wait for the size record -- the GPU never idles on the hand-off.  Every kernel
         // clamps to `cap`, so an overflowing frame writes nothing out of bounds; it is detected
-        // below and redone on the exact path.
+        // in the finishing half and redone on the exact path.
         const int64_t cap = isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0;
         if (sync_event && isect_buf && cap > 0) {
-            MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));
             const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
             uint64_t *keys = (uint64_t *)isect_buf;
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
@@ -103,15 +109,26 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                                                          render_colors, nullptr, nullptr, stream))
                 return rc;
             mark(3);
-            MS_HIP(hipEventSynchronize((hipEvent_t)sync_event));  // long done: it precedes the emit
-            speculated = true;
+            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0);
+        }
+        if (phase == MS_RENDER_BEGIN) return MS_OK;
+    }
+    if (phase != MS_RENDER_RESUME) {
+        // the one size hand-off of a frame (on a speculated frame the record is long written: it
+        // precedes the emit in stream order)
+        if (sync_event) MS_HIP(hipEventSynchronize((hipEvent_t)sync_event));
+        else MS_HIP(hipStreamSynchronize(stream));
+        speculated = (host_info[7] & 1) != 0;
+        if (speculated) {
+            const int64_t cap = (int64_t)((isect_bytes - 512) / 12);
+            const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
             const int64_t Ms = host_info[0];
-            const bool large_ok = host_info[3] == 0 || prev[3] > 0;  // large class sorted iff it was launched
+            const bool large_ok = host_info[3] == 0 || (host_info[7] & 2);  // large class sorted iff launched
             if (Ms > 0 && Ms <= c && host_info[4] == 0 && large_ok) return MS_OK;  // the common case
             // else: empty scene, overflow or a tile needing the merge path -> exact path below
-        } else {
-            MS_HIP(hipStreamSynchronize(stream));  // the one size hand-off of a frame
         }
+    } else {
+        speculated = (host_info[7] & 1) != 0;  // a redo after growing the buffer: events were already marked
     }
     const int64_t M = host_info[0], n_xl = host_info[4];
     MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld intersections do not fit int32",

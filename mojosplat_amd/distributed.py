@@ -11,9 +11,12 @@ so this is new design, MI355X-first:
     the output (in-place form, no staging copy).  Slabs are padded to `rows` tile rows; rows
     below H are never read;
   * the "no intersections anywhere -> zeros image" rule of the reference (render.py:73-76)
-    needs the global intersection count: a 1-float-per-rank all-gather issued right after the
-    local render is enqueued; the frame is scaled by the resulting 0/1 flag on the device (no
-    host sync).
+    needs a frame-level fact; since every rank projects every Gaussian, the count pass reports
+    how many Gaussians touch the FULL tile grid (isect_info[6]) next to the band's own M, so
+    every rank reaches the same verdict locally: no flag collective, no extra device pass;
+  * frames are independent, so the gather of frame k can overlap the render of frame k+1:
+    `async_op=True` hands back a PendingFrame right after the all-gather is enqueued on RCCL's
+    stream; the caller's stream only waits for it in `.wait()`.
 
 One process per GPU; backend "nccl" is RCCL on ROCm.  `stages` makes the orchestration testable
 on CPU with gloo (tests inject CPU stage functions); without it the HIP library renders the band.
@@ -45,32 +48,79 @@ class Stages:
     raster: Callable
 
 
+def _on_grid_count(means2d, radii, tile_size, tw, th) -> int:
+    """Gaussians whose gsplat tile box (floor/ceil, exclusive max, clamped) is non-empty on the
+    full grid -- the torch restatement of isect_info[6] for the injected-stage path."""
+    r = radii.to(torch.float32) / tile_size
+    t = means2d.to(torch.float32) / tile_size
+    x0 = torch.floor(t[:, 0] - r[:, 0]).clamp(0, tw)
+    x1 = torch.ceil(t[:, 0] + r[:, 0]).clamp(0, tw)
+    y0 = torch.floor(t[:, 1] - r[:, 1]).clamp(0, th)
+    y1 = torch.ceil(t[:, 1] + r[:, 1]).clamp(0, th)
+    ok = (radii[:, 0] > 0) & (radii[:, 1] > 0) & (x1 > x0) & (y1 > y0)
+    return int(ok.sum())
+
+
+def _band_of(band, th):
+    # an empty band (more ranks than tile rows) still runs the count pass: its verdict on the
+    # frame must match the other ranks'
+    return (min(band[0], th), min(max(band[1], band[0]), th))
+
+
 def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size, band, out):
-    """Render tile rows `band` into `out`; -> number of intersections in the band."""
+    """Render tile rows `band` into `out`; -> Gaussians touching the full grid (0 = empty frame)."""
     r0, r1 = band
-    if stages is None:
-        from ._fused import render_fwd_hip
-        if r1 <= r0:
-            return 0
-        _, m = render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                              row_range=band, out=out)
-        return m
     H, W = camera.H, camera.W
     th, tw = -(-H // tile_size), -(-W // tile_size)
+    if stages is None:
+        from ._fused import render_fwd_hip
+        info = {}
+        render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                       row_range=_band_of(band, th), out=out, info=info)
+        return info["on_grid"]
     means2d, conics, depths, radii = stages.project(means3d, scales, quats, opacities, camera)
     ids, ranges = stages.bin(means2d, radii, depths, tile_size, tw, th, band)
     if r1 > r0:
         stages.raster(means2d, conics, features, opacities, bg, ranges, ids, camera, tile_size, band, out)
-    return int(ids.numel())
+    return _on_grid_count(means2d, radii, tile_size, tw, th)
+
+
+class PendingFrame:
+    """A sharded frame in flight.  `.wait()` completes it on the host side (size-record check,
+    framebuffer all-gather enqueued on the collective's stream) and makes the CURRENT stream wait
+    for the gather; -> the full (H, W, C) image."""
+
+    def __init__(self, image=None, finalize=None):
+        self._image, self._finalize = image, finalize
+
+    def wait(self) -> torch.Tensor:
+        if self._finalize is not None:
+            self._image = self._finalize()
+            self._finalize = None
+        return self._image
+
+
+_turn = {}  # device -> which of the two lanes the next asynchronous frame takes
 
 
 @torch.no_grad()
 def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera: Camera,
                              background_color: Optional[torch.Tensor] = None, tile_size: int = 16,
-                             group=None, stages: Optional[Stages] = None) -> torch.Tensor:
-    """Every rank returns the full (H, W, C) image.  Inputs must be identical on all ranks."""
+                             group=None, stages: Optional[Stages] = None, async_op: bool = False,
+                             rehearse: Optional[Tuple[int, int]] = None):
+    """Every rank returns the full (H, W, C) image.  Inputs must be identical on all ranks.
+    rehearse=(rank, world) acts as that rank WITHOUT a process group and without the exchange
+    (only its own slab of the image is rendered): single-GPU timing of one rank's share.
+
+    async_op=True returns a PendingFrame (call .wait() for the image) and is meant to be used one
+    frame ahead: `nxt = render(..., async_op=True); img = cur.wait(); cur = nxt`.  The band is
+    enqueued on one of two lane streams without any host wait; .wait() then checks the frame and
+    starts its gather, which overlaps the band render of the frame begun before it.  At most two
+    frames may be pending."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if rehearse is not None:
+        rank, world = rehearse
     dev = means3d.device
     C = features.shape[-1]
     H, W = camera.H, camera.W
@@ -83,21 +133,59 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
 
     slab = rows * tile_size
     H_pad = max(world * slab, H)
-    # a fresh framebuffer per frame (caching allocator: no hipMalloc), handed to the caller as a view
-    full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
-    m_local = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                           bands[rank], full)
-    if world == 1:
-        if m_local == 0:
-            return torch.zeros(H, W, C, device=dev, dtype=torch.float32)
-        return full[:H]
 
-    flags = torch.empty(world, dtype=torch.float32, device=dev)
-    mine = torch.full((1,), float(m_local > 0), dtype=torch.float32, device=dev)
-    flag_work = dist.all_gather_into_tensor(flags, mine, group=group, async_op=True)
-    dist.all_gather_into_tensor(full[:world * slab], full[rank * slab:(rank + 1) * slab], group=group)
-    flag_work.wait()
-    img = full[:H]
-    # zeros (not background) when no rank found an intersection; stays on the device, no host sync
-    img.mul_((flags.sum() > 0).to(torch.float32))
-    return img
+    def gather(full, on_grid):
+        """-> (image, work): the exchange step, or the frame-level zeros rule."""
+        if on_grid == 0:
+            # zeros, not background (render.py:73-76); identical inputs -> every rank takes this
+            # branch, so skipping the collective is consistent across the group
+            return torch.zeros(H, W, C, device=dev, dtype=torch.float32), None
+        if world == 1 or rehearse is not None:
+            return full[:H], None
+        work = dist.all_gather_into_tensor(full[:world * slab], full[rank * slab:(rank + 1) * slab],
+                                           group=group, async_op=True)
+        return full[:H], work
+
+    if stages is not None or not async_op:
+        # a fresh framebuffer per frame (caching allocator: no hipMalloc), handed out as a view
+        full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
+        on_grid = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                               bands[rank], full)
+        img, work = gather(full, on_grid)
+        if not async_op:
+            if work is not None:
+                work.wait()
+            return img
+
+        def finalize_sync():
+            if work is not None:
+                work.wait()
+            return img
+        return PendingFrame(finalize=finalize_sync)
+
+    # asynchronous HIP path: band on a lane stream (ms_render_fwd BEGIN, no host wait).  Streams
+    # are addressed by handle and ordered with events; torch's current stream is never switched
+    # (the context managers would cost more host time than the band's kernels take to launch).
+    from ._fused import _lane_streams, render_begin_hip
+    cur = torch.cuda.current_stream(dev)
+    lanes = _lane_streams(dev)
+    lane = _turn.get(dev, 0)
+    _turn[dev] = 1 - lane
+    s = lanes[lane]
+    s.wait_stream(cur)  # inputs (and whatever the caller enqueued before) are ready
+    full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
+    frame = render_begin_hip(means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                             row_range=_band_of(bands[rank], th), out=full, lane=1 + lane, stream=s.cuda_stream)
+    for t in (means3d, scales, quats, opacities, features, bg, full):
+        t.record_stream(s)
+
+    def finalize():
+        info = {}
+        frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
+        now = torch.cuda.current_stream(dev)
+        now.wait_stream(s)           # the band is complete before the exchange starts
+        img, work = gather(full, info["on_grid"])   # RCCL's stream waits for `now`
+        if work is not None:
+            work.wait()              # ... and `now` for the gather
+        return img
+    return PendingFrame(finalize=finalize)

@@ -66,7 +66,7 @@ def render_gaussians(
             img, _ = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
                                     stage_events=evs)
             return img
-        # tile grids beyond the binning kernels' LDS budget (> 40 960 tiles, e.g. 8K x 4K frames) are
+        # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer
         img = torch.empty((camera.H, camera.W, colors.shape[-1]), dtype=torch.float32, device=means3d.device)
         total = 0

@@ -43,26 +43,34 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, H, W, shift, q):
+def _worker(rank, world, port, H, W, shift, q, use_async=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sc, cam = randscene_v1(1500, W, H, ell=-2.5, seed=5)
         means = sc["means3d"] + torch.tensor([0.0, 0.0, shift])
-        img = render_gaussians_sharded(means, sc["scales"], sc["quats"], sc["opacities"], sc["features"], cam,
-                                       background_color=torch.tensor([0.1, 0.2, 0.3]), stages=cpu_stages())
+        args = (means, sc["scales"], sc["quats"], sc["opacities"], sc["features"], cam)
+        kw = dict(background_color=torch.tensor([0.1, 0.2, 0.3]), stages=cpu_stages())
+        if use_async:  # two frames in flight, consumed in order (what bench.py does for N > 1)
+            a = render_gaussians_sharded(*args, async_op=True, **kw)
+            b = render_gaussians_sharded(*args, async_op=True, **kw)
+            img, img2 = a.wait(), b.wait()
+            assert torch.equal(img, img2)
+        else:
+            img = render_gaussians_sharded(*args, **kw)
         q.put((rank, img.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H,W,shift", [(96, 128, 0.0), (100, 72, 0.0), (64, 64, -500.0)])
-def test_two_rank_bands_equal_single_frame(H, W, shift):
+@pytest.mark.parametrize("H,W,shift,use_async", [(96, 128, 0.0, False), (100, 72, 0.0, False),
+                                                 (64, 64, -500.0, False), (100, 72, 0.0, True)])
+def test_two_rank_bands_equal_single_frame(H, W, shift, use_async):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, shift, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, shift, q, use_async)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))

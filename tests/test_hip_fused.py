@@ -76,6 +76,31 @@ def test_band_calls_assemble_the_full_frame(device):
         assert torch.equal(frame[:cam.H], ref)
         assert (frame[cam.H:] == -1.0).all()      # padding rows are never written
     assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg), ref)
+    assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True).wait(), ref)
+
+
+def test_band_call_reports_frame_level_on_grid_count(device):
+    """isect_info[6]: Gaussians touching the FULL tile grid, the same from every band (also an empty
+    one) -- what lets each rank apply the zeros-image rule without a collective."""
+    from mojosplat_amd.distributed import _on_grid_count, render_gaussians_sharded
+    sc, cam = randscene_v1(20_000, 640, 360, ell=-3.0, seed=2, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    m2, _, _, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+    th, tw = -(-cam.H // 16), -(-cam.W // 16)
+    want = _on_grid_count(m2, rad, 16, tw, th)
+    assert 0 < want < 20_000
+    frame = torch.empty((cam.H, cam.W, 3), device=device)
+    for band in ((0, th), (0, 3), (th - 1, th), (5, 5)):
+        info = {}
+        _fused.render_fwd_hip(*g, cam, bg, 16, row_range=band, out=frame, info=info)
+        assert info["on_grid"] == want, band
+    # everything behind the camera: zeros, not background, from the sharded entry point too
+    far = (sc["means3d"] + torch.tensor([0.0, 0.0, 500.0], device=device),) + g[1:]
+    info = {}
+    _fused.render_fwd_hip(*far, cam, bg, 16, row_range=(0, 3), out=frame, info=info)
+    assert info["on_grid"] == 0
+    assert (render_gaussians_sharded(*far, cam, background_color=bg) == 0).all()
 
 
 def test_multi_view_batch_equals_single_views(device):

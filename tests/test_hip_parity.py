@@ -387,7 +387,7 @@ def test_config2_100k_1080p_stagewise(device):
 
 def test_huge_tile_grid_is_binned_and_rendered_in_bands(device):
     """Maximum sizes: a 4096x4096 frame has 65 536 tiles, beyond the LDS histogram of the binning
-    kernels (40 960): the Python layer splits into row bands; indices stay bit-exact."""
+    kernels (~40.9k): the Python layer splits into row bands; indices stay bit-exact."""
     from mojosplat_amd.binning import lds_row_bands
     W = H = 4096
     assert len(lds_row_bands(H, W, 16)) == 2 and len(lds_row_bands(2160, 3840, 16)) == 1
