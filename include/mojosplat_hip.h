@@ -182,6 +182,28 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
                              float *v_scales, float *v_quats, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Spherical-harmonic colours (view dependent).  The reference leaves SH evaluation as a TODO
+ * that only slices channels (mojosplat/render.py:82-87); this is the operator that belongs
+ * there, in gsplat's convention (spherical_harmonics + the "+0.5, clamp at 0" of its
+ * rasterization()): real SH of degree <= 4, 3DGS signs, coefficient index l*(l+1)+m.
+ *   in : means3d f32[N,3]; camera position (world) cam_x/y/z; coeffs f32[N,K,3] with
+ *        K >= (degree+1)^2 (only the first (degree+1)^2 are read); radii i32[N,2] or NULL:
+ *        Gaussians with a zero radius are skipped (colour 0, zero gradients);
+ *        add_half_and_clamp: colour = max(sum + 0.5, 0) when non-zero, the raw sum otherwise.
+ *   out: colors f32|f16[N,3].
+ * Backward: v_colors f32[N,3] -> v_coeffs f32[N,K,3] (overwritten; zeros beyond the degree) and
+ * / or v_means3d f32[N,3] (overwritten); either may be NULL.  colors_fwd (f32, the forward
+ * output) is required with add_half_and_clamp.
+ * ------------------------------------------------------------------------------------- */
+int ms_spherical_harmonics_fwd(int64_t N, int K, int degree, const float *means3d, float cam_x,
+                               float cam_y, float cam_z, const float *coeffs, const int32_t *radii,
+                               int add_half_and_clamp, int color_dtype, void *colors, void *stream);
+int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3d, float cam_x,
+                               float cam_y, float cam_z, const float *coeffs, const int32_t *radii,
+                               int add_half_and_clamp, const float *colors_fwd, const float *v_colors,
+                               float *v_coeffs, float *v_means3d, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Whole forward path in one call: replaces the three stage calls that
  * render_gaussians makes (mojosplat/render.py:63-101) when the caller does not need the
  * intermediates.  Projection outputs, tile ranges and the sorted list live in caller-owned

@@ -10,6 +10,7 @@ from .projection import project_gaussians
 from .binning import bin_gaussians_to_tiles
 from .rasterization import rasterize_gaussians
 from .render import render_gaussians, render_gaussians_batch, TILE_SIZE
+from .sh import evaluate_sh
 
 __all__ = ["Camera", "look_at", "project_gaussians", "bin_gaussians_to_tiles",
-           "rasterize_gaussians", "render_gaussians", "render_gaussians_batch", "TILE_SIZE"]
+           "rasterize_gaussians", "render_gaussians", "render_gaussians_batch", "evaluate_sh", "TILE_SIZE"]

@@ -104,15 +104,23 @@ def rasterize_gaussians_autograd(means2d, conics, colors, opacities, background,
 
 
 def render_gaussians_trainable(means3d, scales, quats, opacities, features, camera: Camera,
-                               background_color=None, tile_size: int = 16):
+                               background_color=None, tile_size: int = 16, sh_degree=None):
     """Differentiable twin of ``render_gaussians(backend="hip")``: grads for means3d, scales
-    (log-space), quats, opacities and colours (BASELINE config 3)."""
+    (log-space), quats, opacities and colours (BASELINE config 3).  With ``sh_degree`` and
+    features of shape (N, K, 3) the colours are view-dependent SH (sh.py): gradients then reach
+    the coefficients and, through the viewing direction, the means; Gaussians the projection
+    culled are skipped."""
     _hip.require_cuda(means3d, scales, quats, opacities, features, what="gaussian tensor")
-    C = features.shape[-1]
     dev = means3d.device
+    means2d, conics, depths, radii = project_gaussians_autograd(means3d, scales, quats, opacities, camera)
+    if features.dim() == 3:
+        if sh_degree is None:
+            raise ValueError("features of shape (N, K, 3) are SH coefficients: pass sh_degree")
+        from .sh import evaluate_sh_hip
+        features = evaluate_sh_hip(means3d, features, camera, sh_degree, radii=radii)
+    C = features.shape[-1]
     bg = torch.zeros(C, device=dev) if background_color is None else \
         torch.as_tensor(background_color, dtype=torch.float32, device=dev)
-    means2d, conics, depths, radii = project_gaussians_autograd(means3d, scales, quats, opacities, camera)
     th, tw = -(-camera.H // tile_size), -(-camera.W // tile_size)
     with torch.no_grad():
         ids, ranges = bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size, tw, th)

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "project.hip", "binning.hip", "rasterize.hip", "rasterize_bwd.hip",
-           "project_bwd.hip", "pipeline.hip"]
+           "project_bwd.hip", "pipeline.hip", "sh.hip"]
 HEADERS = ["ms_common.hpp", os.path.join("..", "..", "include", "mojosplat_hip.h")]
 LIB = os.path.join(HERE, "libmojosplat_hip.so")
 ARCH = "gfx950"

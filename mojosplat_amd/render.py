@@ -4,8 +4,12 @@ Drop-in for ``mojosplat.render.render_gaussians`` (reference mojosplat/render.py
 signature and checks -- non-CUDA inputs and a background/colour channel mismatch raise
 ValueError (render.py:44-46, 57-58), opacities must be (N,) (render.py:60), an empty
 intersection list returns a ZEROS image, not the background (render.py:73-76), ``sh_degree``
-only slices channels (render.py:82-87).  The reference default backend is "mojo"
-(render.py:23); here it is "hip".
+with 2-D features only slices channels (render.py:82-87).  The reference default backend is
+"mojo" (render.py:23); here it is "hip".
+
+Beyond the reference: ``features`` of shape (N, K, 3) together with ``sh_degree`` are
+spherical-harmonic coefficients and are evaluated per view (sh.py) -- the TODO at
+render.py:83 carried out.
 """
 from typing import Optional
 
@@ -30,7 +34,7 @@ def render_gaussians(
     scales: torch.Tensor,     # (N, 3) log-space scales
     quats: torch.Tensor,      # (N, 4) w, x, y, z
     opacities: torch.Tensor,  # (N,) activated opacities
-    features: torch.Tensor,   # (N, C) colours
+    features: torch.Tensor,   # (N, C) colours, or (N, K, 3) SH coefficients with sh_degree
     camera: Camera,
     sh_degree: Optional[int] = None,
     background_color: Optional[torch.Tensor] = None,
@@ -40,6 +44,15 @@ def render_gaussians(
     required = [means3d, scales, quats, opacities, features]
     if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in required):
         raise ValueError("All input gaussian tensors must be CUDA tensors.")
+
+    if features.dim() == 3:
+        if sh_degree is None:
+            raise ValueError("features of shape (N, K, 3) are SH coefficients: pass sh_degree")
+        from .sh import evaluate_sh
+        out_dtype = features.dtype
+        features = evaluate_sh(means3d, features, camera, sh_degree,
+                               backend="hip" if backend == "hip" else "torch").to(out_dtype)
+        sh_degree = None
 
     num_channels = features.shape[-1]
     if background_color is None:

@@ -51,6 +51,18 @@ class Camera:
         self._vm_cache = (vm, vm._version, flat)
         return flat
 
+    def _campos(self):
+        """World-space camera centre (x, y, z) as Python floats, from the same view matrix the
+        projection uses: -R^T T.  Cached (one D2H read per camera, not per frame)."""
+        vm = self.view_matrix
+        cached = getattr(self, "_cp_cache", None)
+        if cached is not None and cached[0] is vm and cached[1] == vm._version:
+            return cached[2]
+        m = vm.detach().to(torch.float64).cpu()
+        pos = tuple(float(v) for v in (-(m[:3, :3].T @ m[:3, 3])).tolist())
+        self._cp_cache = (vm, vm._version, pos)
+        return pos
+
 
 def look_at(eye: torch.Tensor, target: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     """World->camera 4x4 in the gsplat convention (+X right, +Y down, +Z forward), the one

@@ -129,3 +129,19 @@ def render_fwd(means3d, scales, quats, opacities, colors, viewmat, fx, fy, cx, c
     img, alphas, last = rasterize_fwd(m2, con, colors, opacities, bg, ranges, ids, H, W, tile_size)
     return img, dict(M=int(ids.size), means2d=m2, conics=con, depths=dep, radii=rad, ids=ids,
                      ranges=ranges, alphas=alphas, last_ids=last)
+
+
+def sh_fwd(means3d, campos, coeffs, degree, *, radii=None, clamp=True, want_basis=False):
+    """-> colors f32[N,3] (and the f64[N,25] basis when want_basis).  gsplat convention, see
+    gsplat_oracle.c."""
+    m, c = _f32(means3d), _f32(coeffs)
+    N, K = c.shape[0], c.shape[1]
+    cp = _f32(campos)
+    r = _i32(radii) if radii is not None else None
+    out = np.empty((N, 3), np.float32)
+    basis = np.empty((N, 25), np.float64) if want_basis else None
+    rc = lib().orc_sh_fwd(ctypes.c_int64(N), K, int(degree), _p(m), _p(cp), _p(c), _p(r), int(clamp), _p(out),
+                          _p(basis))
+    if rc:
+        raise ValueError(f"orc_sh_fwd failed ({rc})")
+    return (out, basis) if want_basis else out

@@ -89,3 +89,33 @@ def rasterize(means2d, conics, colors, opacities, background, tile_ranges, flatt
             img[y0:y1, x0:x1] = col.reshape(y1 - y0, x1 - x0, C)
             alph[y0:y1, x0:x1] = (1 - T_fin).reshape(y1 - y0, x1 - x0)
     return img, alph
+
+
+def sh_colors(means3d, campos, coeffs, degree, clamp=True, radii=None):
+    """Differentiable (float64-friendly) restatement of orc_sh_fwd (gsplat_oracle.c): colours
+    (N,3) from SH coefficients (N,K,3) along normalise(mean - campos)."""
+    d = means3d - campos
+    d = d / d.norm(dim=-1, keepdim=True)
+    x, y, z = d.unbind(-1)
+    xx, yy, zz = x * x, y * y, z * z
+    b = [0.28209479177387814 * torch.ones_like(x),
+         -0.4886025119029199 * y, 0.4886025119029199 * z, -0.4886025119029199 * x,
+         1.0925484305920792 * x * y, -1.0925484305920792 * y * z, 0.31539156525252005 * (3 * zz - 1),
+         -1.0925484305920792 * x * z, 0.5462742152960396 * (xx - yy),
+         -0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * x * y * z,
+         -0.4570457994644658 * y * (5 * zz - 1), 0.3731763325901154 * z * (5 * zz - 3),
+         -0.4570457994644658 * x * (5 * zz - 1), 1.445305721320277 * z * (xx - yy),
+         -0.5900435899266435 * x * (xx - 3 * yy),
+         2.5033429417967046 * x * y * (xx - yy), -1.7701307697799304 * y * z * (3 * xx - yy),
+         0.9461746957575601 * x * y * (7 * zz - 1), -0.6690465435572892 * y * z * (7 * zz - 3),
+         0.10578554691520431 * (35 * zz * zz - 30 * zz + 3), -0.6690465435572892 * x * z * (7 * zz - 3),
+         0.47308734787878004 * (xx - yy) * (7 * zz - 1), -1.7701307697799304 * x * z * (xx - 3 * yy),
+         0.6258357354491761 * (xx * (xx - 3 * yy) - yy * (3 * xx - yy))]
+    ku = (degree + 1) ** 2
+    B = torch.stack(b[:ku], dim=-1)
+    col = (B.unsqueeze(-1) * coeffs[:, :ku]).sum(dim=1)
+    if clamp:
+        col = (col + 0.5).clamp_min(0.0)
+    if radii is not None:
+        col = col * ((radii[:, 0] > 0) & (radii[:, 1] > 0)).unsqueeze(-1).to(col.dtype)
+    return col
