@@ -115,18 +115,31 @@ int ms_isect_tiles_count(int64_t N, const float *means2d, const int32_t *radii, 
 int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
                         const float *depths, int tile_size, int tile_w, int tile_h,
                         int row_begin, int row_end, void *workspace, size_t workspace_bytes,
-                        const int32_t *tile_ranges, const int64_t *host_info, uint64_t *sort_keys,
+                        const int32_t *tile_ranges, const int64_t *host_info, int tight,
+                        uint64_t *sort_keys,
                         uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
                         void *stream);
 
 /* ms_project_gaussians_fwd + ms_isect_tiles_count in ONE pass over the Gaussians (same outputs,
  * same semantics; the tile grid is derived from W, H, tile_size).  What ms_render_fwd starts a
- * frame with: the projected means / radii are not re-read and one kernel launch is saved. */
+ * frame with: the projected means / radii are not re-read and one kernel launch is saved.
+ *
+ * tight != 0 (needs opacities): TIGHT binning.  gsplat.isect_tiles lists every tile of a
+ * Gaussian's bounding box; ~18 % of those pairs (config 3) can never blend because the
+ * alpha >= 1/255 ellipse does not reach the tile (box corners, elongated / rotated footprints).
+ * Tight mode drops them (per tile row, the x-extent of the ellipse inside the row's band of pixel
+ * centres; boxes of more than 64 tiles are kept whole), so every later stage handles fewer
+ * intersections and the IMAGE IS UNCHANGED (the dropped pairs are ones the rasteriser would skip).
+ * The lists are then no longer gsplat's: tight mode is for callers that only want pixels
+ * (ms_render_fwd); M and tile_ranges count the kept pairs, isect_info[6] still counts bounding
+ * boxes.  The per-Gaussian reach masks stay in the workspace: the emit that follows a tight count
+ * MUST pass tight = 1 (and tight = 0 after ms_isect_tiles_count or a non-tight count). */
 int ms_project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
                            const float *quats, const float *opacities, const float *viewmat, float fx,
                            float fy, float cx, float cy, int W, int H, float eps2d, float near_plane,
                            float far_plane, float radius_clip, int tile_size, int row_begin,
-                           int row_end, float *means2d, float *conics, float *depths, int32_t *radii,
+                           int row_end, int tight, float *means2d, float *conics, float *depths,
+                           int32_t *radii,
                            void *workspace, size_t workspace_bytes, int32_t *tile_ranges,
                            int64_t *isect_info, void *stream);
 
@@ -260,7 +273,7 @@ int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, const int32
                                     int row_begin, int row_end, void *workspace,
                                     size_t workspace_bytes, const int32_t *tile_ranges,
                                     const int64_t *isect_info_dev, int64_t capacity,
-                                    const int64_t *prev_info_host, uint64_t *sort_keys,
+                                    const int64_t *prev_info_host, int tight, uint64_t *sort_keys,
                                     int32_t *flatten_ids, void *stream);
 
 #ifdef __cplusplus

@@ -30,11 +30,11 @@ _SIGNATURES = {
     "ms_isect_tiles_count": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ms_isect_tiles_emit": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                    c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
     "ms_project_isect_count": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                        c_float, c_float, c_float, c_int, c_int, c_float, c_float, c_float,
-                                       c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "ms_isect_offset_encode": (c_int, [c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ms_rasterize_to_pixels_3dgs_fwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
@@ -55,7 +55,7 @@ _SIGNATURES = {
                               c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ms_isect_tiles_emit_speculative": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int64,
-                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ms_spherical_harmonics_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_float, c_float, c_float, c_void_p,
                                            c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ms_spherical_harmonics_bwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_float, c_float, c_float, c_void_p,

@@ -39,6 +39,51 @@ struct Grid {
     int ts, tw, th, row_begin, row_end;
 };
 
+// Tight binning: which tiles of a Gaussian's box can its alpha >= 1/255 ellipse reach at all?
+// bit (y - y0) * w + (x - x0) of the result, for boxes of at most 64 tiles (larger boxes, and
+// Gaussians without a usable bound, keep every tile: all ones).
+//
+// E = {d : ca dx^2 + 2 cb dx dy + cc dy^2 <= 2 s}, s = ln(255 o) with the rasteriser's slack.  For a
+// tile row, the pixel centres span dy in [yl, yh] (relative to the mean); E restricted to that
+// band is convex, so its x-extent is an interval [xmin, xmax]: the upper root
+// u(dy) = (-cb dy + sqrt(2 ca s - det dy^2)) / ca is concave with its maximum at the ellipse's
+// rightmost point dy = -cb/cc * X (X = sqrt(2 cc s / det)), clamped into the band; the lower root
+// mirrors it.  A tile is reached iff its pixel-centre interval meets [xmin, xmax].  Two square
+// roots per tile ROW instead of a rectangle test per TILE, no divergent inner loop.  The interval is
+// padded by 0.01 px so rounding can only keep a pair too many, never drop one the rasteriser
+// would blend.  Computed ONCE per Gaussian by the count kernel and stored (8 B): the scatter kernel
+// reads it back, so the two agree by construction.
+__device__ __forceinline__ unsigned long long reach_mask(float mx, float my, float ca, float cb, float cc,
+                                                        float opacity, int x0, int x1, int y0, int y1, int ts) {
+    const int w = x1 - x0, h = y1 - y0;
+    const float det = ca * cc - cb * cb;
+    if (w * h > 64 || w * h <= 1 || !(det > 0.f) || !(ca > 0.f) || !(cc > 0.f) || !(opacity >= ms::kAlphaThreshold))
+        return ~0ull;
+    const float s2 = 2.0f * (__logf(opacity * 255.0f) * 1.0001f + 1e-4f);   // 2 s
+    const float inv_det = __builtin_amdgcn_rcpf(det), inv_ca = __builtin_amdgcn_rcpf(ca);
+    const float Y = __builtin_amdgcn_sqrtf(ca * s2 * inv_det);                                // |dy| extent of E
+    const float dy_right = -(cb * __builtin_amdgcn_rcpf(cc)) * __builtin_amdgcn_sqrtf(cc * s2 * inv_det);            // dy of E's rightmost point
+    const float fts = (float)ts, span = (float)(ts - 1), inv_ts = __builtin_amdgcn_rcpf(fts);
+    unsigned long long mask = 0;
+    for (int r = 0; r < h; ++r) {
+        const float yl = (float)((y0 + r) * ts) + 0.5f - my, yh = yl + span;
+        const float lo = fmaxf(yl, -Y), hi = fminf(yh, Y);
+        if (lo > hi + 0.01f) continue;                                      // the band misses E
+        const float dyr = fminf(fmaxf(dy_right, lo), hi), dyl = fminf(fmaxf(-dy_right, lo), hi);
+        const float xmax = (-cb * dyr + __builtin_amdgcn_sqrtf(fmaxf(ca * s2 - det * dyr * dyr, 0.f))) * inv_ca + 0.01f;
+        const float xmin = (-cb * dyl - __builtin_amdgcn_sqrtf(fmaxf(ca * s2 - det * dyl * dyl, 0.f))) * inv_ca - 0.01f;
+        // tiles whose centre interval [tx*ts + 0.5 - mx, + span] meets [xmin, xmax]
+        const float base = 0.5f - mx;
+        // (approximate reciprocals / roots: their error is orders of magnitude inside the 0.01 px padding)
+        int ta = (int)ceilf((xmin - base - span) * inv_ts - 1e-3f), tb = (int)floorf((xmax - base) * inv_ts + 1e-3f);
+        ta = max(ta, x0); tb = min(tb, x1 - 1);
+        if (ta > tb) continue;
+        const unsigned long long rowbits = (tb - ta + 1 >= 64) ? ~0ull : ((1ull << (tb - ta + 1)) - 1ull);
+        mask |= rowbits << (r * w + (ta - x0));
+    }
+    return mask;
+}
+
 __device__ __forceinline__ int clampi(float v, int lo, int hi) {
     if (!(v > (float)lo)) return lo;  // also NaN
     if (v >= (float)hi) return hi;
@@ -75,13 +120,21 @@ __device__ __forceinline__ void count_on_grid(bool on_grid, unsigned int *s_on_g
 // Must be reached by all lanes of the wave (ballot / shuffles inside).
 template <class F>
 __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0, int y1, int n, const Grid &g,
-                                           F &&f) {
+                                           unsigned long long mask, F &&f) {
     const int lane = threadIdx.x & 63;
     const int64_t i = base + threadIdx.x;
     const bool big = n > kCoopThreshold;
     if (n > 0 && !big) {
-        for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x) f((y - g.row_begin) * g.tw + x, i);
+        // only the reached tiles: the trip count is popcount(mask), not the box area
+        const int w = x1 - x0;
+        const float inv_w = 1.0f / (float)w;
+        unsigned int m = (unsigned int)mask & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));   // n <= kCoopThreshold = 32
+        while (m) {
+            const int k = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int r = (int)(((float)k + 0.5f) * inv_w);   // k / w, exact for k < 64
+            f((y0 + r - g.row_begin) * g.tw + x0 + (k - r * w), i);
+        }
     }
     unsigned long long bigmask = __ballot(big);
     while (bigmask) {
@@ -89,11 +142,13 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
         bigmask &= bigmask - 1;
         const int bx0 = __shfl(x0, src), bx1 = __shfl(x1, src);
         const int by0 = __shfl(y0, src), by1 = __shfl(y1, src);
+        const unsigned long long bm = ((unsigned long long)(unsigned)__shfl((int)(mask >> 32), src) << 32) |
+                                      (unsigned)__shfl((int)(mask & 0xffffffffu), src);
         const int64_t bi = base + (threadIdx.x & ~63) + src;
         const int w = bx1 - bx0, cnt = w * (by1 - by0);
         for (int k = lane; k < cnt; k += 64) {
             const int y = by0 + k / w, x = bx0 + k % w;
-            f((y - g.row_begin) * g.tw + x, bi);
+            if (cnt > 64 || ((bm >> k) & 1ull)) f((y - g.row_begin) * g.tw + x, bi);
         }
     }
 }
@@ -102,35 +157,38 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
 // Small boxes are walked by their own lane, big ones by the whole wave.
 template <class F>
 __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const float *means2d,
-                                               const int32_t *radii, const Grid &g,
+                                               const int32_t *radii, const unsigned long long *masks,
+                                               const Grid &g,
                                                int32_t *tiles_per_gauss, unsigned int *s_on_grid, F &&f) {
     for (int64_t base = i0; base < i1; base += kHistThreads) {
         const int64_t i = base + threadIdx.x;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
         bool on_grid = false;
+        unsigned long long mask = ~0ull;
         if (i < i1) {
             const int2 r = reinterpret_cast<const int2 *>(radii)[i];
             if (r.x > 0 && r.y > 0) {
                 const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
                 on_grid = tile_bbox(m, r, g, x0, x1, y0, y1);
                 n = (x1 - x0) * (y1 - y0);
+                if (masks && n > 1) mask = masks[i];
             }
             if (tiles_per_gauss) tiles_per_gauss[i] = n;
         }
         if (s_on_grid) count_on_grid(on_grid, s_on_grid);
-        walk_boxes(base, x0, x1, y0, y1, n, g, f);
+        walk_boxes(base, x0, x1, y0, y1, n, g, mask, f);
     }
 }
 
 // Fused projection + tile counting (the first two kernels of a frame in one): every lane projects
 // its Gaussian (project_device.hpp), stores the projected record, and counts the tiles of its box
 // in the workgroup's LDS histogram.  Same chunking as k_isect_hist / k_isect_scatter.
-__global__ __launch_bounds__(kHistThreads) void k_project_hist(
+__global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     ms::ProjParams P, Grid g, int64_t chunk, float *__restrict__ means2d, float *__restrict__ conics,
     float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist,
-    uint32_t *__restrict__ wg_on_grid) {
+    uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
@@ -142,6 +200,7 @@ __global__ __launch_bounds__(kHistThreads) void k_project_hist(
         const int64_t i = base + threadIdx.x;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
         bool on_grid = false;
+        unsigned long long mask = ~0ull;
         if (i < i1) {
             const ms::ProjOut o = ms::project_one(i, means3d, scales, quats, opacities, viewmat, P);
             reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
@@ -153,10 +212,14 @@ __global__ __launch_bounds__(kHistThreads) void k_project_hist(
             if (o.r0 > 0 && o.r1 > 0) {
                 on_grid = tile_bbox(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1);
                 n = (x1 - x0) * (y1 - y0);
+                if (masks) {
+                    mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], x0, x1, y0, y1, g.ts);
+                    masks[i] = mask;
+                }
             }
         }
         count_on_grid(on_grid, &s_on_grid);
-        walk_boxes(base, x0, x1, y0, y1, n, g, [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
+        walk_boxes(base, x0, x1, y0, y1, n, g, mask, [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
@@ -175,7 +238,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect(i0, i1, means2d, radii, g, tiles_per_gauss, &s_on_grid,
+    for_each_isect(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid,
                    [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
@@ -300,7 +363,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
 
 __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
-    const float *__restrict__ depths, Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
+    const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
+    Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
     const int32_t *__restrict__ tile_ranges, int64_t M, uint64_t *__restrict__ keys) {
     extern __shared__ uint32_t s_cur[];
     const int T_local = (g.row_end - g.row_begin) * g.tw;
@@ -310,7 +374,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
         s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect(i0, i1, means2d, radii, g, nullptr, nullptr, [&](int t, int64_t i) {
+    for_each_isect(i0, i1, means2d, radii, masks, g, nullptr, nullptr, [&](int t, int64_t i) {
         const uint32_t slot = atomicAdd(&s_cur[t], 1u);
         const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
         if ((int64_t)slot < M) keys[slot] = key;
@@ -600,7 +664,7 @@ struct Plan {
     int64_t chunk;
     int T, T_local;
     size_t lds_bytes;
-    size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, total;
+    size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -620,6 +684,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_large = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
     p.off_on_grid = o; o += ms::align_up((size_t)kMaxG * 4, 256);
+    p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -720,7 +785,8 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
                                       const float *quats, const float *opacities, const float *viewmat,
                                       float fx, float fy, float cx, float cy, int W, int H, float eps2d,
                                       float near_plane, float far_plane, float radius_clip, int tile_size,
-                                      int row_begin, int row_end, float *means2d, float *conics, float *depths,
+                                      int row_begin, int row_end, int tight, float *means2d, float *conics,
+                                      float *depths,
                                       int32_t *radii, void *workspace, size_t workspace_bytes,
                                       int32_t *tile_ranges, int64_t *isect_info, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -747,13 +813,14 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
     int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
     uint32_t *on_grid = (uint32_t *)(ws + p.off_on_grid);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+    unsigned long long *masks = (tight && opacities) ? (unsigned long long *)(ws + p.off_mask) : nullptr;
     const ms::ProjParams P = ms::make_proj_params(fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, radius_clip,
                                                   scales_are_log, opacities != nullptr);
     if (N > 0) {
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(k_project_hist)) return rc;
         hipLaunchKernelGGL(k_project_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
-                           quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid);
+                           quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks);
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
@@ -763,7 +830,8 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
 namespace {
 // Shared by the exact emit (host knows M and the class counts) and the speculative one (it does
 // not: `info_dev` is the count pass's device record, `cap` the capacity of the key/id buffers).
-int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
+int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tight,
+              int tile_size,
               int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
               const int32_t *tile_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
               uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
@@ -778,6 +846,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
     const int32_t *medium = (const int32_t *)(ws + p.off_medium);
     const int32_t *large = (const int32_t *)(ws + p.off_large), *xl = (const int32_t *)(ws + p.off_xl);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+    const unsigned long long *masks = tight ? (const unsigned long long *)(ws + p.off_mask) : nullptr;
     const bool spec = info_dev != nullptr;
     const int64_t max_count = spec ? 0 : host_info[1], n_medium = spec ? 0 : host_info[2],
                   n_large = spec ? 0 : host_info[3], n_xl = spec ? 0 : host_info[4];
@@ -785,7 +854,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
     if (p.lds_bytes > 48 * 1024)
         if (int rc = allow_big_lds(k_isect_scatter)) return rc;
     hipLaunchKernelGGL(k_isect_scatter, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d,
-                       radii, depths, g, p.chunk, hist, tile_ranges, cap, sort_keys);
+                       radii, depths, masks, g, p.chunk, hist, tile_ranges, cap, sort_keys);
     MS_LAUNCH_CHECK();
 
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
@@ -841,7 +910,7 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
                                    const float *depths, int tile_size, int tile_w, int tile_h,
                                    int row_begin, int row_end, void *workspace,
                                    size_t workspace_bytes, const int32_t *tile_ranges,
-                                   const int64_t *host_info, uint64_t *sort_keys,
+                                   const int64_t *host_info, int tight, uint64_t *sort_keys,
                                    uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
                                    void *stream_) {
     MS_REQUIRE(N >= 0 && host_info, MS_ERR_INVALID_ARG, "isect_emit: bad N / host_info");
@@ -853,9 +922,9 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
     MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
                MS_ERR_INVALID_ARG, "isect_emit: null pointer");
     MS_REQUIRE(n_xl == 0 || sort_tmp, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
-    return emit_impl(N, means2d, radii, depths, tile_size, tile_w, tile_h, row_begin, row_end, workspace,
-                     workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp, flatten_ids,
-                     isect_ids, (hipStream_t)stream_);
+    return emit_impl(N, means2d, radii, depths, tight, tile_size, tile_w, tile_h, row_begin,
+                     row_end, workspace, workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp,
+                     flatten_ids, isect_ids, (hipStream_t)stream_);
 }
 
 extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, const int32_t *radii,
@@ -863,16 +932,16 @@ extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, 
                                                int row_begin, int row_end, void *workspace,
                                                size_t workspace_bytes, const int32_t *tile_ranges,
                                                const int64_t *isect_info_dev, int64_t capacity,
-                                               const int64_t *prev_info_host, uint64_t *sort_keys,
+                                               const int64_t *prev_info_host, int tight, uint64_t *sort_keys,
                                                int32_t *flatten_ids, void *stream_) {
     MS_REQUIRE(N >= 0 && isect_info_dev && capacity > 0 && capacity <= 0x7fffffffll, MS_ERR_INVALID_ARG,
                "isect_emit_speculative: bad N / info / capacity");
     if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
     MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
                MS_ERR_INVALID_ARG, "isect_emit_speculative: null pointer");
-    return emit_impl(N, means2d, radii, depths, tile_size, tile_w, tile_h, row_begin, row_end, workspace,
-                     workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity, sort_keys, nullptr,
-                     flatten_ids, nullptr, (hipStream_t)stream_);
+    return emit_impl(N, means2d, radii, depths, tight, tile_size, tile_w, tile_h, row_begin,
+                     row_end, workspace, workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity,
+                     sort_keys, nullptr, flatten_ids, nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_w,

@@ -80,7 +80,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         // projection + tile counting share one pass over the Gaussians (k_project_hist)
         if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
                                             cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, tile_size, r0, r1,
-                                            means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
+                                            /*tight=*/1, means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
                                             ranges, info, stream))
             return rc;
         mark(1);
@@ -101,12 +101,12 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
             if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                          ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
-                                                         keys, ids, stream))
+                                                         /*tight=*/opacities != nullptr, keys, ids, stream))
                 return rc;
             mark(2);
-            if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, c, means2d, conics, colors, color_dtype, CDIM, opacities,
-                                                         backgrounds, W, H, tile_size, r0, r1, ranges, ids,
-                                                         render_colors, nullptr, nullptr, stream))
+            if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
+                                           opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
+                                           render_colors, nullptr, nullptr, stream))
                 return rc;
             mark(3);
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0);
@@ -133,9 +133,11 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     const int64_t M = host_info[0], n_xl = host_info[4];
     MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld intersections do not fit int32",
                (long long)M);
-    if (M == 0 && r0 == 0 && r1 == th) {
-        // whole-image call: the reference returns a zeros image here, not the background
-        // (render.py:73-76).  A band call leaves that rule to the caller, who knows the other bands.
+    if (host_info[6] == 0 && r0 == 0 && r1 == th) {
+        // whole-image call with no Gaussian's bounding box on the grid (gsplat's isect_tiles would
+        // return an empty list; with tight binning M alone can be 0 while boxes exist): the
+        // reference returns a zeros image here, not the background (render.py:73-76).  A band call
+        // leaves that rule to the caller, who reads the same count from host_info[6].
         MS_HIP(hipMemsetAsync(render_colors, 0, (size_t)H * W * CDIM * sizeof(float), stream));
         if (!speculated) { mark(2); mark(3); }
         return MS_OK;
@@ -151,7 +153,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     uint64_t *tmp = n_xl > 0 ? (uint64_t *)(ib + key_bytes) : nullptr;
     int32_t *ids = (int32_t *)(ib + key_bytes * (n_xl > 0 ? 2 : 1));
     if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
-                                     L.isect_bytes, ranges, host_info, keys, tmp, ids, nullptr, stream))
+                                     L.isect_bytes, ranges, host_info, /*tight=*/opacities != nullptr, keys, tmp, ids,
+                                     nullptr, stream))
         return rc;
     if (!speculated) mark(2);
     if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, M, means2d, conics, colors, color_dtype, CDIM, opacities,

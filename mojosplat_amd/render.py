@@ -82,12 +82,12 @@ def render_gaussians(
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer
         img = torch.empty((camera.H, camera.W, colors.shape[-1]), dtype=torch.float32, device=means3d.device)
-        total = 0
+        info = {}
         for band in bands:
-            _, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
-                                  row_range=band, out=img)
-            total += m
-        return img if total > 0 else torch.zeros_like(img)
+            render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
+                           row_range=band, out=img, info=info)
+        # zeros when no Gaussian's box touches the grid (band-independent count, render.py:73-76)
+        return img if info["on_grid"] > 0 else torch.zeros_like(img)
 
     means2d, conics, depths, radii = project_gaussians(means3d, scales, quats, opacities, camera,
                                                        backend=backend)
