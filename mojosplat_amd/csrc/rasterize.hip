@@ -39,6 +39,8 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ms_common.hpp"
 
 namespace {
@@ -93,12 +95,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <int CP, typename ColorT, bool AUX, int WPB, int NQ>
 __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(RasterArgs A) {
     constexpr int CS = (CP == 3) ? 4 : CP;       // CP == 3: r,g ride in s_b; b alone at a 16-B stride (same LDS index as s_a/s_b)
-    __shared__ float4 s_a_all[WPB][kBatch];      // mean.x, mean.y, a', b'
-    __shared__ float4 s_b_all[WPB][kBatch];      // c', log2(opacity), (r, g | -, -)
-    __shared__ float s_col_all[WPB][kBatch * CS];
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4 *s_a = s_a_all[wib], *s_b = s_b_all[wib];
-    float *s_col = s_col_all[wib];
+    // one LDS block per wave, the three arrays at fixed offsets of it: with CS == 4 an entry's three
+    // records sit at the SAME index * 16 B, so the blend loop forms one LDS address per evaluation
+    // (a v_mov of the scalar index) and reaches all three through the instruction's offset field
+    struct Stage {
+        float4 a[kBatch];        // mean.x, mean.y, a', b'
+        float4 b[kBatch];        // c', log2(opacity), (r, g | -, -)
+        float col[kBatch * CS];
+    };
+    __shared__ Stage s_stage[WPB];
+    const int wib = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *s_a = s_stage[wib].a, *s_b = s_stage[wib].b;
+    float *s_col = s_stage[wib].col;
 
     const int vbid = blockIdx.x * WPB + wib;
     if (vbid >= A.nblocks) return;
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
     for (int b0 = start; b0 < end; b0 += kBatch) {
         // --- stage this batch: record -> LDS, reach of the alpha >= 1/255 ellipse -> quad votes
         int mask = 0;
+        bool npd = false;
         if (b0 + lane < end && r_op >= ms::kAlphaThreshold) {
             const float det = r_ca * r_cc - r_cb * r_cb;
             if (det > 0.f && r_ca > 0.f && r_cc > 0.f) {
@@ -201,7 +210,9 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
                 }
             } else {
                 mask = 0xf;  // not positive definite: no bound, evaluate everywhere
+                npd = true;
             }
+            npd = npd || r_op > ms::kMaxAlpha;  // the 0.999 clamp can bind: generic loop as well
         }
         unsigned long long B[NQ];
 #pragma unroll
@@ -225,47 +236,58 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
             fetch_id(b0 + 2 * kBatch);
         }
 
+        // sigma < 0 (skipped by the reference, rasterization.mojo:144) cannot happen for a positive
+        // definite conic, and alpha = o exp(-sigma) <= o cannot exceed 0.999 unless o does: only a
+        // batch holding such an entry pays for the sigma compare and the clamp
+        const bool check_sigma = __ballot(npd) != 0;
         bool any_live = false;
+        auto blend_batch = [&](auto check) __attribute__((always_inline)) {
+            constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            const int q = qbase + qi;
-            if (!__any(thr[qi] < kInf)) continue;  // every pixel of this quad is finished (or outside)
-            const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
-            unsigned long long m = B[qi];
-            while (m) {
-                const int t = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const float4 ra = s_a[t];
-                const float4 rb = s_b[t];
-                const float dx = ra.x - px, dy = ra.y - py;
-                // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
-                const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
-                const float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
-                const bool hit = la <= rb.y && alpha >= thr[qi];          // sigma >= 0 and alpha >= 1/255, live
-                const float next_T = fmaf(-alpha, T[qi], T[qi]);           // T (1 - alpha)
-                const bool add = hit && next_T > ms::kTransmittanceStop;
-                // one select (v_cmp / v_cndmask issue at half the FMA rate on gfx950, v_exp at a
-                // quarter): alpha -> 0 for lanes that do not blend, then everything else is FMAs
-                const float a_eff = add ? alpha : 0.f;
-                const float vis = a_eff * T[qi];
-                if constexpr (CP == 3) {
-                    pix[qi][0] += rb.z * vis;
-                    pix[qi][1] += rb.w * vis;
-                    pix[qi][2] += s_col[t * CS] * vis;
-                } else {
+            for (int qi = 0; qi < NQ; ++qi) {
+                const int q = qbase + qi;
+                if (!__any(thr[qi] < kInf)) continue;  // every pixel of this quad is finished (or outside)
+                const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
+                unsigned long long m = B[qi];
+                while (m) {
+                    const int t = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float4 ra = s_a[t];
+                    const float4 rb = s_b[t];
+                    const float dx = ra.x - px, dy = ra.y - py;
+                    // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
+                    const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
+                    float alpha = __builtin_amdgcn_exp2f(la);
+                    if constexpr (CHECK) alpha = fminf(ms::kMaxAlpha, alpha);
+                    bool hit = alpha >= thr[qi];                                  // alpha >= 1/255, pixel live
+                    if constexpr (CHECK) hit = hit && la <= rb.y;               // sigma >= 0
+                    const float next_T = fmaf(-alpha, T[qi], T[qi]);            // T (1 - alpha)
+                    const bool add = hit && next_T > ms::kTransmittanceStop;
+                    // one select (v_cmp / v_cndmask issue at half the FMA rate on gfx950, v_exp at a
+                    // quarter): alpha -> 0 for lanes that do not blend, then everything else is FMAs
+                    const float a_eff = add ? alpha : 0.f;
+                    const float vis = a_eff * T[qi];
+                    if constexpr (CP == 3) {
+                        pix[qi][0] += rb.z * vis;
+                        pix[qi][1] += rb.w * vis;
+                        pix[qi][2] += s_col[t * CS] * vis;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < CP; ++k) pix[qi][k] += s_col[t * CS + k] * vis;
+                        for (int k = 0; k < CP; ++k) pix[qi][k] += s_col[t * CS + k] * vis;
+                    }
+                    if constexpr (AUX) last[qi] = add ? b0 + t : last[qi];
+                    T[qi] = fmaf(-a_eff, T[qi], T[qi]);                         // next_T where blended, T elsewhere
+                    // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path.
+                    if (__ballot(hit && !add)) {
+                        asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
+                        thr[qi] = (hit && !add) ? kInf : thr[qi];
+                    }
                 }
-                if constexpr (AUX) last[qi] = add ? b0 + t : last[qi];
-                T[qi] = fmaf(-a_eff, T[qi], T[qi]);                         // next_T where blended, T elsewhere
-                // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path.
-                if (__ballot(hit && !add)) {
-                    asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
-                    thr[qi] = (hit && !add) ? kInf : thr[qi];
-                }
+                any_live = any_live || __any(thr[qi] < kInf);
             }
-            any_live = any_live || __any(thr[qi] < kInf);
-        }
+        };
+        if (check_sigma) blend_batch(std::true_type{});
+        else blend_batch(std::false_type{});
         if (!any_live) break;
     }
 

@@ -254,6 +254,30 @@ def test_raster_vs_oracle_64(device, N, bg):
     assert torch.equal(img, img2)  # deterministic, run-to-run bit-equal
 
 
+def test_raster_generic_branch_opaque_and_indefinite_conics(device):
+    """The rasteriser's fast blend loop drops the sigma >= 0 compare and the 0.999 clamp when a batch
+    holds only positive definite conics with opacity <= 0.999; entries outside that (opacity 1.0,
+    hand-made indefinite / negative conics where sigma < 0 must be skipped,
+    rasterization.mojo:143-145) take the generic loop.  Both against the oracle, mixed in one list."""
+    means3d, ls, quats, opac, colors = raster_scene(300, seed=21)
+    cam = simple_camera()
+    m2, con, ids, ranges = _oracle_pipeline(means3d, ls, quats, opac, cam)
+    opac = opac.clone()
+    opac[::3] = 1.0                       # alpha clamps at 0.999 near the centre
+    con = con.copy()
+    con[5::7, 1] = 3.0 * np.sqrt(np.abs(con[5::7, 0] * con[5::7, 2]))   # indefinite: sigma < 0 on one diagonal
+    con[6::11] *= -1.0                                                   # negative definite: sigma <= 0 everywhere
+    bgn = np.array([0.2, 0.1, 0.4], np.float32)
+    ref, _, _ = oracle.rasterize_fwd(m2, con, np_(colors), np_(opac), bgn, ranges, ids, 64, 64, 16)
+    to = lambda a: torch.from_numpy(a).to(device)
+    img = rasterize_gaussians_hip(to(m2), to(con), colors.to(device), opac.to(device), to(bgn), to(ranges),
+                                  to(ids), simple_camera(device), 16)
+    check_image(img, ref, max_outlier_frac=2e-3)
+    # and the clamp really binds somewhere in this scene
+    lo = oracle.rasterize_fwd(m2, con, np_(colors), np.minimum(np_(opac), 0.999), bgn, ranges, ids, 64, 64, 16)[0]
+    assert np.abs(lo - ref).max() > 1e-5
+
+
 def test_raster_128_f200(device):
     means3d, ls, quats, opac, colors = raster_scene(100, seed=3)
     cam = simple_camera(H=128, W=128, f=200.0)
