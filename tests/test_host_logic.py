@@ -136,3 +136,59 @@ def test_c_abi_exports_every_declared_symbol():
     assert Lt.ms_version() == _hip.ABI_VERSION
     assert Lt.ms_last_error_string() is not None
     assert Lt.ms_isect_workspace_bytes(1000, 120, 68) > 0
+
+
+def test_c_abi_argument_validation_returns_status_codes():
+    """Every entry point validates its arguments BEFORE touching the device and reports through the
+    status code + ms_last_error_string (no exception crosses the ABI) -- checkable
+    without a GPU.  Pointers are fake but non-null; nothing is dereferenced on these paths."""
+    import ctypes
+    L = _hip.load()
+    P = ctypes.c_void_p(0x1000)           # "some pointer": validation never dereferences it
+    N = ctypes.c_int64(10)
+    OK, INVALID, WORKSPACE, TOO_LARGE = 0, 1, 2, 3
+
+    def err():
+        return L.ms_last_error_string().decode()
+
+    # projection
+    assert L.ms_project_gaussians_fwd(ctypes.c_int64(-1), P, P, 1, P, P, P, 1., 1., 0., 0., 8, 8, .3, .1, 10., 0.,
+                                      P, P, P, P, None) == INVALID and "N < 0" in err()
+    assert L.ms_project_gaussians_fwd(N, None, P, 1, P, P, P, 1., 1., 0., 0., 8, 8, .3, .1, 10., 0.,
+                                      P, P, P, P, None) == INVALID and "null" in err()
+    assert L.ms_project_gaussians_fwd(N, P, P, 1, P, P, P, 0., 1., 0., 0., 8, 8, .3, .1, 10., 0.,
+                                      P, P, P, P, None) == INVALID and "camera" in err()
+    assert L.ms_project_gaussians_fwd(ctypes.c_int64(0), None, None, 1, None, None, None, 1., 1., 0., 0., 8, 8, .3,
+                                      .1, 10., 0., None, None, None, None, None) == OK   # N == 0 is a no-op
+    # binning: grid / band / workspace checks
+    ws_bytes = L.ms_isect_workspace_bytes(N, 4, 4)
+    assert ws_bytes > 0 and L.ms_isect_workspace_bytes(N, 0, 4) == 0
+    assert L.ms_isect_tiles_count(N, P, P, 16, 4, 4, 3, 2, P, ws_bytes, None, P, P, None) == INVALID \
+        and "row band" in err()
+    assert L.ms_isect_tiles_count(N, P, P, 16, 4, 4, 0, 4, P, 16, None, P, P, None) == WORKSPACE \
+        and "workspace" in err()
+    assert L.ms_isect_tiles_count(N, P, P, 16, 100000, 100000, 0, 1, P, ws_bytes, None, P, P, None) == TOO_LARGE
+    big = L.ms_isect_workspace_bytes(N, 512, 512)   # 262 144 tiles: more than one LDS histogram holds
+    assert L.ms_isect_tiles_count(N, P, P, 16, 512, 512, 0, 512, P, big, None, P, P, None) == TOO_LARGE \
+        and "LDS" in err()
+    # rasteriser
+    def rast(cdim=3, dtype=0, r0=0, r1=1, M=5):
+        return L.ms_rasterize_to_pixels_3dgs_fwd(N, ctypes.c_int64(M), P, P, P, dtype, cdim, P, None, 16, 16, 16,
+                                                 r0, r1, P, P, P, None, None, None)
+    assert rast(cdim=33) == INVALID and "CDIM" in err()
+    assert rast(dtype=7) == INVALID and "dtype" in err()
+    assert rast(r0=1, r1=3) == INVALID and "row band" in err()
+    assert rast(r0=1, r1=1) == OK                                    # empty band: nothing to launch
+    # spherical harmonics
+    assert L.ms_spherical_harmonics_fwd(N, 9, 5, P, 0., 0., 0., P, None, 1, 0, P, None) == INVALID and "degree" in err()
+    assert L.ms_spherical_harmonics_fwd(N, 4, 2, P, 0., 0., 0., P, None, 1, 0, P, None) == INVALID \
+        and "coefficients" in err()
+    # fused frame
+    host = (ctypes.c_int64 * 8)()
+    def frame(phase=0, r0=0, r1=1, wsb=1 << 30):
+        return L.ms_render_fwd(N, P, P, 1, P, P, P, 0, 3, P, 1., 1., 0., 0., 16, 16, .3, .1, 10., 16, r0, r1, None,
+                               P, wsb, None, 0, host, phase, P, None, None, None)
+    assert frame(phase=9) == INVALID and "phase" in err()
+    assert frame(r0=1, r1=0) == INVALID and "band" in err()
+    assert frame(wsb=8) == WORKSPACE and "workspace" in err()
+    assert L.ms_render_workspace_bytes(N, 1, 1) >= L.ms_isect_workspace_bytes(N, 1, 1)
