@@ -245,8 +245,10 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  *                after binning, after rasterisation (for in-situ kernel timing).
  * [tile_row_begin, tile_row_end) restricts binning and rasterisation to a band of tile rows
  * (0, tile_h = whole image); render_colors always addresses the FULL image.
- * Whole-image calls: M == 0 yields a ZERO image (reference render.py:73-76), otherwise
- * render_colors f32[H,W,CDIM] = composited colours + T * background.
+ * Whole-image calls: no bounding box on the grid yields a ZERO image (reference render.py:73-76),
+ * otherwise render_colors f32[H,W,CDIM] = composited colours + T * background.  render_alphas
+ * f32[H,W] and last_ids i32[H,W] (both nullable) are the per-pixel records the backward
+ * rasteriser needs (see ms_rasterize_to_pixels_3dgs_fwd).
  * ------------------------------------------------------------------------------------- */
 enum { MS_RENDER_WHOLE = 0, MS_RENDER_RESUME = 1, MS_RENDER_BEGIN = 2, MS_RENDER_FINISH = 3 };
 size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h);
@@ -258,7 +260,17 @@ int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scal
                   int tile_row_begin, int tile_row_end, const float *backgrounds, void *workspace,
                   size_t workspace_bytes,
                   void *isect_buf, size_t isect_bytes, int64_t *host_info, int resume,
-                  float *render_colors, void **stage_events, void *sync_event, void *stream);
+                  float *render_colors, float *render_alphas, int32_t *last_ids,
+                  void **stage_events, void *sync_event, void *stream);
+
+/* Where ms_render_fwd keeps its intermediates inside `workspace` (byte offsets), for callers that
+ * go on to differentiate the frame: offsets[0..4] = means2d f32[N,2], conics f32[N,3],
+ * depths f32[N], radii i32[N,2], tile_ranges i32[tile_h,tile_w,2]; offsets[5] = total bytes.
+ * The sorted Gaussian ids are the i32 array at byte offset align256(8 * capacity) of isect_buf on a
+ * frame that ran sync-free (capacity = (isect_bytes - 512) / 12 entries), and at
+ * align256(8 * M) * (1 + merge) on one that took the exact path (host_info[7] & 4 after the call;
+ * merge = host_info[4] > 0). */
+int ms_render_workspace_layout(int64_t N, int tile_w, int tile_h, size_t *offsets);
 
 /* ms_isect_tiles_emit without the host knowing M: `isect_info_dev` is the DEVICE record written
  * by ms_isect_tiles_count, `capacity` the number of entries sort_keys / flatten_ids can hold.

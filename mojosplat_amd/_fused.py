@@ -48,7 +48,11 @@ class _Frame:
     `run(phase)` makes the library call; `finish()` completes a frame that was only begun."""
 
     def __init__(self, means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                 stage_events, row_range, out, lane, stream=None):
+                 stage_events, row_range, out, lane, stream=None, own=False):
+        """own=True: the frame gets FRESH scratch (workspace, intersection buffer) and the per-pixel
+        records of the backward pass instead of the lane's cached buffers -- a differentiable frame
+        keeps them until its backward has run.  Only the size hint, the pinned record and the event
+        come from the lane."""
         self.L = L = _hip.lib()
         self.dev = dev = means3d.device
         N = means3d.shape[0]
@@ -69,7 +73,17 @@ class _Frame:
             vm = vm.to(dev)
         self.st = st = _dev_state(dev, lane)
         assert not st.get("busy"), "a begun frame still occupies this lane: finish it first"
-        ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
+        self.own = own
+        self.alphas = self.last = None
+        if own:
+            ws = torch.empty(L.ms_render_workspace_bytes(N, tw, th), dtype=torch.uint8, device=dev)
+            hint = st.get("own_isect_bytes", 0)
+            self.isect = torch.empty(hint, dtype=torch.uint8, device=dev) if hint else None
+            self.alphas = torch.empty((H, W), dtype=torch.float32, device=dev)
+            self.last = torch.empty((H, W), dtype=torch.int32, device=dev)
+        else:
+            ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
+        self.ws, self.grid = ws, (N, tw, th)
         r0, r1 = (0, th) if row_range is None else row_range
         if out is not None:
             assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
@@ -84,13 +98,13 @@ class _Frame:
         self.head = (N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(op), _hip.ptr(colors),
                      cdt, C, _hip.ptr(vm), camera.fx, camera.fy, camera.cx, camera.cy, W, H, EPS2D, camera.near,
                      camera.far, tile_size, r0, r1, _hip.ptr(bg), _hip.ptr(ws), ws.numel())
-        self.tail = (_hip.ptr(self.img), evs,
+        self.tail = (_hip.ptr(self.img), _hip.ptr(self.alphas), _hip.ptr(self.last), evs,
                      ctypes.c_void_p(st["ev"].cuda_event) if st.get("speculate", True) else None,
                      _hip.stream(dev) if stream is None else ctypes.c_void_p(stream))
         self.host_ptr = ctypes.c_void_p(st["host"].data_ptr())
 
     def run(self, phase):
-        isect = self.st["isect"]
+        isect = self.isect if self.own else self.st["isect"]
         return self.L.ms_render_fwd(*self.head, _hip.ptr(isect), 0 if isect is None else isect.numel(),
                                     self.host_ptr, phase, *self.tail)
 
@@ -108,7 +122,15 @@ class _Frame:
             rc = self.run(phase)
             if rc == 2:  # MS_ERR_WORKSPACE: the intersection buffer is too small for this frame's M
                 need = int(host[5])
-                if need > 0 and (st["isect"] is None or st["isect"].numel() < need):
+                if self.own:
+                    if need > 0:
+                        # the speculative kernels may still be running on the old block
+                        if self.isect is not None:
+                            torch.cuda.synchronize(self.dev)
+                        self.isect = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.dev)
+                        st["own_isect_bytes"] = self.isect.numel()
+                        rc = self.run(RESUME)
+                elif need > 0 and (st["isect"] is None or st["isect"].numel() < need):
                     _grow(st, "isect", need, self.dev, slack=1.25)
                     rc = self.run(RESUME)
             st["busy"] = False
@@ -118,7 +140,34 @@ class _Frame:
         st["speculate"] = int(host[4]) == 0
         if info is not None:
             info["on_grid"] = int(host[6])
+            info["flags"] = int(host[7])
+            info["n_xl"] = int(host[4])
         return self.img, int(host[0])
+
+    def intermediates(self, M, flags, n_xl):
+        """Views of what the frame left in its scratch: means2d, conics, radii, tile_ranges,
+        flatten_ids (ms_render_workspace_layout / the isect_buf layout rules of the header)."""
+        N, tw, th = self.grid
+        off = (ctypes.c_size_t * 6)()
+        _hip.check(self.L.ms_render_workspace_layout(N, tw, th, off), "ms_render_workspace_layout")
+
+        def view(buf, o, count, dtype, shape):
+            nbytes = count * torch.empty((), dtype=dtype).element_size()
+            return buf[o:o + nbytes].view(dtype).view(shape)
+        ws = self.ws
+        means2d = view(ws, off[0], N * 2, torch.float32, (N, 2))
+        conics = view(ws, off[1], N * 3, torch.float32, (N, 3))
+        radii = view(ws, off[3], N * 2, torch.int32, (N, 2))
+        ranges = view(ws, off[4], tw * th * 2, torch.int32, (th, tw, 2))
+        isect = self.isect if self.own else self.st["isect"]
+        align = lambda v: (v + 255) // 256 * 256
+        if flags & 4:   # exact layout
+            ids_off = align(8 * max(M, 1)) * (2 if n_xl > 0 else 1)
+        else:           # sync-free layout: keys sized by the buffer's capacity
+            cap = min((isect.numel() - 512) // 12, 0x7fffffff)
+            ids_off = align(8 * cap)
+        ids = view(isect, ids_off, M, torch.int32, (M,)) if M > 0 else torch.empty(0, dtype=torch.int32, device=self.dev)
+        return means2d, conics, radii, ranges, ids
 
 
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,

@@ -93,6 +93,66 @@ class _RasterizeHip(torch.autograd.Function):
         return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None
 
 
+class _RenderFusedHip(torch.autograd.Function):
+    """The whole differentiable frame around ONE forward library call (ms_render_fwd with the
+    backward's per-pixel records): fused projection + counting, tight binning, sync-free emit and
+    rasterise -- the inference path's forward -- with the frame's scratch kept alive for backward."""
+
+    @staticmethod
+    def forward(ctx, means3d, scales, quats, opacities, colors, background, camera, tile_size):
+        from ._fused import WHOLE, _Frame
+        frame = _Frame(means3d.detach(), scales.detach(), quats.detach(), opacities.detach(), colors.detach(),
+                       camera, background, tile_size, None, None, None, 0, own=True)
+        info = {}
+        img, M = frame.finish(WHOLE, info)
+        ctx.empty = info["on_grid"] == 0
+        ctx.camera, ctx.tile_size = camera, tile_size
+        m3, sc, qu, op, col, bg = frame.keep[:6]
+        if ctx.empty:
+            ctx.save_for_backward(m3, sc, qu, op, col, bg)
+            return img
+        means2d, conics, radii, ranges, ids = frame.intermediates(M, info["flags"], info["n_xl"])
+        ctx.scratch = (frame.ws, frame.isect)  # the views below alias these
+        ctx.save_for_backward(m3, sc, qu, op, col, bg, means2d, conics, radii, ranges, ids, frame.alphas, frame.last)
+        return img
+
+    @staticmethod
+    def backward(ctx, v_img):
+        cam, ts = ctx.camera, ctx.tile_size
+        if ctx.empty:
+            m3, sc, qu, op, col, bg = ctx.saved_tensors
+            return (torch.zeros_like(m3), torch.zeros_like(sc), torch.zeros_like(qu), torch.zeros_like(op),
+                    torch.zeros_like(col), None if bg is None else torch.zeros_like(bg), None, None)
+        m3, sc, qu, op, col, bg, means2d, conics, radii, ranges, ids, alphas, last = ctx.saved_tensors
+        L = _hip.lib()
+        N, C = col.shape
+        dev = m3.device
+        v_img = _hip.f32c(v_img)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        v_means2d, v_conics, v_colors, v_opac = z(N, 2), z(N, 3), z(N, C), z(N)
+        ws_bytes = L.ms_rasterize_bwd_workspace_bytes(N, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        v_means3d = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        vm = cam._viewmat_f32().to(dev)
+        with _hip.on_device(dev):
+            st = _hip.stream(dev)
+            _hip.check(L.ms_rasterize_to_pixels_3dgs_bwd(
+                N, ids.numel(), _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(col), C, _hip.ptr(op), _hip.ptr(bg),
+                cam.W, cam.H, ts, _hip.ptr(ranges), _hip.ptr(ids), _hip.ptr(alphas), _hip.ptr(last),
+                _hip.ptr(v_img), None, _hip.ptr(v_means2d), _hip.ptr(v_conics), _hip.ptr(v_colors),
+                _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes, st), "ms_rasterize_to_pixels_3dgs_bwd")
+            _hip.check(L.ms_project_gaussians_bwd(
+                N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(vm), cam.fx, cam.fy, cam.cx, cam.cy,
+                cam.W, cam.H, EPS2D, _hip.ptr(radii), _hip.ptr(v_means2d), _hip.ptr(v_conics), None,
+                _hip.ptr(v_means3d), _hip.ptr(v_scales), _hip.ptr(v_quats), st), "ms_project_gaussians_bwd")
+        v_bg = None
+        if bg is not None and ctx.needs_input_grad[5]:
+            v_bg = ((1.0 - alphas)[..., None] * v_img).sum(dim=(0, 1))
+        return v_means3d, v_scales, v_quats, v_opac, v_colors, v_bg, None, None
+
+
 def project_gaussians_autograd(means3d, scales, quats, opacities, camera: Camera):
     return _ProjectHip.apply(means3d, scales, quats, opacities, camera)
 
@@ -104,28 +164,34 @@ def rasterize_gaussians_autograd(means2d, conics, colors, opacities, background,
 
 
 def render_gaussians_trainable(means3d, scales, quats, opacities, features, camera: Camera,
-                               background_color=None, tile_size: int = 16, sh_degree=None):
+                               background_color=None, tile_size: int = 16, sh_degree=None,
+                               stagewise: bool = False):
     """Differentiable twin of ``render_gaussians(backend="hip")``: grads for means3d, scales
     (log-space), quats, opacities and colours (BASELINE config 3).  With ``sh_degree`` and
     features of shape (N, K, 3) the colours are view-dependent SH (sh.py): gradients then reach
-    the coefficients and, through the viewing direction, the means; Gaussians the projection
-    culled are skipped."""
+    the coefficients and, through the viewing direction, the means.
+
+    The forward is the inference path's single library call (fused projection + counting, tight
+    binning, sync-free emit + rasterise) with the backward's per-pixel records switched on;
+    ``stagewise=True`` runs the three per-stage autograd functions instead (gsplat-exact lists,
+    one host sync) -- same image, same gradients."""
     _hip.require_cuda(means3d, scales, quats, opacities, features, what="gaussian tensor")
     dev = means3d.device
-    means2d, conics, depths, radii = project_gaussians_autograd(means3d, scales, quats, opacities, camera)
     if features.dim() == 3:
         if sh_degree is None:
             raise ValueError("features of shape (N, K, 3) are SH coefficients: pass sh_degree")
         from .sh import evaluate_sh_hip
-        features = evaluate_sh_hip(means3d, features, camera, sh_degree, radii=radii)
+        features = evaluate_sh_hip(means3d, features, camera, sh_degree)
     C = features.shape[-1]
     bg = torch.zeros(C, device=dev) if background_color is None else \
         torch.as_tensor(background_color, dtype=torch.float32, device=dev)
-    th, tw = -(-camera.H // tile_size), -(-camera.W // tile_size)
-    with torch.no_grad():
-        ids, ranges = bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size, tw, th)
-    if ids.numel() == 0:
-        # same zeros image as the inference path (reference render.py:73-76), grad-connected
-        return (means3d.sum() + features.sum()) * 0 + torch.zeros(camera.H, camera.W, C, device=dev)
-    return rasterize_gaussians_autograd(means2d, conics, features, opacities, bg, ranges, ids,
-                                        camera, tile_size)
+    if stagewise or features.dtype != torch.float32:
+        means2d, conics, depths, radii = project_gaussians_autograd(means3d, scales, quats, opacities, camera)
+        th, tw = -(-camera.H // tile_size), -(-camera.W // tile_size)
+        with torch.no_grad():
+            ids, ranges = bin_gaussians_to_tiles_hip(means2d, radii, depths, tile_size, tw, th)
+        if ids.numel() == 0:
+            # same zeros image as the inference path (reference render.py:73-76), grad-connected
+            return (means3d.sum() + features.sum()) * 0 + torch.zeros(camera.H, camera.W, C, device=dev)
+        return rasterize_gaussians_autograd(means2d, conics, features, opacities, bg, ranges, ids, camera, tile_size)
+    return _RenderFusedHip.apply(means3d, scales, quats, opacities.reshape(-1), features, bg, camera, tile_size)

@@ -36,6 +36,15 @@ extern "C" size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h) {
     return ws_layout(N, tile_w, tile_h).total;
 }
 
+extern "C" int ms_render_workspace_layout(int64_t N, int tile_w, int tile_h, size_t *offsets) {
+    MS_REQUIRE(offsets && tile_w > 0 && tile_h > 0 && (int64_t)tile_w * tile_h < (1ll << 30), MS_ERR_INVALID_ARG,
+               "render_workspace_layout: bad argument");
+    const WsLayout L = ws_layout(N, tile_w, tile_h);
+    offsets[0] = L.off_means2d; offsets[1] = L.off_conics; offsets[2] = L.off_depths;
+    offsets[3] = L.off_radii;   offsets[4] = L.off_ranges; offsets[5] = L.total;
+    return MS_OK;
+}
+
 extern "C" size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch) {
     const size_t m = (size_t)(M > 0 ? M : 1);
     return ms::align_up(m * 8, 256) * (with_merge_scratch ? 2 : 1) + ms::align_up(m * 4, 256);
@@ -48,8 +57,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                              float far_plane, int tile_size, int tile_row_begin, int tile_row_end,
                              const float *backgrounds, void *workspace, size_t workspace_bytes, void *isect_buf,
                              size_t isect_bytes, int64_t *host_info, int resume,
-                             float *render_colors, void **stage_events, void *sync_event,
-                             void *stream_) {
+                             float *render_colors, float *render_alphas, int32_t *last_ids,
+                             void **stage_events, void *sync_event, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int phase = resume;
     MS_REQUIRE(phase >= MS_RENDER_WHOLE && phase <= MS_RENDER_FINISH, MS_ERR_INVALID_ARG, "render_fwd: bad phase %d",
@@ -106,7 +115,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             mark(2);
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
-                                           render_colors, nullptr, nullptr, stream))
+                                           render_colors, render_alphas, last_ids, stream))
                 return rc;
             mark(3);
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0);
@@ -144,6 +153,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     }
     const size_t need = ms_render_isect_bytes(M, n_xl > 0);
     host_info[5] = (int64_t)need;
+    host_info[7] |= 4;  // the lists the caller may read back are in the EXACT layout (below)
     MS_REQUIRE(isect_buf && isect_bytes >= need, MS_ERR_WORKSPACE,
                "render_fwd: intersection buffer %zu < %zu (grow it and call again with resume=1)", isect_bytes,
                need);
@@ -159,7 +169,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     if (!speculated) mark(2);
     if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, M, means2d, conics, colors, color_dtype, CDIM, opacities,
                                                  backgrounds, W, H, tile_size, r0, r1, ranges, ids, render_colors,
-                                                 nullptr, nullptr, stream))
+                                                 render_alphas, last_ids, stream))
         return rc;
     if (!speculated) mark(3);
     return MS_OK;

@@ -312,14 +312,13 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream) {
     const dim3 grid((unsigned)A.nblocks), block(64);
-    if (A.render_alphas || A.last_ids)
-        hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, true, 1, 4>), grid, block, 0, stream, A);
-    else if (A.parts == 2)
-        hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 1, 2>), grid, block, 0, stream, A);
-    else if (A.parts == 4)
-        hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 1, 1>), grid, block, 0, stream, A);
-    else
-        hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 1, 4>), grid, block, 0, stream, A);
+    const bool aux = A.render_alphas || A.last_ids;
+#define MS_LAUNCH_RASTER(AUXV, NQV) \
+    hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, 1, NQV>), grid, block, 0, stream, A)
+    if (A.parts == 2) { if (aux) MS_LAUNCH_RASTER(true, 2); else MS_LAUNCH_RASTER(false, 2); }
+    else if (A.parts == 4) { if (aux) MS_LAUNCH_RASTER(true, 1); else MS_LAUNCH_RASTER(false, 1); }
+    else { if (aux) MS_LAUNCH_RASTER(true, 4); else MS_LAUNCH_RASTER(false, 4); }
+#undef MS_LAUNCH_RASTER
 }
 
 template <typename ColorT>
@@ -377,7 +376,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     // per frame), 500 -> 2 (raster 165 -> 145 us), 3 000 -> 1 (2 costs +7 %); many-round launches
     // (4K: 32 400 blocks) gain nothing.
     A.parts = 1;
-    if (!render_alphas && !last_ids && blocks < 16384) {
+    if (blocks < 16384) {
         const int64_t per_block = density_hint / blocks;
         A.parts = per_block > 1500 ? 1 : per_block > 150 ? 2 : 4;
     }

@@ -138,3 +138,34 @@ def test_end_to_end_gradients_and_finite_difference(device):
     fd = ((lp - lm) / (2 * eps)).item()
     an = (leaves[4].grad * d).sum().item()
     assert abs(fd - an) <= 2e-3 * max(1.0, abs(an))
+
+
+@pytest.mark.parametrize("N,W,H,ell", [(3000, 320, 200, -3.0), (20000, 640, 360, -3.5)])
+def test_fused_differentiable_frame_equals_stagewise(device, N, W, H, ell):
+    """render_gaussians_trainable's default forward is ONE library call (tight binning, sync-free);
+    stagewise=True is the three per-stage autograd functions over gsplat-exact lists.  Same image
+    bit for bit (the pairs tight binning drops blend nowhere), gradients equal up to the order of
+    the float atomics; also on repeated frames (the second one runs sync-free) and on a growing
+    scene (the intersection buffer of the first is too small for the second)."""
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    bg = torch.tensor([0.2, 0.1, 0.3], device=device)
+    for rep, n in enumerate((N, N, 3 * N)):
+        sc, cam = randscene_v1(n, W, H, ell=ell, seed=17, device=device)
+        v_img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)).to(device)
+        res = []
+        for stagewise in (False, True):
+            leaves = [sc[k].clone().requires_grad_(True) for k in names]
+            img = render_gaussians_trainable(*leaves, cam, background_color=bg, stagewise=stagewise)
+            (img * v_img).sum().backward()
+            res.append((img.detach(), [l.grad for l in leaves]))
+        assert torch.equal(res[0][0], res[1][0]), rep
+        for name, a, b in zip(names, res[0][1], res[1][1]):
+            assert_grad_close(name, a, b, rel=1e-4)
+    # an empty frame: zeros image, zero gradients
+    sc, cam = randscene_v1(500, W, H, ell=ell, seed=17, device=device)
+    leaves = [sc[k].clone().requires_grad_(True) for k in names]
+    leaves[0] = (sc["means3d"] + torch.tensor([0.0, 0.0, 500.0], device=device)).requires_grad_(True)
+    img = render_gaussians_trainable(*leaves, cam, background_color=bg)
+    assert (img == 0).all()
+    img.sum().backward()
+    assert all((l.grad == 0).all() for l in leaves)
