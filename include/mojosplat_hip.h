@@ -115,8 +115,8 @@ int ms_isect_tiles_count(int64_t N, const float *means2d, const int32_t *radii, 
 int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
                         const float *depths, int tile_size, int tile_w, int tile_h,
                         int row_begin, int row_end, void *workspace, size_t workspace_bytes,
-                        const int32_t *tile_ranges, const int64_t *host_info, int tight,
-                        uint64_t *sort_keys,
+                        const int32_t *tile_ranges, const int64_t *host_info, int tight, int lazy,
+                        float depth_near, float depth_far, uint64_t *sort_keys,
                         uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
                         void *stream);
 
@@ -285,7 +285,8 @@ int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, const int32
                                     int row_begin, int row_end, void *workspace,
                                     size_t workspace_bytes, const int32_t *tile_ranges,
                                     const int64_t *isect_info_dev, int64_t capacity,
-                                    const int64_t *prev_info_host, int tight, uint64_t *sort_keys,
+                                    const int64_t *prev_info_host, int tight, int lazy,
+                                    float depth_near, float depth_far, uint64_t *sort_keys,
                                     int32_t *flatten_ids, void *stream);
 
 #ifdef __cplusplus

@@ -30,8 +30,8 @@ _SIGNATURES = {
     "ms_isect_tiles_count": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ms_isect_tiles_emit": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                    c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p]),
+                                    c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ms_project_isect_count": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                        c_float, c_float, c_float, c_int, c_int, c_float, c_float, c_float,
                                        c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -56,7 +56,8 @@ _SIGNATURES = {
     "ms_render_workspace_layout": (c_int, [c_int64, c_int, c_int, c_void_p]),
     "ms_isect_tiles_emit_speculative": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int64,
-                                                c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+                                                c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+                                                c_void_p]),
     "ms_spherical_harmonics_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_float, c_float, c_float, c_void_p,
                                            c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ms_spherical_harmonics_bwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_float, c_float, c_float, c_void_p,

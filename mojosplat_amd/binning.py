@@ -151,7 +151,7 @@ def _bin_hip_band(means2d, radii, depths, tile_size: int, tile_width: int, tile_
             _hip.check(L.ms_isect_tiles_emit(
                 N, _hip.ptr(means2d), _hip.ptr(radii), _hip.ptr(depths), tile_size, tile_width,
                 tile_height, r0, r1, _hip.ptr(ws), ws.numel(), _hip.ptr(tile_ranges), host_info,
-                0,  # gsplat-exact lists (tight binning is for ms_render_fwd only)
+                0, 0, 0.0, 0.0,  # gsplat-exact, fully sorted lists (tight binning / lazy sorting are for ms_render_fwd only)
                 _hip.ptr(keys), _hip.ptr(tmp), _hip.ptr(flatten_ids), _hip.ptr(isect_ids), st),
                 "ms_isect_tiles_emit")
     out = (flatten_ids, tile_ranges)

@@ -24,6 +24,7 @@
 //                     entries (136 KB); fixed-size persistent grids on sync-free frames
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
 #include <stdlib.h>
+#include <string.h>
 
 #include "project_device.hpp"
 
@@ -293,6 +294,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
                                                           int32_t *__restrict__ large_list,
                                                           int32_t *__restrict__ xl_list,
                                                           const uint32_t *__restrict__ wg_on_grid, int G,
+                                                          int32_t *__restrict__ redo_flag,
+                                                          int32_t *__restrict__ redo_count,
                                                           int64_t *__restrict__ info) {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
             const unsigned long long b = run + (incl - c), e = run + incl;
             reinterpret_cast<int2 *>(tile_ranges)[t] =
                 make_int2((int32_t)min(b, 0x7fffffffull), (int32_t)min(e, 0x7fffffffull));
+            redo_flag[t] = 0;
             lmax = max(lmax, c);
             if (c > (unsigned)kLargeCapDecl) xl_list[atomicAdd(&s_nxl, 1u)] = t;
             else if (c > (unsigned)kMediumCapDecl) large_list[atomicAdd(&s_nlarge, 1u)] = t;
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
         info[3] = (int64_t)s_nlarge;
         info[4] = (int64_t)s_nxl;
         info[5] = 0;
+        *redo_count = 0;
         info[6] = (int64_t)s_on_grid;  // Gaussians whose tile box touches the FULL grid (band-independent)
         info[7] = 0;
     }
@@ -588,6 +593,151 @@ __global__ __launch_bounds__(1024, (E <= 8 ? 8 : 4)) void k_tile_sort_list(const
     }
 }
 
+// ---- lazy sorting (fused path) ----------------------------------------------------------------
+// The rasteriser stops reading a tile's list once its 256 pixels are saturated -- after a few
+// hundred entries even where the list holds tens of thousands (measured: at most 459 entries of any
+// tile at config 3, 309 of lists up to 30 510 long at config 4; 3.9 % of all entries there).  So a
+// HEAVY tile (> 1024 entries) does not get its list sorted: only its FRONT -- the ~kFrontK nearest
+// entries -- is selected and sorted; the rasteriser is told how long the sorted front is and raises
+// a flag in the (so far unseen) case that pixels are still alive at its end, and a clean-up kernel
+// redoes exactly those tiles.
+//   pass A: min / max of the depth bits;  pass B: LDS histogram over 2048 order-preserving buckets;
+//   scan; b* = first bucket whose inclusive prefix reaches kFrontK;  pass C: keys of buckets <= b*
+//   go to LDS, rank themselves inside their bucket (as in sort_segment_lds) and leave as ids.
+// Three streams over the tile's keys (fresh from the scatter, mostly L2 / Infinity-Cache hits)
+// instead of a full sort; tiles of any length, no merge scratch, no host knowledge of sizes.
+constexpr int kFrontK = 1024;
+constexpr int kFrontCap = 4096;   // LDS room for selected keys (32 KB)
+constexpr int kFrontNB = 2048;
+constexpr size_t kFrontLds = (size_t)kFrontCap * 8 + (size_t)kFrontNB * 4 + 64 * 4 + 16;
+
+__global__ __launch_bounds__(1024) void k_tile_front(const int32_t *__restrict__ medium,
+                                                     const int32_t *__restrict__ large,
+                                                     const int32_t *__restrict__ xl,
+                                                     const int64_t *__restrict__ info_dev, int nm_host, int nl_host,
+                                                     int nx_host, const int32_t *__restrict__ tile_ranges,
+                                                     const uint64_t *__restrict__ keys,
+                                                     int32_t *__restrict__ flatten_ids,
+                                                     int32_t *__restrict__ front_count, int64_t cap,
+                                                     uint32_t fixed_min, int fixed_shift) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    uint64_t *s_out = reinterpret_cast<uint64_t *>(smem_dyn);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + kFrontCap);
+    uint32_t *s_red = s_cnt + kFrontNB;          // 64 words of reduction scratch
+    int *s_sel = reinterpret_cast<int *>(s_red + 64);  // [0] = b*, [1] = F
+    constexpr int THREADS = 1024, NW = 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nm = info_dev ? (int)info_dev[2] : nm_host, nl = info_dev ? (int)info_dev[3] : nl_host;
+    const int nx = info_dev ? (int)info_dev[4] : nx_host;
+    const int total = nm + nl + nx;
+    for (int li = blockIdx.x; li < total; li += gridDim.x) {
+        const int tile = li < nm ? medium[li] : (li < nm + nl ? large[li - nm] : xl[li - nm - nl]);
+        const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+        if ((int64_t)start + n > cap) continue;   // speculative overflow: the frame is redone (uniform)
+        const uint64_t *kin = keys + start;
+        // A. depth-bit range: the camera's [near, far] when the caller knows it (every surviving
+        //    depth lies inside, so the pass over the keys is saved), else the tile's own min / max
+        uint32_t kmin = fixed_min;
+        int shift = fixed_shift;
+        for (int b = tid; b < kFrontNB; b += THREADS) s_cnt[b] = 0;
+        if (fixed_shift < 0) {
+            uint32_t kmax = 0u;
+            kmin = 0xffffffffu;
+            for (int i = tid; i < n; i += THREADS) {
+                const uint32_t d = (uint32_t)(kin[i] >> 32);
+                kmin = min(kmin, d);
+                kmax = max(kmax, d);
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d));
+                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
+            }
+            if (lane == 0) { s_red[w] = kmin; s_red[16 + w] = kmax; }
+            __syncthreads();
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) { kmin = min(kmin, s_red[ww]); kmax = max(kmax, s_red[16 + ww]); }
+            const uint32_t span = kmax - kmin;
+            const int bits = span ? 32 - __clz(span) : 0;
+            shift = max(0, bits - 11);       // 2048 buckets
+        } else {
+            __syncthreads();
+        }
+        // B. histogram
+        auto bucket_of = [&](uint64_t k) -> int {
+            const uint32_t d = (uint32_t)(k >> 32);
+            const uint32_t b = (d > kmin ? d - kmin : 0u) >> shift;
+            return (int)min(b, (uint32_t)(kFrontNB - 1));
+        };
+        for (int i = tid; i < n; i += THREADS) atomicAdd(&s_cnt[bucket_of(kin[i])], 1u);
+        __syncthreads();
+        // scan: thread t owns buckets 2t, 2t+1
+        const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        __syncthreads();   // s_red reuse
+        if (lane == 63) s_red[w] = incl;
+        if (tid == 0) { s_sel[0] = -1; s_sel[1] = 0; }
+        __syncthreads();
+        uint32_t run = incl - (c0 + c1);
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww)
+            if (ww < w) run += s_red[ww];
+        const uint32_t e0 = run, e1 = run + c0, i1 = e1 + c1;   // exclusive prefixes of the two buckets, inclusive of the 2nd
+        // b* = the bucket whose inclusive prefix first reaches kFrontK (n > kFrontK, so it exists);
+        // if that would overflow the LDS room, stop one bucket earlier (possibly with nothing:
+        // >= kFrontCap entries at one depth -- the clean-up kernel takes such a tile)
+        if (c0 && e0 < (uint32_t)kFrontK && e1 >= (uint32_t)kFrontK) {
+            if (e1 <= (uint32_t)kFrontCap) { s_sel[0] = 2 * tid; s_sel[1] = (int)e1; }
+            else { s_sel[0] = 2 * tid - 1; s_sel[1] = (int)e0; }
+        }
+        if (c1 && e1 < (uint32_t)kFrontK && i1 >= (uint32_t)kFrontK) {
+            if (i1 <= (uint32_t)kFrontCap) { s_sel[0] = 2 * tid + 1; s_sel[1] = (int)i1; }
+            else { s_sel[0] = 2 * tid; s_sel[1] = (int)e1; }
+        }
+        s_cnt[2 * tid] = e0;
+        s_cnt[2 * tid + 1] = e1;
+        __syncthreads();
+        const int bstar = s_sel[0], F = s_sel[1];
+        // C. select
+        for (int i = tid; i < n; i += THREADS) {
+            const uint64_t k = kin[i];
+            const int b = bucket_of(k);
+            if (b <= bstar) s_out[atomicAdd(&s_cnt[b], 1u)] = k;   // s_cnt[b] becomes the END of bucket b
+        }
+        __syncthreads();
+        // rank inside the bucket; keys are distinct, so ranks are a permutation
+        uint64_t kk[kFrontCap / THREADS];
+        int dest[kFrontCap / THREADS];
+#pragma unroll
+        for (int e = 0; e < kFrontCap / THREADS; ++e) {
+            const int i = e * THREADS + tid;
+            dest[e] = -1;
+            if (i < F) {
+                kk[e] = s_out[i];
+                const int b = bucket_of(kk[e]);
+                const int beg = b ? (int)s_cnt[b - 1] : 0, end = (int)s_cnt[b];
+                // buckets > b* kept their exclusive prefix in s_cnt, so s_cnt[b-1] is the end of b-1 for every b <= b*
+                int r = 0;
+                for (int j = beg; j < end; ++j) r += s_out[j] < kk[e] ? 1 : 0;
+                dest[e] = beg + r;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kFrontCap / THREADS; ++e)
+            if (dest[e] >= 0) s_out[dest[e]] = kk[e];
+        __syncthreads();
+        for (int i = tid; i < F; i += THREADS) flatten_ids[start + i] = (int32_t)(uint32_t)s_out[i];
+        if (tid == 0) front_count[tile] = F;
+        __syncthreads();   // LDS is reused by the next list entry
+    }
+}
+
 // XL tiles: sort runs of kLargeCap in place ...
 __global__ __launch_bounds__(1024) void k_xl_chunk_sort(const int32_t *__restrict__ xl_list,
                                                         const int32_t *__restrict__ tile_ranges,
@@ -664,7 +814,8 @@ struct Plan {
     int64_t chunk;
     int T, T_local;
     size_t lds_bytes;
-    size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, total;
+    size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
+        off_redo_list, off_redo_count, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -685,6 +836,10 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
     p.off_on_grid = o; o += ms::align_up((size_t)kMaxG * 4, 256);
     p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
+    p.off_front = o;      o += ms::align_up((size_t)p.T * 4, 256);  // lazy sorting: sorted-front length per tile
+    p.off_redo_flag = o;  o += ms::align_up((size_t)p.T * 4, 256);  //   tiles whose front did not saturate them
+    p.off_redo_list = o;  o += ms::align_up((size_t)p.T * 4, 256);
+    p.off_redo_count = o; o += 256;
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -714,20 +869,34 @@ int allow_big_lds(K kernel) {
 
 namespace {
 // per-tile prefix over the partial histograms -> tile_ranges, M, work lists
-int count_tail(const Plan &p, const Grid &g, uint32_t *hist, uint32_t *count, int32_t *medium, int32_t *large,
-               int32_t *xl, const uint32_t *wg_on_grid, int n_wg, int32_t *tile_ranges, int64_t *isect_info,
-               hipStream_t stream) {
+int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t *count, int32_t *medium,
+               int32_t *large, int32_t *xl, const uint32_t *wg_on_grid, int n_wg, int32_t *tile_ranges,
+               int64_t *isect_info, hipStream_t stream) {
     if (p.T_local > 0) {
         hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
                            p.G, p.T_local, hist, count);
         MS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium, large, xl,
-                       wg_on_grid, n_wg, isect_info);
+                       wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count),
+                       isect_info);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
 }  // namespace
+
+// Where the lazy-sorting bookkeeping lives inside an isect workspace (for ms_render_fwd's rasteriser).
+void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, ms::LazyLists *out) {
+    Plan p;
+    make_plan(N, tile_w, tile_h, 0, tile_h, p);
+    char *ws = (char *)workspace;
+    out->front_count = (int32_t *)(ws + p.off_front);
+    out->redo_flag = (int32_t *)(ws + p.off_redo_flag);
+    out->redo_list = (int32_t *)(ws + p.off_redo_list);
+    out->redo_count = (int32_t *)(ws + p.off_redo_count);
+    out->front_threshold = kFrontK;
+    out->keys = nullptr;  // the caller knows where it put them
+}
 
 extern "C" size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h) {
     Plan p;
@@ -774,7 +943,7 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
                            p.chunk, hist, tiles_per_gauss, on_grid);
         MS_LAUNCH_CHECK();
     }
-    return count_tail(p, g, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
+    return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
                       stream);
 }
 
@@ -823,15 +992,15 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
                            quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks);
         MS_LAUNCH_CHECK();
     }
-    return count_tail(p, g, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
+    return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
                       stream);
 }
 
 namespace {
 // Shared by the exact emit (host knows M and the class counts) and the speculative one (it does
 // not: `info_dev` is the count pass's device record, `cap` the capacity of the key/id buffers).
-int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tight,
-              int tile_size,
+int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tight, int lazy,
+              float depth_near, float depth_far, int tile_size,
               int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
               const int32_t *tile_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
               uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
@@ -859,6 +1028,36 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
 
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
                   "sort class thresholds out of sync");
+    if (lazy) {
+        // heavy tiles: sorted front only (k_tile_front); everything else as usual
+        static_assert(kFrontK == kSmallCapDecl, "the front kernel takes over exactly where the small class ends");
+        if (spec || n_medium + n_large + n_xl > 0) {
+            if (int rc = allow_big_lds(k_tile_front)) return rc;
+            const int64_t heavy = n_medium + n_large + n_xl;
+            const unsigned grid = spec ? (unsigned)min(p.T, 1024) : (unsigned)(heavy < 1024 ? heavy : 1024);
+            // all surviving depths lie in the camera's (near, far): fixed order-preserving buckets
+            uint32_t fixed_min = 0;
+            int fixed_shift = -1;
+            if (depth_near > 0.f && depth_far > depth_near) {
+                uint32_t lo, hi;
+                memcpy(&lo, &depth_near, 4);
+                memcpy(&hi, &depth_far, 4);
+                const uint32_t span = hi - lo;
+                int bits = 0;
+                while (bits < 32 && (span >> bits)) ++bits;
+                fixed_min = lo;
+                fixed_shift = bits > 11 ? bits - 11 : 0;
+            }
+            hipLaunchKernelGGL(k_tile_front, dim3(grid), dim3(1024), kFrontLds, stream, medium, large, xl,
+                               spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
+                               sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift);
+            MS_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
+                           flatten_ids, isect_ids, cap);
+        MS_LAUNCH_CHECK();
+        return MS_OK;
+    }
     // (Running the size classes on two streams was measured: the fork/join events cost more
     // than the overlap buys -- bin stage 176 us forked vs 160 us in order.)
     hipStream_t big = stream;
@@ -910,7 +1109,8 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
                                    const float *depths, int tile_size, int tile_w, int tile_h,
                                    int row_begin, int row_end, void *workspace,
                                    size_t workspace_bytes, const int32_t *tile_ranges,
-                                   const int64_t *host_info, int tight, uint64_t *sort_keys,
+                                   const int64_t *host_info, int tight, int lazy, float depth_near,
+                                   float depth_far, uint64_t *sort_keys,
                                    uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
                                    void *stream_) {
     MS_REQUIRE(N >= 0 && host_info, MS_ERR_INVALID_ARG, "isect_emit: bad N / host_info");
@@ -921,9 +1121,10 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
     if (M == 0) return MS_OK;
     MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
                MS_ERR_INVALID_ARG, "isect_emit: null pointer");
-    MS_REQUIRE(n_xl == 0 || sort_tmp, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
-    return emit_impl(N, means2d, radii, depths, tight, tile_size, tile_w, tile_h, row_begin,
-                     row_end, workspace, workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp,
+    MS_REQUIRE(n_xl == 0 || sort_tmp || lazy, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
+    MS_REQUIRE(!lazy || !isect_ids, MS_ERR_INVALID_ARG, "isect_emit: lazy lists carry no isect_ids");
+    return emit_impl(N, means2d, radii, depths, tight, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+                     row_begin, row_end, workspace, workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp,
                      flatten_ids, isect_ids, (hipStream_t)stream_);
 }
 
@@ -932,15 +1133,16 @@ extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, 
                                                int row_begin, int row_end, void *workspace,
                                                size_t workspace_bytes, const int32_t *tile_ranges,
                                                const int64_t *isect_info_dev, int64_t capacity,
-                                               const int64_t *prev_info_host, int tight, uint64_t *sort_keys,
+                                               const int64_t *prev_info_host, int tight, int lazy,
+                                               float depth_near, float depth_far, uint64_t *sort_keys,
                                                int32_t *flatten_ids, void *stream_) {
     MS_REQUIRE(N >= 0 && isect_info_dev && capacity > 0 && capacity <= 0x7fffffffll, MS_ERR_INVALID_ARG,
                "isect_emit_speculative: bad N / info / capacity");
     if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
     MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
                MS_ERR_INVALID_ARG, "isect_emit_speculative: null pointer");
-    return emit_impl(N, means2d, radii, depths, tight, tile_size, tile_w, tile_h, row_begin,
-                     row_end, workspace, workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity,
+    return emit_impl(N, means2d, radii, depths, tight, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+                     row_begin, row_end, workspace, workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity,
                      sort_keys, nullptr, flatten_ids, nullptr, (hipStream_t)stream_);
 }
 

@@ -6,6 +6,8 @@
 // between the counting and the emitting half of the binning stage -- the same place
 // gsplat.isect_tiles has its own (reference call site mojosplat/binning.py:73-82).  Everything
 // else is enqueued back to back on the caller's stream.
+#include <stdlib.h>
+
 #include "ms_common.hpp"
 
 namespace {
@@ -30,6 +32,15 @@ WsLayout ws_layout(int64_t N, int tw, int th) {
 }
 
 }  // namespace
+
+// MOJOSPLAT_LAZY_SORT=0 switches lazy sorting off (full per-tile sorts, as the per-stage API does)
+static int ms_lazy_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_LAZY_SORT");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
 
 extern "C" size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h) {
     if (tile_w <= 0 || tile_h <= 0 || (int64_t)tile_w * tile_h >= (1ll << 30)) return 0;
@@ -83,6 +94,11 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
 
     // host_info[7] belongs to the library between the two halves of a frame: bit 0 = emit +
     // rasterise were enqueued speculatively, bit 1 = the large sort class was among them
+    // lazy sorting (binning.hip, k_tile_front): not for a differentiable frame, whose backward walks
+    // the full lists by position
+    const int lazy = (render_alphas || last_ids || !opacities || CDIM > 4) ? 0 : ms_lazy_enabled();
+    ms::LazyLists lazy_lists;
+    if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, tw, th, &lazy_lists);
     bool speculated = false;
     if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);
@@ -110,12 +126,13 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
             if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                          ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
-                                                         /*tight=*/opacities != nullptr, keys, ids, stream))
+                                                         /*tight=*/opacities != nullptr, lazy, near_plane, far_plane, keys, ids, stream))
                 return rc;
             mark(2);
+            lazy_lists.keys = keys;
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
-                                           render_colors, render_alphas, last_ids, stream))
+                                           render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr, stream))
                 return rc;
             mark(3);
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0);
@@ -132,8 +149,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             const int64_t cap = (int64_t)((isect_bytes - 512) / 12);
             const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
             const int64_t Ms = host_info[0];
-            const bool large_ok = host_info[3] == 0 || (host_info[7] & 2);  // large class sorted iff launched
-            if (Ms > 0 && Ms <= c && host_info[4] == 0 && large_ok) return MS_OK;  // the common case
+            const bool large_ok = lazy || host_info[3] == 0 || (host_info[7] & 2);  // large class sorted iff launched
+            if (Ms > 0 && Ms <= c && (lazy || host_info[4] == 0) && large_ok) return MS_OK;  // the common case
             // else: empty scene, overflow or a tile needing the merge path -> exact path below
         }
     } else {
@@ -151,7 +168,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         if (!speculated) { mark(2); mark(3); }
         return MS_OK;
     }
-    const size_t need = ms_render_isect_bytes(M, n_xl > 0);
+    const size_t need = ms_render_isect_bytes(M, n_xl > 0 && !lazy);
     host_info[5] = (int64_t)need;
     host_info[7] |= 4;  // the lists the caller may read back are in the EXACT layout (below)
     MS_REQUIRE(isect_buf && isect_bytes >= need, MS_ERR_WORKSPACE,
@@ -160,16 +177,18 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     char *ib = (char *)isect_buf;
     const size_t key_bytes = ms::align_up((size_t)M * 8, 256);
     uint64_t *keys = (uint64_t *)ib;
-    uint64_t *tmp = n_xl > 0 ? (uint64_t *)(ib + key_bytes) : nullptr;
-    int32_t *ids = (int32_t *)(ib + key_bytes * (n_xl > 0 ? 2 : 1));
+    const bool merge = n_xl > 0 && !lazy;
+    uint64_t *tmp = merge ? (uint64_t *)(ib + key_bytes) : nullptr;
+    int32_t *ids = (int32_t *)(ib + key_bytes * (merge ? 2 : 1));
     if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
-                                     L.isect_bytes, ranges, host_info, /*tight=*/opacities != nullptr, keys, tmp, ids,
-                                     nullptr, stream))
+                                     L.isect_bytes, ranges, host_info, /*tight=*/opacities != nullptr, lazy, near_plane, far_plane,
+                                     keys, tmp, ids, nullptr, stream))
         return rc;
     if (!speculated) mark(2);
-    if (int rc = ms_rasterize_to_pixels_3dgs_fwd(N, M, means2d, conics, colors, color_dtype, CDIM, opacities,
-                                                 backgrounds, W, H, tile_size, r0, r1, ranges, ids, render_colors,
-                                                 render_alphas, last_ids, stream))
+    lazy_lists.keys = keys;
+    if (int rc = ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
+                                   tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
+                                   lazy ? &lazy_lists : nullptr, stream))
         return rc;
     if (!speculated) mark(3);
     return MS_OK;

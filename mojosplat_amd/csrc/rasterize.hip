@@ -57,6 +57,7 @@ struct RasterArgs {
     float *render_alphas;
     int32_t *last_ids;
     int W, H, ts, tw, nsx, nsub, cdim, tile0, nblocks, max_isects, n_gauss, parts;
+    ms::LazyLists lazy;   // front_count == nullptr: every list is fully sorted
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -142,8 +143,11 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
     }
 
     // clamped to the list length the caller vouches for (a sync-free frame passes its buffer capacity)
-    const int end = min(A.tile_ranges[2 * tile + 1], A.max_isects);
-    const int start = min(A.tile_ranges[2 * tile], end);
+    const int end_all = min(A.tile_ranges[2 * tile + 1], A.max_isects);
+    const int start = min(A.tile_ranges[2 * tile], end_all);
+    // lazily sorted frame: a heavy tile's list is only sorted up to its front
+    int end = end_all;
+    if (A.lazy.front_count && end_all - start > A.lazy.front_threshold) end = start + min(A.lazy.front_count[tile], end_all - start);
     const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
     const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
 
@@ -291,6 +295,18 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
         if (!any_live) break;
     }
 
+    if (end < end_all) {  // wave-uniform; only heavy tiles of a lazily sorted frame get here
+        bool alive = false;
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) alive = alive || __any(thr[qi] < kInf);
+        if (alive) {
+            // pixels outlived the sorted front: the clean-up kernel redoes the whole tile (and
+            // overwrites what is stored below); once per tile, whichever wave gets there first
+            if (lane == 0 && atomicExch(&A.lazy.redo_flag[tile], 1) == 0)
+                A.lazy.redo_list[atomicAdd(A.lazy.redo_count, 1)] = tile;
+        }
+    }
+
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
         const int q = qbase + qi;
@@ -309,6 +325,217 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
     }
 }
 
+// ---- clean-up pass of a lazily sorted frame -----------------------------------------------------
+// Tiles on the redo list ran out of sorted front with pixels still alive (never seen on the
+// benchmark scenes; forced by tests with stacks of faint Gaussians and by 32-px tiles).  They are
+// redone from scratch here WITHOUT ever sorting their whole list: one 256-thread workgroup per tile
+// repeatedly (1) selects the next <= kRedoChunk smallest keys above the last one consumed -- range
+// of the eligible 64-bit keys, LDS histogram over 2048 order-preserving buckets, prefix, narrowing
+// into a crowded first bucket if need be (keys are distinct, so that terminates) -- (2) ranks them
+// inside their buckets, and (3) composites them, one wave per 8x8 quad and one pixel per lane, with
+// exactly the arithmetic of k_rasterize_fwd's generic loop, until every pixel is finished or the
+// list is exhausted.  Any list length, no scratch beyond LDS.  Slow and simple by design.
+constexpr int kRedoChunk = 512, kRedoCap = 1024, kRedoNB = 2048;
+
+template <int CP, typename ColorT>
+__global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
+    __shared__ uint64_t s_key[kRedoCap];
+    __shared__ uint32_t s_cnt[kRedoNB];
+    __shared__ unsigned long long s_red[16];
+    __shared__ int s_sel[4];                 // b*, F, first bucket, first bucket's count
+    __shared__ float4 s_pa[256], s_pb[256];  // staged entries: mean.x mean.y a' b' | c' log2(o) - -
+    __shared__ float s_pc[256 * CP];
+    __shared__ int s_alive[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lx = lane & 7, ly = lane >> 3;
+    const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
+    const int n_redo = *A.lazy.redo_count;
+    constexpr float kInf = __builtin_huge_valf();
+
+    for (int ri = blockIdx.x; ri < n_redo; ri += gridDim.x) {
+        const int tile = A.lazy.redo_list[ri];
+        const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
+        const int end_all = min(A.tile_ranges[2 * tile + 1], A.max_isects);
+        const int start = min(A.tile_ranges[2 * tile], end_all);
+        const int n = end_all - start;
+        const uint64_t *kin = A.lazy.keys + start;
+        for (int sub = 0; sub < A.nsub; ++sub) {
+            const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
+            const int q = w;  // one quad per wave
+            const int ox = sub_x * 16 + lx + (q & 1) * 8, oy = sub_y * 16 + ly + (q >> 1) * 8;
+            const int X = tile_x * A.ts + ox, Y = tile_y * A.ts + oy;
+            const bool in = ox < A.ts && oy < A.ts && X < A.W && Y < A.H;
+            const float px = (float)X + 0.5f, py = (float)Y + 0.5f;
+            float T = 1.0f, thr = in ? ms::kAlphaThreshold : kInf, pix[CP];
+#pragma unroll
+            for (int k = 0; k < CP; ++k) pix[k] = 0.f;
+            unsigned long long lower = 0ull;   // keys consumed so far are <= lower (exclusive bound once !first)
+            bool first = true;
+            for (;;) {
+                // ---- (1) next chunk: window [wlo, whi] over eligible keys
+                unsigned long long wlo = first ? 0ull : lower + 1ull, whi = ~0ull;
+                int bstar = -1, F = 0;
+                unsigned long long kmin = 0ull;
+                int shift = 0;
+                bool none = false;
+                for (;;) {
+                    unsigned long long mn = ~0ull, mx = 0ull;
+                    unsigned int cnt = 0;
+                    for (int i = tid; i < n; i += 256) {
+                        const unsigned long long k = kin[i];
+                        if (k >= wlo && k <= whi) { mn = k < mn ? k : mn; mx = k > mx ? k : mx; ++cnt; }
+                    }
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) {
+                        const unsigned long long omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+                        mn = omn < mn ? omn : mn;
+                        mx = omx > mx ? omx : mx;
+                        cnt += (unsigned int)__shfl_xor((int)cnt, d);
+                    }
+                    __syncthreads();   // previous users of s_red / s_cnt / s_sel are done
+                    if (lane == 0) { s_red[w] = mn; s_red[4 + w] = mx; s_red[8 + w] = cnt; }
+                    for (int b = tid; b < kRedoNB; b += 256) s_cnt[b] = 0;
+                    if (tid == 0) { s_sel[0] = -1; s_sel[1] = 0; s_sel[2] = -1; s_sel[3] = 0; }
+                    __syncthreads();
+                    unsigned long long total = 0;
+                    mn = ~0ull; mx = 0ull;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        mn = s_red[ww] < mn ? s_red[ww] : mn;
+                        mx = s_red[4 + ww] > mx ? s_red[4 + ww] : mx;
+                        total += s_red[8 + ww];
+                    }
+                    if (total == 0) { none = true; break; }   // uniform
+                    kmin = mn;
+                    const unsigned long long span = mx - mn;
+                    const int bits = span ? 64 - __clzll((long long)span) : 0;
+                    shift = max(0, bits - 11);
+                    for (int i = tid; i < n; i += 256) {
+                        const unsigned long long k = kin[i];
+                        if (k >= wlo && k <= whi) atomicAdd(&s_cnt[(unsigned int)((k - kmin) >> shift)], 1u);
+                    }
+                    __syncthreads();
+                    // exclusive scan of 2048 counters: thread t owns buckets 8t .. 8t+7
+                    unsigned int c[8], sum = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { c[j] = s_cnt[8 * tid + j]; sum += c[j]; }
+                    unsigned int incl = sum;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const unsigned int o = (unsigned int)__shfl_up((int)incl, d);
+                        if (lane >= d) incl += o;
+                    }
+                    __syncthreads();
+                    if (lane == 63) s_red[12 + w] = incl;
+                    __syncthreads();
+                    unsigned int run = incl - sum;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww)
+                        if (ww < w) run += (unsigned int)s_red[12 + ww];
+                    const unsigned int want = total < (unsigned long long)kRedoChunk ? (unsigned int)total : (unsigned int)kRedoChunk;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned int e = run, i2 = run + c[j];
+                        if (c[j] && e == 0) { s_sel[2] = 8 * tid + j; s_sel[3] = (int)c[j]; }   // first non-empty bucket
+                        if (c[j] && e < want && i2 >= want) {
+                            if (i2 <= (unsigned int)kRedoCap) { s_sel[0] = 8 * tid + j; s_sel[1] = (int)i2; }
+                            else { s_sel[0] = 8 * tid + j - 1; s_sel[1] = (int)e; }
+                        }
+                        s_cnt[8 * tid + j] = e;
+                        run = i2;
+                    }
+                    __syncthreads();
+                    bstar = s_sel[0]; F = s_sel[1];
+                    if (F > 0) break;
+                    // the first bucket alone overflows the chunk: narrow the window into it and retry
+                    const unsigned long long blo = kmin + ((unsigned long long)s_sel[2] << shift);
+                    wlo = blo > wlo ? blo : wlo;
+                    const unsigned long long bhi = shift ? blo + ((1ull << shift) - 1ull) : blo;
+                    whi = bhi < whi ? bhi : whi;
+                }
+                if (none) break;
+                // gather + rank
+                for (int i = tid; i < n; i += 256) {
+                    const unsigned long long k = kin[i];
+                    if (k >= wlo && k <= whi) {
+                        const int b = (int)((k - kmin) >> shift);
+                        if (b <= bstar) s_key[atomicAdd(&s_cnt[b], 1u)] = k;
+                    }
+                }
+                __syncthreads();
+                unsigned long long kk[kRedoCap / 256];
+                int dest[kRedoCap / 256];
+#pragma unroll
+                for (int e = 0; e < kRedoCap / 256; ++e) {
+                    const int i = e * 256 + tid;
+                    dest[e] = -1;
+                    if (i < F) {
+                        kk[e] = s_key[i];
+                        const int b = (int)((kk[e] - kmin) >> shift);
+                        const int beg = b ? (int)s_cnt[b - 1] : 0, en = (int)s_cnt[b];
+                        int r = 0;
+                        for (int j = beg; j < en; ++j) r += s_key[j] < kk[e] ? 1 : 0;
+                        dest[e] = beg + r;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < kRedoCap / 256; ++e)
+                    if (dest[e] >= 0) s_key[dest[e]] = kk[e];
+                __syncthreads();
+                lower = s_key[F - 1];
+                first = false;
+                // ---- (2) composite the chunk, 256 entries staged at a time
+                for (int e0 = 0; e0 < F; e0 += 256) {
+                    __syncthreads();
+                    if (e0 + tid < F) {
+                        const int g = min(max((int)(unsigned int)s_key[e0 + tid], 0), A.n_gauss - 1);
+                        const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
+                        const float ca = A.conics[3 * g], cb = A.conics[3 * g + 1], cc = A.conics[3 * g + 2];
+                        const float op = A.opacities[g];
+                        s_pa[tid] = make_float4(m.x, m.y, -0.5f * kLog2e * ca, -kLog2e * cb);
+                        // opacity below 1/255 can never blend: log2 -> -inf keeps alpha at 0
+                        s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold ? __log2f(op) : -kInf, 0.f, 0.f);
+#pragma unroll
+                        for (int k = 0; k < CP; ++k)
+                            s_pc[tid * CP + k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
+                    }
+                    __syncthreads();
+                    const int m = min(256, F - e0);
+                    for (int t = 0; t < m; ++t) {
+                        const float4 ra = s_pa[t], rb = s_pb[t];
+                        const float dx = ra.x - px, dy = ra.y - py;
+                        const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
+                        const float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
+                        const bool hit = alpha >= thr && la <= rb.y;
+                        const float next_T = fmaf(-alpha, T, T);
+                        const bool add = hit && next_T > ms::kTransmittanceStop;
+                        const float a_eff = add ? alpha : 0.f;
+                        const float vis = a_eff * T;
+#pragma unroll
+                        for (int k = 0; k < CP; ++k) pix[k] += s_pc[t * CP + k] * vis;
+                        T = fmaf(-a_eff, T, T);
+                        if (hit && !add) thr = kInf;
+                    }
+                }
+                // ---- (3) anyone still alive?
+                const bool wa = __any(thr < kInf);
+                __syncthreads();
+                if (lane == 0) s_alive[w] = wa ? 1 : 0;
+                __syncthreads();
+                if (!(s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3])) break;
+            }
+            if (in) {
+                const size_t p = (size_t)Y * A.W + X;
+#pragma unroll
+                for (int k = 0; k < CP; ++k)
+                    if (k < A.cdim) A.render_colors[p * A.cdim + k] = pix[k] + (A.backgrounds ? T * A.backgrounds[k] : 0.f);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream) {
     const dim3 grid((unsigned)A.nblocks), block(64);
@@ -319,6 +546,11 @@ void launch_cp(const RasterArgs &A, hipStream_t stream) {
     else if (A.parts == 4) { if (aux) MS_LAUNCH_RASTER(true, 1); else MS_LAUNCH_RASTER(false, 1); }
     else { if (aux) MS_LAUNCH_RASTER(true, 4); else MS_LAUNCH_RASTER(false, 4); }
 #undef MS_LAUNCH_RASTER
+    if constexpr (CP <= 4) {
+        // lazily sorted frame: redo the (normally zero) tiles whose front did not saturate them
+        if (A.lazy.front_count)
+            hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(64), dim3(256), 0, stream, A);
+    }
 }
 
 template <typename ColorT>
@@ -340,7 +572,8 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
                       const void *colors, int color_dtype, int CDIM, const float *opacities,
                       const float *backgrounds, int W, int H, int tile_size, int tile_row_begin,
                       int tile_row_end, const int32_t *tile_ranges, const int32_t *flatten_ids,
-                      float *render_colors, float *render_alphas, int32_t *last_ids, void *stream) {
+                      float *render_colors, float *render_alphas, int32_t *last_ids,
+                      const ms::LazyLists *lazy, void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_fwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_fwd: CDIM %d not in 1..32", CDIM);
@@ -354,6 +587,8 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.means2d = means2d; A.conics = conics; A.colors = colors; A.opacities = opacities;
     A.backgrounds = backgrounds; A.tile_ranges = tile_ranges; A.flatten_ids = flatten_ids;
     A.render_colors = render_colors; A.render_alphas = render_alphas; A.last_ids = last_ids;
+    if (lazy) A.lazy = *lazy;
+    else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     A.W = W; A.H = H; A.ts = tile_size;
     A.tw = (W + tile_size - 1) / tile_size;
     const int th = (H + tile_size - 1) / tile_size;
@@ -399,5 +634,5 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
                                                void *stream) {
     return ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                              tile_size, tile_row_begin, tile_row_end, tile_ranges, flatten_ids, render_colors,
-                             render_alphas, last_ids, stream);
+                             render_alphas, last_ids, nullptr, stream);
 }

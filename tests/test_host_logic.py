@@ -187,7 +187,7 @@ def test_c_abi_argument_validation_returns_status_codes():
     host = (ctypes.c_int64 * 8)()
     def frame(phase=0, r0=0, r1=1, wsb=1 << 30):
         return L.ms_render_fwd(N, P, P, 1, P, P, P, 0, 3, P, 1., 1., 0., 0., 16, 16, .3, .1, 10., 16, r0, r1, None,
-                               P, wsb, None, 0, host, phase, P, None, None, None)
+                               P, wsb, None, 0, host, phase, P, None, None, None, None, None)
     assert frame(phase=9) == INVALID and "phase" in err()
     assert frame(r0=1, r1=0) == INVALID and "band" in err()
     assert frame(wsb=8) == WORKSPACE and "workspace" in err()
