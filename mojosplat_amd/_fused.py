@@ -8,11 +8,14 @@ needs more).  The per-stage entry points stay available for callers that want th
 intermediates (project_gaussians / bin_gaussians_to_tiles / rasterize_gaussians).
 """
 import ctypes
+import os
 
 import torch
 
 from . import _hip
 from .projection import EPS2D
+
+LAZY_SORT = os.environ.get("MOJOSPLAT_LAZY_SORT", "1") != "0"  # mirrors csrc/pipeline.hip
 
 _state = {}  # (device, lane) -> dict(ws, isect, host, ev); lane 0 = the plain single-frame path
 
@@ -136,8 +139,10 @@ class _Frame:
             st["busy"] = False
             _hip.check(rc, "ms_render_fwd")
         # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
-        # on the exact path); do not speculate on the next frame of such a scene
-        st["speculate"] = int(host[4]) == 0
+        # on the exact path); do not speculate on the next frame of such a scene.  Lazily sorted frames
+        # (the library's default for plain forward frames of <= 4 channels) have no such tiles.
+        lazy = LAZY_SORT and not self.own and self.head[8] <= 4
+        st["speculate"] = lazy or int(host[4]) == 0
         if info is not None:
             info["on_grid"] = int(host[6])
             info["flags"] = int(host[7])
