@@ -51,7 +51,7 @@ int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means
                   const void *colors, int color_dtype, int CDIM, const float *opacities, const float *backgrounds,
                   int W, int H, int tile_size, int tile_row_begin, int tile_row_end, const int32_t *tile_ranges,
                   const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
-                  const LazyLists *lazy, void *stream);
+                  const LazyLists *lazy, void *after_raster_event, void *stream);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -132,9 +132,9 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             lazy_lists.keys = keys;
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
-                                           render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr, stream))
+                                           render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr,
+                                           stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
-            mark(3);
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0);
         }
         if (phase == MS_RENDER_BEGIN) return MS_OK;
@@ -188,8 +188,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     lazy_lists.keys = keys;
     if (int rc = ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                                    tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
-                                   lazy ? &lazy_lists : nullptr, stream))
+                                   lazy ? &lazy_lists : nullptr,
+                                   (!speculated && stage_events) ? stage_events[3] : nullptr, stream))
         return rc;
-    if (!speculated) mark(3);
     return MS_OK;
 }

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
 }
 
 template <int CP, typename ColorT>
-void launch_cp(const RasterArgs &A, hipStream_t stream) {
+void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
     const dim3 grid((unsigned)A.nblocks), block(64);
     const bool aux = A.render_alphas || A.last_ids;
 #define MS_LAUNCH_RASTER(AUXV, NQV) \
@@ -546,6 +546,8 @@ void launch_cp(const RasterArgs &A, hipStream_t stream) {
     else if (A.parts == 4) { if (aux) MS_LAUNCH_RASTER(true, 1); else MS_LAUNCH_RASTER(false, 1); }
     else { if (aux) MS_LAUNCH_RASTER(true, 4); else MS_LAUNCH_RASTER(false, 4); }
 #undef MS_LAUNCH_RASTER
+    // in-situ timing of THIS kernel: the caller's event goes between it and the clean-up launch
+    if (after_raster_event) (void)hipEventRecord((hipEvent_t)after_raster_event, stream);
     if constexpr (CP <= 4) {
         // lazily sorted frame: redo the (normally zero) tiles whose front did not saturate them
         if (A.lazy.front_count)
@@ -554,12 +556,12 @@ void launch_cp(const RasterArgs &A, hipStream_t stream) {
 }
 
 template <typename ColorT>
-int launch_fwd(const RasterArgs &A, hipStream_t stream) {
-    if (A.cdim == 3) launch_cp<3, ColorT>(A, stream);
-    else if (A.cdim <= 4) launch_cp<4, ColorT>(A, stream);
-    else if (A.cdim <= 8) launch_cp<8, ColorT>(A, stream);
-    else if (A.cdim <= 16) launch_cp<16, ColorT>(A, stream);
-    else launch_cp<32, ColorT>(A, stream);
+int launch_fwd(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
+    if (A.cdim == 3) launch_cp<3, ColorT>(A, stream, after_raster_event);
+    else if (A.cdim <= 4) launch_cp<4, ColorT>(A, stream, after_raster_event);
+    else if (A.cdim <= 8) launch_cp<8, ColorT>(A, stream, after_raster_event);
+    else if (A.cdim <= 16) launch_cp<16, ColorT>(A, stream, after_raster_event);
+    else launch_cp<32, ColorT>(A, stream, after_raster_event);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -573,7 +575,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
                       const float *backgrounds, int W, int H, int tile_size, int tile_row_begin,
                       int tile_row_end, const int32_t *tile_ranges, const int32_t *flatten_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
-                      const ms::LazyLists *lazy, void *stream) {
+                      const ms::LazyLists *lazy, void *after_raster_event, void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_fwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_fwd: CDIM %d not in 1..32", CDIM);
@@ -600,7 +602,10 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
                tile_row_end, th);
     A.tile0 = tile_row_begin * A.tw;
     const int band_tiles = (tile_row_end - tile_row_begin) * A.tw;
-    if (band_tiles == 0) return MS_OK;
+    if (band_tiles == 0) {
+        if (after_raster_event) (void)hipEventRecord((hipEvent_t)after_raster_event, (hipStream_t)stream);
+        return MS_OK;
+    }
     const int64_t blocks = (int64_t)band_tiles * A.nsub;
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
     // Waves per 16x16 block.  One wave per block leaves a one-round launch (<= 8192 wave slots on
@@ -619,8 +624,8 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.max_isects = (int)M;
     MS_REQUIRE(N > 0 || M == 0, MS_ERR_INVALID_ARG, "rasterize_fwd: M > 0 with N == 0");
     A.n_gauss = (int)(N < 0x7fffffffll ? (N > 0 ? N : 1) : 0x7fffffffll);
-    if (color_dtype == MS_COLOR_F16) return launch_fwd<__half>(A, (hipStream_t)stream);
-    return launch_fwd<float>(A, (hipStream_t)stream);
+    if (color_dtype == MS_COLOR_F16) return launch_fwd<__half>(A, (hipStream_t)stream, after_raster_event);
+    return launch_fwd<float>(A, (hipStream_t)stream, after_raster_event);
 }
 
 extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float *means2d,
@@ -634,5 +639,5 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
                                                void *stream) {
     return ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                              tile_size, tile_row_begin, tile_row_end, tile_ranges, flatten_ids, render_colors,
-                             render_alphas, last_ids, nullptr, stream);
+                             render_alphas, last_ids, nullptr, nullptr, stream);
 }
