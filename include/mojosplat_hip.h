@@ -133,7 +133,16 @@ int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
  * The lists are then no longer gsplat's: tight mode is for callers that only want pixels
  * (ms_render_fwd); M and tile_ranges count the kept pairs, isect_info[6] still counts bounding
  * boxes.  The per-Gaussian reach masks stay in the workspace: the emit that follows a tight count
- * MUST pass tight = 1 (and tight = 0 after ms_isect_tiles_count or a non-tight count). */
+ * MUST pass tight = 1 (and tight = 0 after ms_isect_tiles_count or a non-tight count).
+ *
+ * lazy != 0 on the emit calls: LAZY SORTING, also for pixel-only callers.  Tiles of more than 1024
+ * entries get only their front (about the 1024 nearest entries) selected and sorted; the workspace
+ * then holds, per tile, the length of that sorted front, and flatten_ids beyond it is undefined.
+ * depth_near / depth_far (> 0, the camera planes every surviving depth lies between) let the
+ * selection use fixed depth buckets and skip a pass; 0, 0 = unknown.  Only ms_render_fwd's
+ * rasteriser understands such lists (it redoes a tile whose front did not saturate its pixels);
+ * pass lazy = 0 for lists that anyone else reads.  MOJOSPLAT_LAZY_SORT=0 in the environment makes
+ * ms_render_fwd sort fully. */
 int ms_project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
                            const float *quats, const float *opacities, const float *viewmat, float fx,
                            float fy, float cx, float cy, int W, int H, float eps2d, float near_plane,
