@@ -44,6 +44,7 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 
 
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
+FULL_SORT = 0x100
 
 
 class _Frame:
@@ -107,6 +108,8 @@ class _Frame:
         self.host_ptr = ctypes.c_void_p(st["host"].data_ptr())
 
     def run(self, phase):
+        if self.st.get("full_sort"):
+            phase |= FULL_SORT
         isect = self.isect if self.own else self.st["isect"]
         return self.L.ms_render_fwd(*self.head, _hip.ptr(isect), 0 if isect is None else isect.numel(),
                                     self.host_ptr, phase, *self.tail)
@@ -141,7 +144,12 @@ class _Frame:
         # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
         # on the exact path); do not speculate on the next frame of such a scene.  Lazily sorted frames
         # (the library's default for plain forward frames of <= 4 channels) have no such tiles.
-        lazy = LAZY_SORT and not self.own and self.head[8] <= 4
+        # a scene whose lazily sorted fronts keep failing (the clean-up pass is slow by design) goes
+        # back to full sorts: host[5] = tiles the previous frame on this lane had to redo
+        heavy = int(host[2]) + int(host[3]) + int(host[4])
+        if rc == 0 and not self.own and not (int(host[7]) & 4) and int(host[5]) > max(3, heavy // 4):
+            st["full_sort"] = True
+        lazy = LAZY_SORT and not self.own and self.head[8] <= 4 and not st.get("full_sort")
         st["speculate"] = lazy or int(host[4]) == 0
         if info is not None:
             info["on_grid"] = int(host[6])

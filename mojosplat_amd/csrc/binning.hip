@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
         info[2] = (int64_t)s_nmedium;
         info[3] = (int64_t)s_nlarge;
         info[4] = (int64_t)s_nxl;
-        info[5] = 0;
+        info[5] = (int64_t)*redo_count;  // tiles the PREVIOUS frame on this workspace had to redo (lazy sorting)
         *redo_count = 0;
         info[6] = (int64_t)s_on_grid;  // Gaussians whose tile box touches the FULL grid (band-independent)
         info[7] = 0;

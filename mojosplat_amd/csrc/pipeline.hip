@@ -71,7 +71,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                              float *render_colors, float *render_alphas, int32_t *last_ids,
                              void **stage_events, void *sync_event, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    const int phase = resume;
+    const int phase = resume & 0xff;
     MS_REQUIRE(phase >= MS_RENDER_WHOLE && phase <= MS_RENDER_FINISH, MS_ERR_INVALID_ARG, "render_fwd: bad phase %d",
                phase);
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "render_fwd: bad sizes");
@@ -96,7 +96,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     // rasterise were enqueued speculatively, bit 1 = the large sort class was among them
     // lazy sorting (binning.hip, k_tile_front): not for a differentiable frame, whose backward walks
     // the full lists by position
-    const int lazy = (render_alphas || last_ids || !opacities || CDIM > 4) ? 0 : ms_lazy_enabled();
+    const int lazy = (render_alphas || last_ids || !opacities || CDIM > 4 || (resume & MS_RENDER_FULL_SORT)) ? 0 : ms_lazy_enabled();
     ms::LazyLists lazy_lists;
     if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, tw, th, &lazy_lists);
     bool speculated = false;

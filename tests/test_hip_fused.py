@@ -138,10 +138,12 @@ def _stack_scene(n, z_lo, z_hi, opacity, device, seed=0):
     return {k: v.to(device) for k, v in sc.items()}, cam
 
 
-@pytest.mark.parametrize("n,z_lo,z_hi,opacity", [(4000, 4.0, 6.0, 0.005),     # fronts of 1024 leave T ~ 0.006
-                                                 (6000, 5.0, 5.0, 0.004),     # ONE depth: the order is by index alone
-                                                 (3000, 4.0, 4.0001, 0.02)])  # a handful of depth values, saturating late
-def test_lazy_sorting_clean_up_pass(device, n, z_lo, z_hi, opacity):
+@pytest.mark.parametrize("n,z_lo,z_hi,opacity,falls_back", [
+    (4000, 4.0, 6.0, 0.005, True),       # fronts of 1024 leave T ~ 0.006: every heavy tile is redone
+    (6000, 5.0, 5.0, 0.004, False),      # ONE depth, ~2000 per tile: one crowded bucket = the whole list = the front
+    (16000, 5.0, 5.0, 0.0055, True),     # ONE depth, > 4096 per tile: no front fits; the clean-up narrows by index
+    (3000, 4.0, 4.0001, 0.02, False)])   # a handful of depth values, saturating late
+def test_lazy_sorting_clean_up_pass(device, n, z_lo, z_hi, opacity, falls_back):
     """ms_render_fwd sorts only the front (~1024 nearest entries) of a heavy tile; here that front
     cannot saturate the pixels, so every tile goes through the clean-up kernel (chunked selection,
     including the narrowing into crowded buckets when thousands of entries share one depth).  The
@@ -158,6 +160,10 @@ def test_lazy_sorting_clean_up_pass(device, n, z_lo, z_hi, opacity):
     # some pixel really blended an entry beyond the 1024-entry front of its (heavy) tile
     deepest = (last.view(4, 16, 4, 16).permute(0, 2, 1, 3).reshape(4, 4, 256).max(-1).values - ranges[..., 0])
     assert (deepest[counts > 1024] > 1100).any()
-    for _ in range(2):   # exact path first, sync-free second
-        img = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    _fused._state.clear()
+    for _ in range(4):   # exact path first, then sync-free; the scene keeps failing its fronts, so the
+        img = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")   # lane falls back to full sorts
         assert torch.equal(img, ref)
+    if falls_back:
+        assert _fused._dev_state(sc["means3d"].device, 0).get("full_sort")
+    _fused._state.clear()   # do not leak the fallback into other tests
