@@ -206,7 +206,9 @@ __device__ __forceinline__ void wave_lds_sync_bwd() {
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return v;
+    // every lane holds the maximum: hand it back as a SCALAR, so that everything derived from it
+    // (per-quad entry masks, loop bounds) stays in SGPRs and branches on it are scalar branches
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // Sum 8 per-lane values over the 64 lanes with a halving butterfly: at distance 1, 2, 4 each lane
@@ -365,28 +367,29 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
                 const float alpha = fminf(ms::kMaxAlpha, ov);
                 const bool valid = cur <= binf[q] && lp <= 0.f && alpha >= ms::kAlphaThreshold;
                 anyv |= __ballot(valid);
-                if (valid) {
-                    const float ra_ = 1.0f / (1.0f - alpha);
-                    T[q] *= ra_;
-                    const float fac = alpha * T[q];
-                    float v_alpha = tb[q] * ra_;
+                // Branch-free from here on: lanes that do not blend this entry contribute zeros through
+                // selects.  (Divergent `if (valid)` blocks made the compiler copy the nine accumulators
+                // at every merge -- ~30 v_mov per evaluation -- and an IEEE division cost 12 more.)
+                const float ra_ = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float Tn = T[q] * ra_;                  // transmittance in front of this entry
+                T[q] = valid ? Tn : T[q];
+                const float fac = valid ? alpha * Tn : 0.f;
+                float v_alpha = tb[q] * ra_;
 #pragma unroll
-                    for (int k = 0; k < CP; ++k) {
-                        acc[6 + k] = fmaf(fac, v_out[q][k], acc[6 + k]);
-                        v_alpha = fmaf(fmaf(cv[k], T[q], -buf[q][k] * ra_), v_out[q][k], v_alpha);
-                        buf[q][k] = fmaf(cv[k], fac, buf[q][k]);
-                    }
-                    if (ov <= ms::kMaxAlpha) {
-                        const float vs = -ov * v_alpha;
-                        const float sx = vs * dx, sy = vs * dy;
-                        acc[0] += sx;
-                        acc[1] += sy;
-                        acc[2] = fmaf(sx, dx, acc[2]);
-                        acc[3] = fmaf(sx, dy, acc[3]);
-                        acc[4] = fmaf(sy, dy, acc[4]);
-                        acc[5] = fmaf(vis, v_alpha, acc[5]);
-                    }
+                for (int k = 0; k < CP; ++k) {
+                    acc[6 + k] = fmaf(fac, v_out[q][k], acc[6 + k]);
+                    v_alpha = fmaf(fmaf(cv[k], Tn, -buf[q][k] * ra_), v_out[q][k], v_alpha);
+                    buf[q][k] = fmaf(cv[k], fac, buf[q][k]);
                 }
+                const bool unclamped = valid && ov <= ms::kMaxAlpha;   // the 0.999 clamp has no gradient
+                const float vs = unclamped ? -ov * v_alpha : 0.f;
+                const float sx = vs * dx, sy = vs * dy;
+                acc[0] += sx;
+                acc[1] += sy;
+                acc[2] = fmaf(sx, dx, acc[2]);
+                acc[3] = fmaf(sx, dy, acc[3]);
+                acc[4] = fmaf(sy, dy, acc[4]);
+                acc[5] += unclamped ? vis * v_alpha : 0.f;
             }
             if (anyv == 0ull) continue;
             // raw sums Sx Sy S1 S2 S3 op c0 c1 -> lanes 0..7; remaining colour channel(s) -> lane 63
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
         wave_lds_sync_bwd();
         // ---- flush: 4 packed rows (4 x 64 B contiguous) per wave instruction
         const int colm = lane & 15, rsub = lane >> 4;
+#pragma unroll 1
         for (int r4 = 0; r4 < 64; r4 += 4) {
             if (((flush >> r4) & 0xfull) == 0ull) continue;
             const int r = r4 + rsub;
