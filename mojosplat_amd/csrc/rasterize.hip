@@ -192,7 +192,8 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
                 // for elongated / rotated Gaussians).  Slack keeps the test conservative w.r.t. the
                 // per-pixel alpha >= 1/255 decision.
                 const float smax = __logf(r_op * 255.0f) * 1.0001f + 1e-4f;
-                const float nb_c = -r_cb / r_cc, nb_a = -r_cb / r_ca;
+                // (approximate reciprocals: their 1e-7 relative error is far inside the test's slack)
+                const float nb_c = -r_cb * __builtin_amdgcn_rcpf(r_cc), nb_a = -r_cb * __builtin_amdgcn_rcpf(r_ca);
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) {
                     const int q = qbase + qi;
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
             bool first = true;
             for (;;) {
                 // ---- (1) next chunk: window [wlo, whi] over eligible keys
+                if (!first && lower == ~0ull) break;   // nothing can follow the largest key (and lower + 1 would wrap)
                 unsigned long long wlo = first ? 0ull : lower + 1ull, whi = ~0ull;
                 int bstar = -1, F = 0;
                 unsigned long long kmin = 0ull;

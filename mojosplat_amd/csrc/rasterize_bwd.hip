@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
                 if (det > 0.f && ca > 0.f && cc > 0.f) {
                     // exact ellipse-vs-quad test, as in the forward kernel (rasterize.hip)
                     const float smax = __logf(op * 255.0f) * 1.0001f + 1e-4f;
-                    const float nb_c = -cb / cc, nb_a = -cb / ca;
+                    const float nb_c = -cb * __builtin_amdgcn_rcpf(cc), nb_a = -cb * __builtin_amdgcn_rcpf(ca);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float xl = fbx + (float)((q & 1) * 8) - mx, xh = xl + 7.0f;
