@@ -124,7 +124,8 @@ int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
  * same semantics; the tile grid is derived from W, H, tile_size).  What ms_render_fwd starts a
  * frame with: the projected means / radii are not re-read and one kernel launch is saved.
  *
- * tight != 0 (needs opacities): TIGHT binning.  gsplat.isect_tiles lists every tile of a
+ * `tight` is a bit set.  Bit 1 (value 2): tile_ranges is written for the tiles of the band only
+ * (for a caller whose later stages all stay inside the band).  Bit 0 (needs opacities): TIGHT binning.  gsplat.isect_tiles lists every tile of a
  * Gaussian's bounding box; ~18 % of those pairs (config 3) can never blend because the
  * alpha >= 1/255 ellipse does not reach the tile (box corners, elongated / rotated footprints).
  * Tight mode drops them (per tile row, the x-extent of the ellipse inside the row's band of pixel

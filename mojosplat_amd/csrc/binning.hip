@@ -296,14 +296,16 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
                                                           const uint32_t *__restrict__ wg_on_grid, int G,
                                                           int32_t *__restrict__ redo_flag,
                                                           int32_t *__restrict__ redo_count,
-                                                          int64_t *__restrict__ info) {
+                                                          int band_only, int64_t *__restrict__ info) {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
-    const int T = g.tw * g.th;
     const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
+    // band_only: tile_ranges is written for the band's tiles alone (a caller whose later stages all
+    // stay inside the band -- ms_render_fwd on a multi-GPU rank -- saves the walk over the rest)
+    const int t_lo = band_only ? band0 : 0, t_hi = band_only ? band1 : g.tw * g.th;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int per_wave = ((T + 15) / 16 + 63) & ~63;   // tiles per wave, a multiple of 64
-    const int w0 = w * per_wave, w1 = min(T, w0 + per_wave);
+    const int per_wave = ((t_hi - t_lo + 15) / 16 + 63) & ~63;   // tiles per wave, a multiple of 64
+    const int w0 = t_lo + w * per_wave, w1 = min(t_hi, w0 + per_wave);
     if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; }
     auto count_of = [&](int t) -> unsigned int {
         return (t < w1 && t >= band0 && t < band1) ? tile_count[t - band0] : 0u;
@@ -564,9 +566,10 @@ constexpr int kLargeCap = SortCfg<1024, 16>::CAP;   // 16384: 1024 threads, 144 
 __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restrict__ tile_ranges,
                                                          const uint64_t *__restrict__ keys,
                                                          int32_t *__restrict__ flatten_ids,
-                                                         int64_t *__restrict__ isect_ids, int64_t cap) {
+                                                         int64_t *__restrict__ isect_ids, int64_t cap,
+                                                         int tile_lo) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SortCfg<256, 4>::LDS];
-    const int tile = blockIdx.x;
+    const int tile = tile_lo + blockIdx.x;   // the band's tiles: ranges outside it are empty (or unwritten)
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
     if (n <= 0 || n > kSmallCap || (int64_t)start + n > cap) return;  // beyond cap: speculative overflow
     sort_segment_lds<256, 4>(smem, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
@@ -871,7 +874,7 @@ namespace {
 // per-tile prefix over the partial histograms -> tile_ranges, M, work lists
 int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t *count, int32_t *medium,
                int32_t *large, int32_t *xl, const uint32_t *wg_on_grid, int n_wg, int32_t *tile_ranges,
-               int64_t *isect_info, hipStream_t stream) {
+               int64_t *isect_info, int band_only, hipStream_t stream) {
     if (p.T_local > 0) {
         hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
                            p.G, p.T_local, hist, count);
@@ -879,7 +882,7 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
     }
     hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium, large, xl,
                        wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count),
-                       isect_info);
+                       band_only, isect_info);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -944,7 +947,7 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
-                      stream);
+                      /*band_only=*/0, stream);
 }
 
 // Projection + tile counting in one pass over the Gaussians (what a frame starts with): the
@@ -982,7 +985,7 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
     int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
     uint32_t *on_grid = (uint32_t *)(ws + p.off_on_grid);
     const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
-    unsigned long long *masks = (tight && opacities) ? (unsigned long long *)(ws + p.off_mask) : nullptr;
+    unsigned long long *masks = ((tight & 1) && opacities) ? (unsigned long long *)(ws + p.off_mask) : nullptr;
     const ms::ProjParams P = ms::make_proj_params(fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, radius_clip,
                                                   scales_are_log, opacities != nullptr);
     if (N > 0) {
@@ -993,7 +996,7 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
-                      stream);
+                      (tight & 2) ? 1 : 0, stream);
 }
 
 namespace {
@@ -1053,8 +1056,9 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift);
             MS_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
-                           flatten_ids, isect_ids, cap);
+        if (p.T_local > 0)
+            hipLaunchKernelGGL(k_tile_sort_small, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
+                               sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w);
         MS_LAUNCH_CHECK();
         return MS_OK;
     }
@@ -1080,8 +1084,9 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                            sort_keys, flatten_ids, isect_ids, spec ? info_dev + 3 : nullptr, (int)n_large, cap);
         MS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_tile_sort_small, dim3(p.T), dim3(256), 0, stream, tile_ranges, sort_keys,
-                       flatten_ids, isect_ids, cap);
+    if (p.T_local > 0)
+        hipLaunchKernelGGL(k_tile_sort_small, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
+                           sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w);
     MS_LAUNCH_CHECK();
     if (n_xl > 0) {  // exact mode only: a speculative frame with XL tiles is redone by the caller
         if (int rc = allow_big_lds(k_xl_chunk_sort)) return rc;

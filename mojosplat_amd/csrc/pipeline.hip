@@ -105,7 +105,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         // projection + tile counting share one pass over the Gaussians (k_project_hist)
         if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
                                             cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, tile_size, r0, r1,
-                                            /*tight=*/1, means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
+                                            /*tight | ranges for the band only=*/1 | 2, means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
                                             ranges, info, stream))
             return rc;
         mark(1);
