@@ -11,7 +11,8 @@ total work per step is fixed).  Rank 0 prints ONE JSON line.
 
 `roofline` prices the dominant kernel (the tile rasteriser) with SURVEY.md 8(d)'s algorithmic
 bytes (40 B/intersection + 8 B/tile + 12 B/pixel) over its average duration measured with HIP
-events on the launch stream inside the timed region.  `cpu_baseline` times the scalar C oracle
+events on the launch stream inside the timed region (the two events that bracket the kernel; the
+project / bin split comes from a short untimed pass with all four stage events).  `cpu_baseline` times the scalar C oracle
 (1 core) on ONE frame of the same workload on this box's host.
 """
 import argparse
@@ -106,22 +107,31 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    # stage boundaries -> HIP events recorded by ms_render_fwd on the launch stream (torch's
-    # current stream, whose handle is what every ms_* call is given), inside the timed region
+    # In-situ kernel timing: ms_render_fwd records HIP events on the launch stream (torch's current
+    # stream, whose handle is what every ms_* call is given).  Inside the timed region only the
+    # two that bracket the dominant kernel (the rasteriser) are recorded -- every event between two
+    # kernels costs the GPU a ~6 us bubble -- and the full stage breakdown comes from a short
+    # untimed pass afterwards.
     stage_events = []
     pool = []
-    if world == 1:  # created (and recorded once, so the hipEvent_t exists) outside the timed region
-        for _ in range(args.steps):
+
+    def make_events(n):
+        out = []
+        for _ in range(n):
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             for e in evs:
-                e.record()
-            pool.append(evs)
+                e.record()   # recorded once, so the hipEvent_t exists
+            out.append(evs)
         torch.cuda.synchronize()
+        return out
+
+    if world == 1:  # created outside the timed region
+        pool = make_events(args.steps)
 
     def hook():
         evs = pool.pop()
         stage_events.append(evs)
-        return evs
+        return [None, None, evs[2], evs[3]]
 
     if world == 1:
         render_mod._STAGE_HOOK = hook
@@ -133,6 +143,20 @@ def main():
     dt = time.perf_counter() - t0
     render_mod._STAGE_HOOK = None
 
+    breakdown = []
+    if world == 1:   # untimed: all four stage boundaries
+        extra = make_events(20)
+
+        def hook_all():
+            evs = extra.pop()
+            breakdown.append(evs)
+            return evs
+        render_mod._STAGE_HOOK = hook_all
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        render_mod._STAGE_HOOK = None
+
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -142,12 +166,11 @@ def main():
 
     stage_us = {}
     if stage_events:
-        names = ("project", "bin", "raster")
-        acc = {n: [] for n in names}
-        for evs in stage_events:
-            for i, n in enumerate(names):
-                acc[n].append(evs[i].elapsed_time(evs[i + 1]) * 1e3)
-        stage_us = {k: sum(v) / len(v) for k, v in acc.items()}
+        raster = [evs[2].elapsed_time(evs[3]) * 1e3 for evs in stage_events]
+        stage_us["raster"] = sum(raster) / len(raster)          # inside the timed region
+        for i, n in enumerate(("project", "bin", "raster_untimed_pass")):
+            v = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for evs in breakdown]
+            stage_us[n] = sum(v) / len(v)
 
     out = None
     if rank == 0:

@@ -97,7 +97,8 @@ class _Frame:
             self.img = torch.empty((H, W, C), dtype=torch.float32, device=dev)
         evs = None
         if stage_events is not None:
-            evs = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
+            evs = (ctypes.c_void_p * 4)(*[None if e is None else ctypes.c_void_p(e.cuda_event)
+                                          for e in stage_events])  # entries may be None: not recorded
         self.keep = (means3d, scales, quats, op, colors, bg, vm, ws)  # keep the marshalled tensors alive
         self.head = (N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(op), _hip.ptr(colors),
                      cdt, C, _hip.ptr(vm), camera.fx, camera.fy, camera.cx, camera.cy, W, H, EPS2D, camera.near,
