@@ -124,6 +124,9 @@ int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
  * same semantics; the tile grid is derived from W, H, tile_size).  What ms_render_fwd starts a
  * frame with: the projected means / radii are not re-read and one kernel launch is saved.
  *
+ * isect_info_mirror (nullable): a DEVICE-VISIBLE address of pinned host memory (hipHostGetDevicePointer)
+ * that receives words 0..6 of the record straight from the kernel -- no copy kernel; read it after
+ * an event recorded behind this call has completed.
  * `tight` is a bit set.  Bit 1 (value 2): tile_ranges is written for the tiles of the band only
  * (for a caller whose later stages all stay inside the band).  Bit 0 (needs opacities): TIGHT binning.  gsplat.isect_tiles lists every tile of a
  * Gaussian's bounding box; ~18 % of those pairs (config 3) can never blend because the
@@ -151,7 +154,7 @@ int ms_project_isect_count(int64_t N, const float *means3d, const float *scales,
                            int row_end, int tight, float *means2d, float *conics, float *depths,
                            int32_t *radii,
                            void *workspace, size_t workspace_bytes, int32_t *tile_ranges,
-                           int64_t *isect_info, void *stream);
+                           int64_t *isect_info, int64_t *isect_info_mirror, void *stream);
 
 /* gsplat.isect_offset_encode: from SORTED keys (tile<<32|depth_bits) to per-tile start
  * offsets i32[tile_h*tile_w] (empty tiles inherit the next start; trailing tiles get M). */

@@ -35,7 +35,7 @@ _SIGNATURES = {
     "ms_project_isect_count": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                        c_float, c_float, c_float, c_int, c_int, c_float, c_float, c_float,
                                        c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ms_isect_offset_encode": (c_int, [c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ms_rasterize_to_pixels_3dgs_fwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                                 c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
                                                           const uint32_t *__restrict__ wg_on_grid, int G,
                                                           int32_t *__restrict__ redo_flag,
                                                           int32_t *__restrict__ redo_count,
-                                                          int band_only, int64_t *__restrict__ info) {
+                                                          int band_only, int64_t *__restrict__ info,
+                                                          int64_t *__restrict__ info_mirror) {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
     const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
@@ -365,6 +366,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
         *redo_count = 0;
         info[6] = (int64_t)s_on_grid;  // Gaussians whose tile box touches the FULL grid (band-independent)
         info[7] = 0;
+        if (info_mirror) {
+            // a second copy straight into the caller's pinned host memory (zero-copy store): saves the
+            // copy kernel and the two pipeline bubbles around it; visible to the host once an event
+            // recorded after this kernel has completed.  Word 7 belongs to the host side.
+#pragma unroll
+            for (int k = 0; k < 7; ++k) info_mirror[k] = info[k];
+            __threadfence_system();
+        }
     }
 }
 
@@ -874,7 +883,7 @@ namespace {
 // per-tile prefix over the partial histograms -> tile_ranges, M, work lists
 int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t *count, int32_t *medium,
                int32_t *large, int32_t *xl, const uint32_t *wg_on_grid, int n_wg, int32_t *tile_ranges,
-               int64_t *isect_info, int band_only, hipStream_t stream) {
+               int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream) {
     if (p.T_local > 0) {
         hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
                            p.G, p.T_local, hist, count);
@@ -882,7 +891,7 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
     }
     hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium, large, xl,
                        wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count),
-                       band_only, isect_info);
+                       band_only, isect_info, info_mirror);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -947,7 +956,7 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
-                      /*band_only=*/0, stream);
+                      /*band_only=*/0, nullptr, stream);
 }
 
 // Projection + tile counting in one pass over the Gaussians (what a frame starts with): the
@@ -960,7 +969,8 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
                                       int row_begin, int row_end, int tight, float *means2d, float *conics,
                                       float *depths,
                                       int32_t *radii, void *workspace, size_t workspace_bytes,
-                                      int32_t *tile_ranges, int64_t *isect_info, void *stream_) {
+                                      int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
+                                      void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && fx != 0.f && fy != 0.f, MS_ERR_INVALID_ARG,
                "project_isect_count: bad sizes / camera");
@@ -996,7 +1006,7 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
-                      (tight & 2) ? 1 : 0, stream);
+                      (tight & 2) ? 1 : 0, isect_info_mirror, stream);
 }
 
 namespace {

@@ -103,16 +103,24 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);
         // projection + tile counting share one pass over the Gaussians (k_project_hist)
-        if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
-                                            cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, tile_size, r0, r1,
-                                            /*tight | ranges for the band only=*/1 | 2, means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
-                                            ranges, info, stream))
-            return rc;
-        mark(1);
         int64_t prev[8];  // the previous frame's record: a hint for what this frame will need
         for (int k = 0; k < 8; ++k) prev[k] = host_info[k];
+        // the size record reaches the host by a zero-copy store from the scan kernel when host_info
+        // is mapped pinned memory (what the header asks for); else by a copy
+        void *mirror = nullptr;
+        if (hipHostGetDevicePointer(&mirror, host_info, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            mirror = nullptr;
+        }
+        if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
+                                            cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, tile_size, r0, r1,
+                                            /*tight | ranges for the band only=*/1 | 2, means2d, conics, depths,
+                                            radii, ws + L.off_isect, L.isect_bytes, ranges, info,
+                                            (int64_t *)mirror, stream))
+            return rc;
+        mark(1);
         host_info[7] = 0;
-        MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        if (!mirror) MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         if (sync_event) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
         // sized by an earlier frame), enqueue emit + rasterise against that capacity NOW and only
