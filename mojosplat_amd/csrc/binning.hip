@@ -998,14 +998,15 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
     unsigned long long *masks = ((tight & 1) && opacities) ? (unsigned long long *)(ws + p.off_mask) : nullptr;
     const ms::ProjParams P = ms::make_proj_params(fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, radius_clip,
                                                   scales_are_log, opacities != nullptr);
-    if (N > 0) {
+    {   // also for N == 0 (one workgroup that walks nothing): the histogram row and the on-grid slot the
+        // scans read must exist
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(k_project_hist)) return rc;
         hipLaunchKernelGGL(k_project_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
                            quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks);
         MS_LAUNCH_CHECK();
     }
-    return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, N > 0 ? p.G : 0, tile_ranges, isect_info,
+    return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
                       (tight & 2) ? 1 : 0, isect_info_mirror, stream);
 }
 

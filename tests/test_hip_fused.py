@@ -191,3 +191,39 @@ def test_fused_path_fuzz_against_stagewise(device, seed):
                                   background_color=bg, tile_size=ts, backend="hip")
         assert torch.equal(got, want), (N, W, H, ell, ts)
     _fused._state.clear()
+
+
+def test_fused_path_edge_cases(device):
+    """Empty input, a single screen-filling Gaussian (its box exceeds the 64-tile reach mask and is
+    walked by whole waves), 1 / 4 / 8 colour channels (lazy sorting only exists for <= 4),
+    non-contiguous and strided inputs, fp16 colours -- fused path == per-stage path."""
+    bg3 = torch.tensor(BACKGROUND_V1, device=device)
+    sc, cam = randscene_v1(3000, 320, 200, ell=-2.5, seed=31, device=device)
+    # N = 0 -> zeros image like the reference (render.py:73-76)
+    z = ms.render_gaussians(sc["means3d"][:0], sc["scales"][:0], sc["quats"][:0], sc["opacities"][:0],
+                            sc["features"][:0], cam, background_color=bg3, backend="hip")
+    assert z.shape == (200, 320, 3) and (z == 0).all()
+    # one Gaussian covering the whole image, plus the cloud behind it
+    big = dict(means3d=torch.cat([torch.tensor([[0.0, 0.0, 2.0]], device=device), sc["means3d"]]),
+               scales=torch.cat([torch.full((1, 3), 1.0, device=device), sc["scales"]]),
+               quats=torch.cat([torch.tensor([[1.0, 0, 0, 0]], device=device), sc["quats"]]),
+               opacities=torch.cat([torch.tensor([0.3], device=device), sc["opacities"]]),
+               features=torch.cat([torch.tensor([[0.9, 0.1, 0.2]], device=device), sc["features"]]))
+    a = ms.render_gaussians(big["means3d"], big["scales"], big["quats"], big["opacities"], big["features"], cam,
+                            background_color=bg3, backend="hip")
+    assert torch.equal(a, stagewise(big, cam, bg3, 16))
+    # channel counts
+    for C in (1, 4, 8):
+        scC = dict(sc, features=torch.rand(3000, C, generator=torch.Generator().manual_seed(C)).to(device))
+        bgC = torch.linspace(0.1, 0.6, C, device=device)
+        a = ms.render_gaussians(scC["means3d"], scC["scales"], scC["quats"], scC["opacities"], scC["features"], cam,
+                                background_color=bgC, backend="hip")
+        assert a.shape == (200, 320, C) and torch.equal(a, stagewise(scC, cam, bgC, 16))
+    # strided views of bigger tensors
+    pad = {k: torch.cat([v, v], dim=-1) if v.dim() > 1 else torch.stack([v, v], 1) for k, v in sc.items()}
+    view = dict(means3d=pad["means3d"][:, :3], scales=pad["scales"][:, 3:], quats=pad["quats"][:, 4:],
+                opacities=pad["opacities"][:, 1], features=pad["features"][:, :3])
+    assert not view["means3d"].is_contiguous()
+    assert torch.equal(ms.render_gaussians(view["means3d"], view["scales"], view["quats"], view["opacities"],
+                                           view["features"], cam, background_color=bg3, backend="hip"),
+                       stagewise(sc, cam, bg3, 16))
