@@ -128,7 +128,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         // clamps to `cap`, so an overflowing frame writes nothing out of bounds; it is detected
         // in the finishing half and redone on the exact path.
         const int64_t cap = isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0;
-        if (sync_event && isect_buf && cap > 0) {
+        if (sync_event && isect_buf && cap > 0 && N > 0) {   // (an empty set has null inputs: exact path, M = 0)
             const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
             uint64_t *keys = (uint64_t *)isect_buf;
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));

@@ -169,3 +169,32 @@ def test_fused_differentiable_frame_equals_stagewise(device, N, W, H, ell):
     assert (img == 0).all()
     img.sum().backward()
     assert all((l.grad == 0).all() for l in leaves)
+
+
+def test_differentiable_frame_edge_cases(device):
+    """N = 0 and a single Gaussian through the differentiable frame; 4-channel colours."""
+    sc, cam = randscene_v1(50, 96, 64, ell=-2.0, seed=2, device=device)
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    empty = [sc[k][:0].clone().requires_grad_(True) for k in names]
+    img = render_gaussians_trainable(*empty, cam, background_color=torch.tensor([0.1, 0.2, 0.3], device=device))
+    assert img.shape == (64, 96, 3) and (img == 0).all()
+    img.sum().backward()
+    assert all(l.grad is not None and l.grad.numel() == 0 for l in empty)
+    one = [sc[k][:1].clone().requires_grad_(True) for k in names]
+    with torch.no_grad():
+        one[0][0] = torch.tensor([0.0, 0.0, 0.0], device=device)   # in front of the camera (which sits at z = 5)
+    img = render_gaussians_trainable(*one, cam)
+    img.sum().backward()
+    assert torch.isfinite(one[0].grad).all() and one[4].grad.abs().sum() > 0
+    # four channels, fused vs stage-wise
+    feats = torch.rand(50, 4, generator=torch.Generator().manual_seed(3)).to(device)
+    res = []
+    for stagewise in (False, True):
+        leaves = [sc[k].clone().requires_grad_(True) for k in names[:4]] + [feats.clone().requires_grad_(True)]
+        out = render_gaussians_trainable(*leaves, cam, background_color=torch.rand(4).to(device) * 0 + 0.2,
+                                         stagewise=stagewise)
+        out.square().sum().backward()
+        res.append((out.detach(), [l.grad for l in leaves]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert_grad_close("grad", a, b, rel=1e-4)
