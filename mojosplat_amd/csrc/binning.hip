@@ -633,10 +633,13 @@ __global__ __launch_bounds__(1024, (E <= 8 ? 8 : 4)) void k_tile_sort_list(const
 // instead of a full sort; tiles of any length, no merge scratch, no host knowledge of sizes.
 constexpr int kFrontK = 1024;
 constexpr int kFrontCap = 4096;   // LDS room for selected keys (32 KB)
-constexpr int kFrontNB = 2048;
+constexpr int kFrontThreads = 512;           // more workgroups in flight than with 1024 (heavy tiles are latency bound)
+constexpr int kFrontNB = 2 * kFrontThreads;  // two buckets per thread in the scan
+constexpr int kFrontLogNB = 10;
+static_assert((1 << kFrontLogNB) == kFrontNB, "bucket count");
 constexpr size_t kFrontLds = (size_t)kFrontCap * 8 + (size_t)kFrontNB * 4 + 64 * 4 + 16;
 
-__global__ __launch_bounds__(1024) void k_tile_front(const int32_t *__restrict__ medium,
+__global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__restrict__ medium,
                                                      const int32_t *__restrict__ large,
                                                      const int32_t *__restrict__ xl,
                                                      const int64_t *__restrict__ info_dev, int nm_host, int nl_host,
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(1024) void k_tile_front(const int32_t *__restrict__
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + kFrontCap);
     uint32_t *s_red = s_cnt + kFrontNB;          // 64 words of reduction scratch
     int *s_sel = reinterpret_cast<int *>(s_red + 64);  // [0] = b*, [1] = F
-    constexpr int THREADS = 1024, NW = 16;
+    constexpr int THREADS = kFrontThreads, NW = kFrontThreads / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nm = info_dev ? (int)info_dev[2] : nm_host, nl = info_dev ? (int)info_dev[3] : nl_host;
     const int nx = info_dev ? (int)info_dev[4] : nx_host;
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(1024) void k_tile_front(const int32_t *__restrict__
             for (int ww = 0; ww < NW; ++ww) { kmin = min(kmin, s_red[ww]); kmax = max(kmax, s_red[16 + ww]); }
             const uint32_t span = kmax - kmin;
             const int bits = span ? 32 - __clz(span) : 0;
-            shift = max(0, bits - 11);       // 2048 buckets
+            shift = max(0, bits - kFrontLogNB);
         } else {
             __syncthreads();
         }
@@ -1073,9 +1076,9 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                 int bits = 0;
                 while (bits < 32 && (span >> bits)) ++bits;
                 fixed_min = lo;
-                fixed_shift = bits > 11 ? bits - 11 : 0;
+                fixed_shift = bits > kFrontLogNB ? bits - kFrontLogNB : 0;
             }
-            hipLaunchKernelGGL(k_tile_front, dim3(grid), dim3(1024), kFrontLds, stream, medium, large, xl,
+            hipLaunchKernelGGL(k_tile_front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift);
             MS_LAUNCH_CHECK();
