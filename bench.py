@@ -58,11 +58,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
+    # Rehearsal only (the N > 1 path on a single-GPU box): MOJOSPLAT_BENCH_REHEARSE=1 puts every rank
+    # on device 0 and uses gloo, which moves device tensors; RCCL refuses two ranks on one device.
+    rehearse = os.environ.get("MOJOSPLAT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import mojosplat_amd as ms
     from mojosplat_amd import _hip, render as render_mod
@@ -145,16 +153,27 @@ def main():
         torch.cuda.synchronize()
         return out
 
-    if world == 1:  # created outside the timed region
-        pool = make_events(args.steps)
+    pool = make_events(args.steps)   # created outside the timed region
+
+    # N > 1: this rank's band of the frame (for its share of the algorithmic bytes)
+    band_stats = None
+    if world > 1:
+        from mojosplat_amd.binning import bin_gaussians_to_tiles_hip
+        from mojosplat_amd.distributed import band_plan
+        th_, tw_ = -(-H // 16), -(-W // 16)
+        _, bands_ = band_plan(th_, world)
+        r0_, r1_ = bands_[rank]
+        m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+        ids_b, _ = bin_gaussians_to_tiles_hip(m2, rad, dep, 16, tw_, th_, row_range=(r0_, r1_))
+        band_stats = dict(M=int(ids_b.numel()), T=(r1_ - r0_) * tw_, px=(min(r1_ * 16, H) - min(r0_ * 16, H)) * W)
+        del m2, con, dep, rad, ids_b
 
     def hook():
         evs = pool.pop()
         stage_events.append(evs)
         return [None, None, evs[2], evs[3]]
 
-    if world == 1:
-        render_mod._STAGE_HOOK = hook
+    render_mod._STAGE_HOOK = hook   # (N > 1: the sharded entry point consults the same hook)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -188,22 +207,26 @@ def main():
     if stage_events:
         raster = [evs[2].elapsed_time(evs[3]) * 1e3 for evs in stage_events]
         stage_us["raster"] = sum(raster) / len(raster)          # inside the timed region
-        for i, n in enumerate(("project", "bin", "raster_untimed_pass")):
-            v = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for evs in breakdown]
-            stage_us[n] = sum(v) / len(v)
+        if breakdown:
+            for i, n in enumerate(("project", "bin", "raster_untimed_pass")):
+                v = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for evs in breakdown]
+                stage_us[n] = sum(v) / len(v)
 
     out = None
     if rank == 0:
         b_raster = (40 - (6 if fp16 else 0)) * M + 8 * T + 12 * H * W
+        if band_stats is not None:   # N > 1: the kernel timed is rank 0's band
+            b_raster = (40 - (6 if fp16 else 0)) * band_stats["M"] + 8 * band_stats["T"] + 12 * band_stats["px"]
         b_frame = 96 * N + (84 - (6 if fp16 else 0)) * M + 12 * T + 12 * H * W
         roofline = None
         if "raster" in stage_us:
             ach = b_raster / (stage_us["raster"] * 1e-6) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and world == 1:   # measured on the whole frame
                 traffic = json.load(open(tpath)).get(args.workload, {}).get("rasterize_fwd_bytes")
-            roofline = {"bound": "hbm", "kernel": "k_rasterize_fwd", "achieved": round(ach, 1),
+            roofline = {"bound": "hbm", "kernel": "k_rasterize_fwd" + ("" if world == 1 else " (rank 0's band)"),
+                        "achieved": round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "algorithmic_bytes": b_raster,
                         "avg_kernel_us": round(stage_us["raster"], 1),
@@ -231,7 +254,8 @@ def main():
             "metric": "frames/sec at 1M Gaussians 1920x1080 fwd; achieved HBM GB/s vs peak",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearse else ""),
             "config": {"workload": f"{args.workload}: randscene-v1 N={N} {W}x{H} ell={ell} seed=42 forward",
                        "gaussians": N, "intersections": M, "tiles": T, "tile_size": 16,
                        "colour_dtype": "f16" if fp16 else "f32",

@@ -198,7 +198,7 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
 
 
 def render_begin_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                     row_range=None, out=None, lane=0, stream=None):
+                     row_range=None, out=None, lane=0, stream=None, stage_events=None):
     """Enqueue a frame on the current stream (or on the raw hipStream_t handle `stream`; scratch
     that a redo has to grow is then allocated on the current stream and must only be used by
     streams the caller orders after it) WITHOUT waiting for its size record; -> a frame
@@ -206,7 +206,7 @@ def render_begin_hip(means3d, scales, quats, opacities, colors, camera, backgrou
     frame (on another lane) before finishing this one, which hides the count -> host -> emit
     hand-off latency entirely."""
     return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                  None, row_range, out, lane, stream).begin()
+                  stage_events, row_range, out, lane, stream).begin()
 
 
 @torch.no_grad()

@@ -174,8 +174,11 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     s = lanes[lane]
     s.wait_stream(cur)  # inputs (and whatever the caller enqueued before) are ready
     full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
+    from . import render as _render   # bench.py's in-situ kernel timing hook (None otherwise)
+    evs = _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None
     frame = render_begin_hip(means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                             row_range=_band_of(bands[rank], th), out=full, lane=1 + lane, stream=s.cuda_stream)
+                             row_range=_band_of(bands[rank], th), out=full, lane=1 + lane, stream=s.cuda_stream,
+                             stage_events=evs)
     for t in (means3d, scales, quats, opacities, features, bg, full):
         t.record_stream(s)
 
