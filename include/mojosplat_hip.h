@@ -183,7 +183,8 @@ int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float *means2d,
  *   in : forward inputs + render_alphas, last_ids from the forward,
  *        v_render_colors f32[H,W,CDIM], v_render_alphas f32[H,W] or NULL.
  *   out: v_means2d f32[N,2], v_conics f32[N,3], v_colors f32[N,CDIM], v_opacities f32[N];
- *        ACCUMULATED INTO (caller zero-fills).                                           */
+ *        ACCUMULATED INTO (caller zero-fills, gsplat's convention) when overwrite == 0;
+ *        OVERWRITTEN (no zero-fill needed) when overwrite != 0.                            */
 int ms_rasterize_to_pixels_3dgs_bwd(int64_t N, int64_t M, const float *means2d,
                                     const float *conics, const float *colors, int CDIM,
                                     const float *opacities, const float *backgrounds, int W,
@@ -192,7 +193,8 @@ int ms_rasterize_to_pixels_3dgs_bwd(int64_t N, int64_t M, const float *means2d,
                                     const int32_t *last_ids, const float *v_render_colors,
                                     const float *v_render_alphas, float *v_means2d,
                                     float *v_conics, float *v_colors, float *v_opacities,
-                                    void *workspace, size_t workspace_bytes, void *stream);
+                                    void *workspace, size_t workspace_bytes, int overwrite,
+                                    void *stream);
 /* scratch for the packed-gradient path of the backward rasteriser (0 = not needed / not used:
  * without it, or for CDIM > 4, the call still works through the one-atomic-per-component path) */
 size_t ms_rasterize_bwd_workspace_bytes(int64_t N, int CDIM);

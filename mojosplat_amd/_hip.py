@@ -45,7 +45,7 @@ _SIGNATURES = {
                                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                c_size_t, c_void_p]),
+                                                c_size_t, c_int, c_void_p]),
     "ms_rasterize_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ms_render_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "ms_render_isect_bytes": (c_size_t, [c_int64, c_int]),

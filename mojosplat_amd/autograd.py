@@ -76,7 +76,7 @@ class _RasterizeHip(torch.autograd.Function):
         N, C = colors.shape
         dev = means2d.device
         v_img = _hip.f32c(v_img)
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # overwritten by the library
         v_means2d, v_conics, v_colors, v_opac = z(N, 2), z(N, 3), z(N, C), z(N)
         ws_bytes = L.ms_rasterize_bwd_workspace_bytes(N, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
@@ -85,7 +85,7 @@ class _RasterizeHip(torch.autograd.Function):
                 N, ids.numel(), _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(colors), C,
                 _hip.ptr(opacities), _hip.ptr(bg), cam.W, cam.H, ts, _hip.ptr(ranges), _hip.ptr(ids),
                 _hip.ptr(alphas), _hip.ptr(last), _hip.ptr(v_img), None, _hip.ptr(v_means2d),
-                _hip.ptr(v_conics), _hip.ptr(v_colors), _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes,
+                _hip.ptr(v_conics), _hip.ptr(v_colors), _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes, 1,
                 _hip.stream(dev)), "ms_rasterize_to_pixels_3dgs_bwd")
         v_bg = None
         if bg is not None and ctx.needs_input_grad[4]:
@@ -128,7 +128,7 @@ class _RenderFusedHip(torch.autograd.Function):
         N, C = col.shape
         dev = m3.device
         v_img = _hip.f32c(v_img)
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # overwritten by the library
         v_means2d, v_conics, v_colors, v_opac = z(N, 2), z(N, 3), z(N, C), z(N)
         ws_bytes = L.ms_rasterize_bwd_workspace_bytes(N, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
@@ -142,7 +142,7 @@ class _RenderFusedHip(torch.autograd.Function):
                 N, ids.numel(), _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(col), C, _hip.ptr(op), _hip.ptr(bg),
                 cam.W, cam.H, ts, _hip.ptr(ranges), _hip.ptr(ids), _hip.ptr(alphas), _hip.ptr(last),
                 _hip.ptr(v_img), None, _hip.ptr(v_means2d), _hip.ptr(v_conics), _hip.ptr(v_colors),
-                _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes, st), "ms_rasterize_to_pixels_3dgs_bwd")
+                _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes, 1, st), "ms_rasterize_to_pixels_3dgs_bwd")
             _hip.check(L.ms_project_gaussians_bwd(
                 N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(vm), cam.fx, cam.fy, cam.cx, cam.cy,
                 cam.W, cam.H, EPS2D, _hip.ptr(radii), _hip.ptr(v_means2d), _hip.ptr(v_conics), None,

@@ -429,6 +429,7 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
     }
 }
 
+template <bool OVERWRITE>
 __global__ __launch_bounds__(256) void k_unpack_grads(int64_t N, int cdim, const float *__restrict__ packed,
                                                       float *__restrict__ v_means2d, float *__restrict__ v_conics,
                                                       float *__restrict__ v_colors, float *__restrict__ v_opacities) {
@@ -436,14 +437,15 @@ __global__ __launch_bounds__(256) void k_unpack_grads(int64_t N, int cdim, const
     if (i >= N) return;
     const float4 *row = reinterpret_cast<const float4 *>(packed + i * kRow);
     const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-    v_means2d[2 * i] += r0.x;
-    v_means2d[2 * i + 1] += r0.y;
-    v_conics[3 * i] += r0.z;
-    v_conics[3 * i + 1] += r0.w;
-    v_conics[3 * i + 2] += r1.x;
-    v_opacities[i] += r1.y;
+    auto put = [](float &dst, float v) { if (OVERWRITE) dst = v; else dst += v; };
+    put(v_means2d[2 * i], r0.x);
+    put(v_means2d[2 * i + 1], r0.y);
+    put(v_conics[3 * i], r0.z);
+    put(v_conics[3 * i + 1], r0.w);
+    put(v_conics[3 * i + 2], r1.x);
+    put(v_opacities[i], r1.y);
     const float c[4] = {r1.z, r1.w, r2.x, r2.y};
-    for (int k = 0; k < cdim && k < 4; ++k) v_colors[i * cdim + k] += c[k];
+    for (int k = 0; k < cdim && k < 4; ++k) put(v_colors[i * cdim + k], c[k]);
 }
 
 }  // namespace
@@ -454,11 +456,23 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     const int32_t *tile_ranges, const int32_t *flatten_ids, const float *render_alphas,
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *workspace,
-    size_t workspace_bytes, void *stream) {
+    size_t workspace_bytes, int overwrite, void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_bwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_bwd: CDIM %d not in 1..32", CDIM);
-    if (M == 0 || N == 0) return MS_OK;
+    if (N == 0) return MS_OK;
+    const bool packed_path = CDIM <= 4 && workspace && workspace_bytes >= (size_t)N * kRow * sizeof(float) &&
+                             N <= 0x7fffffffll && M > 0;
+    if (overwrite && !packed_path) {
+        // the packed path overwrites in its unpack kernel; everywhere else "overwrite" = zero-fill, then add
+        MS_REQUIRE(v_means2d && v_conics && v_colors && v_opacities, MS_ERR_INVALID_ARG, "rasterize_bwd: null output");
+        hipStream_t s0 = (hipStream_t)stream;
+        MS_HIP(hipMemsetAsync(v_means2d, 0, (size_t)N * 2 * sizeof(float), s0));
+        MS_HIP(hipMemsetAsync(v_conics, 0, (size_t)N * 3 * sizeof(float), s0));
+        MS_HIP(hipMemsetAsync(v_colors, 0, (size_t)N * CDIM * sizeof(float), s0));
+        MS_HIP(hipMemsetAsync(v_opacities, 0, (size_t)N * sizeof(float), s0));
+    }
+    if (M == 0) return MS_OK;
     MS_REQUIRE(means2d && conics && colors && opacities && tile_ranges && flatten_ids && render_alphas &&
                    last_ids && v_render_colors && v_means2d && v_conics && v_colors && v_opacities,
                MS_ERR_INVALID_ARG, "rasterize_bwd: null pointer");
@@ -480,7 +494,7 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
     const size_t packed_bytes = (size_t)N * kRow * sizeof(float);
-    if (CDIM <= 4 && workspace && workspace_bytes >= packed_bytes && N <= 0x7fffffffll) {
+    if (packed_path) {
         // v2: packed 64-byte gradient rows (contiguous float atomics), then unpack
         RasterBwd2Args B2;
         B2.a = A;
@@ -491,8 +505,12 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
         if (CDIM <= 3) hipLaunchKernelGGL(k_rasterize_bwd_v2<3>, grid, dim3(64), 0, st, B2);
         else hipLaunchKernelGGL(k_rasterize_bwd_v2<4>, grid, dim3(64), 0, st, B2);
         MS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_unpack_grads, dim3((unsigned)ms::ceil_div(N, 256)), dim3(256), 0, st, N, CDIM,
-                           (const float *)workspace, v_means2d, v_conics, v_colors, v_opacities);
+        if (overwrite)
+            hipLaunchKernelGGL(k_unpack_grads<true>, dim3((unsigned)ms::ceil_div(N, 256)), dim3(256), 0, st, N, CDIM,
+                               (const float *)workspace, v_means2d, v_conics, v_colors, v_opacities);
+        else
+            hipLaunchKernelGGL(k_unpack_grads<false>, dim3((unsigned)ms::ceil_div(N, 256)), dim3(256), 0, st, N, CDIM,
+                               (const float *)workspace, v_means2d, v_conics, v_colors, v_opacities);
         MS_LAUNCH_CHECK();
         return MS_OK;
     }
