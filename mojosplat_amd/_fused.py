@@ -147,8 +147,15 @@ class _Frame:
         # (the library's default for plain forward frames of <= 4 channels) have no such tiles.
         # a scene whose lazily sorted fronts keep failing (the clean-up pass is slow by design) goes
         # back to full sorts: host[5] = tiles the previous frame on this lane had to redo
+        # (the count lives in the lane's workspace, whose layout follows N and the tile grid: it only
+        # means something when the previous frame had the same shape, and a new shape starts afresh)
         heavy = int(host[2]) + int(host[3]) + int(host[4])
-        if rc == 0 and not self.own and not (int(host[7]) & 4) and int(host[5]) > max(3, heavy // 4):
+        same_shape = st.get("shape") == self.grid
+        if not self.own:
+            if not same_shape:
+                st["full_sort"] = False
+            st["shape"] = self.grid
+        if rc == 0 and not self.own and same_shape and not (int(host[7]) & 4) and int(host[5]) > max(3, heavy // 4):
             st["full_sort"] = True
         lazy = LAZY_SORT and not self.own and self.head[8] <= 4 and not st.get("full_sort")
         st["speculate"] = lazy or int(host[4]) == 0

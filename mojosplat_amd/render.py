@@ -28,6 +28,51 @@ TILE_SIZE = 16
 _STAGE_HOOK = None
 
 
+# ---- binning granularity -------------------------------------------------------------------------
+# The frame does not depend on the tile size: a pixel blends the same Gaussians in the same order
+# whatever grid they were binned on, and the rasteriser works in 16x16 blocks inside any tile
+# (measured bit-identical for 16 / 32 / 64 px at every BASELINE config).  What the tile size moves
+# is cost: coarser bins mean fewer (Gaussian, tile) pairs to scatter and sort (config 5: 38 M at
+# 16 px, 9.9 M at 64 px) but every block then stages a longer, less relevant list.  Dense scenes win
+# big from coarse bins (config 5: 1.62 -> 0.74 ms at 64 px, config 4: 0.85 -> 0.62 ms at 32 px), sparse
+# ones lose (config 3: 0.29 -> 0.72 ms at 32 px).  So: the first frame of a scene (same N and image
+# size) is binned on the caller's tile size; its intersections per tile decide the rest.
+_BIN_CHOICE = {}            # (device, N, W, H, tile_size) -> bin size for the following frames
+_DENSE_PER_TILE = 800       # (tight) intersections per 16-px tile from which coarse bins pay
+_MANY_TILES = 16384         # grids this large have the parallelism to absorb 64-px bins
+
+
+_REPROBE_EVERY = 256        # a scene drifts (camera moves): one frame in 256 is binned at 16 px again
+
+
+def _bin_size(means3d, camera, tile_size):
+    if tile_size != TILE_SIZE:
+        return tile_size    # an explicit non-default tile size is honoured as given
+    key = (means3d.device, means3d.shape[0], camera.W, camera.H, tile_size)
+    entry = _BIN_CHOICE.get(key)
+    if entry is None:
+        return tile_size
+    entry[1] += 1
+    if entry[1] % _REPROBE_EVERY == 0:
+        return tile_size
+    return entry[0]
+
+
+def _note_density(means3d, camera, tile_size, bin_size, m):
+    if tile_size != TILE_SIZE or bin_size != tile_size:
+        return              # only frames binned at the default size are evidence
+    tiles = (-(-camera.H // tile_size)) * (-(-camera.W // tile_size))
+    choice = tile_size
+    if m >= _DENSE_PER_TILE * tiles:
+        choice = 64 if tiles >= _MANY_TILES else 32
+    key = (means3d.device, means3d.shape[0], camera.W, camera.H, tile_size)
+    entry = _BIN_CHOICE.get(key)
+    if entry is None:
+        _BIN_CHOICE[key] = [choice, 0]
+    else:
+        entry[0] = choice
+
+
 @torch.no_grad()
 def render_gaussians(
     means3d: torch.Tensor,    # (N, 3) world coordinates
@@ -74,10 +119,12 @@ def render_gaussians(
         if sh_degree is not None and features.shape[-1] > 3:
             colors, bg = features[..., :3], bg[:3]  # the reference's placeholder (render.py:82-87)
         evs = _STAGE_HOOK() if _STAGE_HOOK is not None else None
-        bands = lds_row_bands(camera.H, camera.W, tile_size)
+        bin_size = _bin_size(means3d, camera, tile_size)
+        bands = lds_row_bands(camera.H, camera.W, bin_size)
         if len(bands) == 1:
-            img, _ = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
+            img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, bin_size,
                                     stage_events=evs)
+            _note_density(means3d, camera, tile_size, bin_size, m)
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer

@@ -250,3 +250,36 @@ def test_sharded_rehearsal_assembles_the_frame(device, world):
         assert torch.equal(ia[y0:y1], ib[y0:y1])
         out[y0:y1] = ia[y0:y1]
     assert torch.equal(out, ref)
+
+
+def test_frame_does_not_depend_on_the_binning_granularity(device):
+    """A pixel blends the same Gaussians in the same order whatever tile grid they were binned on, so
+    16 / 32 / 64-px bins (the rasteriser works in 16x16 blocks inside any tile) give the same frame bit
+    for bit -- which is what lets render_gaussians pick coarse bins for dense scenes on its own."""
+    from mojosplat_amd import render as R
+    sc, cam = randscene_v1(60_000, 512, 384, ell=-2.6, seed=41, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    ref = stagewise(sc, cam, bg, 16)
+    for ts in (16, 32, 64):
+        _fused._state.clear()
+        for _ in range(2):
+            assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, tile_size=ts, backend="hip"), ref), ts
+    # the automatic choice: dense -> coarse bins from the second frame on, same pixels
+    _fused._state.clear()
+    R._BIN_CHOICE.clear()
+    old = R._DENSE_PER_TILE
+    try:
+        R._DENSE_PER_TILE = 10          # make this small scene count as dense
+        a = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+        assert list(R._BIN_CHOICE.values())[0][0] == 32
+        b = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+        R._DENSE_PER_TILE = 10 ** 9     # sparse: stays on the caller's tile size
+        R._BIN_CHOICE.clear()
+        ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+        assert list(R._BIN_CHOICE.values())[0][0] == 16
+    finally:
+        R._DENSE_PER_TILE = old
+        R._BIN_CHOICE.clear()
+        _fused._state.clear()
