@@ -647,7 +647,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
                                                      const uint64_t *__restrict__ keys,
                                                      int32_t *__restrict__ flatten_ids,
                                                      int32_t *__restrict__ front_count, int64_t cap,
-                                                     uint32_t fixed_min, int fixed_shift) {
+                                                     uint32_t fixed_min, int fixed_shift, int front_k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem_dyn);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + kFrontCap);
@@ -719,11 +719,13 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
         // b* = the bucket whose inclusive prefix first reaches kFrontK (n > kFrontK, so it exists);
         // if that would overflow the LDS room, stop one bucket earlier (possibly with nothing:
         // >= kFrontCap entries at one depth -- the clean-up kernel takes such a tile)
-        if (c0 && e0 < (uint32_t)kFrontK && e1 >= (uint32_t)kFrontK) {
+        // (front_k: kFrontK per 16x16 block of the tile; a tile shorter than that is selected whole)
+        const uint32_t want = min((uint32_t)front_k, (uint32_t)n);
+        if (c0 && e0 < want && e1 >= want) {
             if (e1 <= (uint32_t)kFrontCap) { s_sel[0] = 2 * tid; s_sel[1] = (int)e1; }
             else { s_sel[0] = 2 * tid - 1; s_sel[1] = (int)e0; }
         }
-        if (c1 && e1 < (uint32_t)kFrontK && i1 >= (uint32_t)kFrontK) {
+        if (c1 && e1 < want && i1 >= want) {
             if (i1 <= (uint32_t)kFrontCap) { s_sel[0] = 2 * tid + 1; s_sel[1] = (int)i1; }
             else { s_sel[0] = 2 * tid; s_sel[1] = (int)e1; }
         }
@@ -1078,9 +1080,13 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                 fixed_min = lo;
                 fixed_shift = bits > kFrontLogNB ? bits - kFrontLogNB : 0;
             }
+            // a tile of (tile_size/16)^2 blocks needs that many times the front of one block (up to the LDS room)
+            const int blocks_per_tile = ((tile_size + 15) / 16) * ((tile_size + 15) / 16);
+            const int front_k = min(kFrontK * blocks_per_tile, kFrontCap - 1024);
             hipLaunchKernelGGL(k_tile_front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
-                               sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift);
+                               sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift,
+                               front_k);
             MS_LAUNCH_CHECK();
         }
         if (p.T_local > 0)
