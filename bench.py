@@ -32,6 +32,7 @@ WORKLOADS = {
     # name: (N, W, H, ell, fp16 colours)
     "cfg2": (100_000, 1920, 1080, -4.0, False),
     "cfg3": (1_000_000, 1920, 1080, -4.0, False),
+    "cfg2-heavy": (100_000, 1920, 1080, -3.0, False),
     "cfg3-heavy": (1_000_000, 1920, 1080, -3.0, False),
     "cfg4": (6_000_000, 1600, 1063, -4.0, True),
     "cfg5": (5_000_000, 3840, 2160, -4.0, False),

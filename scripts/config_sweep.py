@@ -21,6 +21,7 @@ from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1  # noqa: E402
 CFG = {
     "cfg2": (100_000, 1920, 1080, -4.0, False),
     "cfg3": (1_000_000, 1920, 1080, -4.0, False),
+    "cfg2-heavy": (100_000, 1920, 1080, -3.0, False),   # the reference benchmark's scale
     "cfg3-heavy": (1_000_000, 1920, 1080, -3.0, False),
     "cfg4": (6_000_000, 1600, 1063, -4.0, True),
     "cfg5": (5_000_000, 3840, 2160, -4.0, False),
@@ -39,7 +40,7 @@ def timed(fn, iters=10, warm=2):
 
 
 def main():
-    names = sys.argv[1:] or ["cfg2", "cfg3", "cfg3-bwd", "cfg4", "cfg5"]
+    names = sys.argv[1:] or ["cfg2", "cfg3", "cfg3-bwd", "cfg4", "cfg5", "cfg2-heavy", "cfg3-heavy"]
     dev = torch.device("cuda:0")
     bg = torch.tensor(BACKGROUND_V1, device=dev)
     for name in names:
