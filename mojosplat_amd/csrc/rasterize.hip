@@ -330,13 +330,13 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
 // Tiles on the redo list ran out of sorted front with pixels still alive (never seen on the
 // benchmark scenes; forced by tests with stacks of faint Gaussians and by 32-px tiles).  They are
 // redone from scratch here WITHOUT ever sorting their whole list: one 256-thread workgroup per tile
-// repeatedly (1) selects the next <= kRedoChunk smallest keys above the last one consumed -- range
+// repeatedly (1) selects the next ~kRedoChunk (1024) smallest keys above the last one consumed -- range
 // of the eligible 64-bit keys, LDS histogram over 2048 order-preserving buckets, prefix, narrowing
 // into a crowded first bucket if need be (keys are distinct, so that terminates) -- (2) ranks them
 // inside their buckets, and (3) composites them, one wave per 8x8 quad and one pixel per lane, with
 // exactly the arithmetic of k_rasterize_fwd's generic loop, until every pixel is finished or the
 // list is exhausted.  Any list length, no scratch beyond LDS.  Slow and simple by design.
-constexpr int kRedoChunk = 512, kRedoCap = 1024, kRedoNB = 2048;
+constexpr int kRedoChunk = 1024, kRedoCap = 2048, kRedoNB = 2048;
 
 template <int CP, typename ColorT>
 __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
