@@ -133,6 +133,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    binning = None
+    if world == 1:
+        # render_gaussians settles its binning granularity by racing the modes over a scene's first
+        # frames (render.py, _BinTuner): let that finish before the W warm-up steps, untimed
+        for _ in range(16):
+            step()
+            tuners = list(render_mod._BIN_CHOICE.values())
+            if tuners and not tuners[0].queue:
+                binning = {"chosen_bin_px": tuners[0].choice,
+                           "race_ms": {str(k): round(v * 1e3, 4) for k, v in tuners[0].times.items()}}
+                break
     for _ in range(args.warmup):
         step()
 
@@ -258,7 +269,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearse else ""),
             "config": {"workload": f"{args.workload}: randscene-v1 N={N} {W}x{H} ell={ell} seed=42 forward",
-                       "gaussians": N, "intersections": M, "tiles": T, "tile_size": 16,
+                       "gaussians": N, "intersections": M, "tiles": T, "tile_size": 16, "binning": binning,
                        "colour_dtype": "f16" if fp16 else "f32",
                        "parallelism": "single GPU" if world == 1 else f"{world} tile-row bands + RCCL all-gather" + (", gather of frame k overlapped with render of frame k+1" if mode["async"] else " (blocking)")},
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,

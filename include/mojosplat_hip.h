@@ -266,7 +266,9 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  * rasteriser needs (see ms_rasterize_to_pixels_3dgs_fwd).
  * ------------------------------------------------------------------------------------- */
 enum { MS_RENDER_WHOLE = 0, MS_RENDER_RESUME = 1, MS_RENDER_BEGIN = 2, MS_RENDER_FINISH = 3,
-       MS_RENDER_FULL_SORT = 0x100 /* or-ed into `resume`: no lazy sorting for this frame */ };
+       MS_RENDER_FULL_SORT = 0x100, /* or-ed into `resume`: no lazy sorting for this frame */
+       MS_RENDER_FRONT_LEVEL = 0x200 /* x 0..3, or-ed into `resume`: lazily sorted fronts 2^level times as deep
+                                        (a caller whose previous frame needed the clean-up pass, host_info[5] > 0) */ };
 size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h);
 size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch);
 int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,

@@ -45,6 +45,7 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
 FULL_SORT = 0x100
+FRONT_LEVEL = 0x200  # x level (0..3): deeper lazily sorted fronts
 
 
 class _Frame:
@@ -89,6 +90,12 @@ class _Frame:
             ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
         self.ws, self.grid = ws, (N, tw, th)
         r0, r1 = (0, th) if row_range is None else row_range
+        # what the lane's sorting mode (below) was learnt on: scene size, grid and band
+        self.shape = (N, tw, th, r0, r1)
+        # sorting mode of this frame, fixed for both of its halves: lazily sorted fronts of the lane's
+        # current depth level, or full sorts once the lane has given up on them
+        self.level = int(st.get("front_level", 0))
+        self.mode = FULL_SORT if st.get("full_sort") else FRONT_LEVEL * self.level
         if out is not None:
             assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
             assert out.shape[0] >= H and tuple(out.shape[1:]) == (W, C)
@@ -109,8 +116,7 @@ class _Frame:
         self.host_ptr = ctypes.c_void_p(st["host"].data_ptr())
 
     def run(self, phase):
-        if self.st.get("full_sort"):
-            phase |= FULL_SORT
+        phase |= self.mode
         isect = self.isect if self.own else self.st["isect"]
         return self.L.ms_render_fwd(*self.head, _hip.ptr(isect), 0 if isect is None else isect.numel(),
                                     self.host_ptr, phase, *self.tail)
@@ -145,18 +151,24 @@ class _Frame:
         # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
         # on the exact path); do not speculate on the next frame of such a scene.  Lazily sorted frames
         # (the library's default for plain forward frames of <= 4 channels) have no such tiles.
-        # a scene whose lazily sorted fronts keep failing (the clean-up pass is slow by design) goes
-        # back to full sorts: host[5] = tiles the previous frame on this lane had to redo
-        # (the count lives in the lane's workspace, whose layout follows N and the tile grid: it only
-        # means something when the previous frame had the same shape, and a new shape starts afresh)
+        # Lazily sorted fronts that turn out too short are made good by a clean-up pass that is slow by
+        # design (one heavy bin costs more than lazy sorting saves on a whole frame).  host[5] = tiles the
+        # PREVIOUS frame on this lane had to redo: when that frame ran at the lane's current level, the
+        # lane moves on to fronts twice as deep, and after level 2 (or when many tiles fail at once) to
+        # full sorts.  (The count lives in the lane's workspace, whose layout follows the frame's shape: it
+        # only means something when the previous frame had the same shape, and a new shape starts afresh.)
         heavy = int(host[2]) + int(host[3]) + int(host[4])
-        same_shape = st.get("shape") == self.grid
         if not self.own:
+            same_shape = st.get("shape") == self.shape
             if not same_shape:
-                st["full_sort"] = False
-            st["shape"] = self.grid
-        if rc == 0 and not self.own and same_shape and not (int(host[7]) & 4) and int(host[5]) > max(3, heavy // 4):
-            st["full_sort"] = True
+                st["full_sort"], st["front_level"] = False, 0
+            elif (rc == 0 and not (int(host[7]) & 4) and int(host[5]) > 0 and not st.get("full_sort")
+                  and st.get("prev_level") == st.get("front_level", 0)):
+                if int(host[5]) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
+                    st["full_sort"] = True
+                else:
+                    st["front_level"] = st.get("front_level", 0) + 1
+            st["shape"], st["prev_level"] = self.shape, (self.level if not self.mode & FULL_SORT else None)
         lazy = LAZY_SORT and not self.own and self.head[8] <= 4 and not st.get("full_sort")
         st["speculate"] = lazy or int(host[4]) == 0
         if info is not None:

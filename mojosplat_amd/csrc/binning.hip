@@ -23,7 +23,6 @@
 //   k_tile_sort_list  work lists of tiles with <= 8192 (74 KB LDS, two per CU) and <= 16384
 //                     entries (136 KB); fixed-size persistent grids on sync-free frames
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
-#include <stdlib.h>
 #include <string.h>
 
 #include "project_device.hpp"
@@ -38,6 +37,11 @@ constexpr size_t kMaxLds = 160 * 1024;
 
 struct Grid {
     int ts, tw, th, row_begin, row_end;
+    // block masks (split mode of ms_render_fwd, pipeline.hip): for boxes of at most 16 tiles the reach
+    // mask is kept at HALF-tile granularity and every emitted entry carries the 4 bits of its tile's
+    // half-tile blocks next to the Gaussian index (id << 4 | blocks): the sorted lists of 32-px bins can
+    // then be split into the per-16x16-block lists the rasteriser wants, without testing anything again
+    int pack, cw, ch;   // cw x ch: the half-tile (block) grid of the image
 };
 
 // Tight binning: which tiles of a Gaussian's box can its alpha >= 1/255 ellipse reach at all?
@@ -115,26 +119,97 @@ __device__ __forceinline__ void count_on_grid(bool on_grid, unsigned int *s_on_g
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(s_on_grid, (unsigned int)__popcll(b));
 }
 
+// The tile box of one Gaussian for either mode.  Block-mask mode (g.pack) derives it from the gsplat box
+// on the half-tile grid -- the lists must hold exactly what 16-px tiles would -- and reports in `edges`
+// which outer half-columns / half-rows of the box lie outside that finer box (bit 0 left, 1 right, 2 top,
+// 3 bottom).
+__device__ __forceinline__ bool bin_box(float2 m, int2 r, const Grid &g, int &x0, int &x1, int &y0, int &y1,
+                                        int &edges) {
+    edges = 0;
+    if (!g.pack) return tile_bbox(m, r, g, x0, x1, y0, y1);
+    const Grid gc{g.ts >> 1, g.cw, g.ch, 0, g.ch, 0, 0, 0};
+    int cx0, cx1, cy0, cy1;
+    const bool on = tile_bbox(m, r, gc, cx0, cx1, cy0, cy1);
+    x0 = cx0 >> 1; x1 = (cx1 + 1) >> 1;
+    y0 = cy0 >> 1; y1 = (cy1 + 1) >> 1;
+    if (!on) { x1 = x0; y1 = y0; }
+    y0 = max(y0, g.row_begin);
+    y1 = min(y1, g.row_end);
+    y1 = max(y1, y0);
+    edges = (cx0 > 2 * x0 ? 1 : 0) | (cx1 < 2 * x1 ? 2 : 0) | (cy0 > 2 * y0 ? 4 : 0) | (cy1 < 2 * y1 ? 8 : 0);
+    return on;
+}
+
+// the blocks (2x2 per tile, bit = 2*dy + dx) of box tile (c, r) that lie inside the finer box
+__device__ __forceinline__ int edge_blocks(int edges, int c, int r, int w, int h) {
+    int q = 0xf;
+    if ((edges & 1) && c == 0) q &= 0xa;
+    if ((edges & 2) && c == w - 1) q &= 0x5;
+    if ((edges & 4) && r == 0) q &= 0xc;
+    if ((edges & 8) && r == h - 1) q &= 0x3;
+    return q;
+}
+
+// cell mask of a box of w x h tiles (2w x 2h cells) with the edge half-columns / half-rows removed
+__device__ __forceinline__ unsigned long long clip_cells(unsigned long long m, int edges, int w, int h) {
+    const int cwid = 2 * w, rows = 2 * h;
+    if (cwid * rows < 64) m &= (1ull << (cwid * rows)) - 1ull;
+    if (edges & 4) m &= ~((1ull << cwid) - 1ull);
+    if (edges & 8) m &= (1ull << ((rows - 1) * cwid)) - 1ull;
+    if (edges & 3) {
+        unsigned long long p = 1ull;   // bit 0 of every row
+        for (int sh = cwid; sh < 64; sh <<= 1) p |= p << sh;
+        if (edges & 1) m &= ~p;
+        if (edges & 2) m &= ~(p << (cwid - 1));
+    }
+    return m;
+}
+
 // One step of a chunk walk: every lane of the workgroup brings the tile box of ONE Gaussian
 // (index base + threadIdx.x, n = 0 if it has none); F(local_tile, gaussian_index) is called for
 // every tile of every box.  Small boxes are walked by their own lane, big ones by the whole wave.
 // Must be reached by all lanes of the wave (ballot / shuffles inside).
 template <class F>
-__device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0, int y1, int n, const Grid &g,
-                                           unsigned long long mask, F &&f) {
+__device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0, int y1, int n, int edges,
+                                           const Grid &g, unsigned long long mask, F &&f) {
     const int lane = threadIdx.x & 63;
     const int64_t i = base + threadIdx.x;
     const bool big = n > kCoopThreshold;
     if (n > 0 && !big) {
-        // only the reached tiles: the trip count is popcount(mask), not the box area
+        // only the reached tiles: the trip count is popcount, not the box area
         const int w = x1 - x0;
         const float inv_w = 1.0f / (float)w;
-        unsigned int m = (unsigned int)mask & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));   // n <= kCoopThreshold = 32
+        unsigned int m;
+        const bool cells = g.pack && n <= 16;   // `mask` is per half-tile cell (2w cells per row): fold to tiles
+        if (cells) {
+            const int cw = 2 * w, h = y1 - y0;
+            const unsigned int rowmask = cw >= 32 ? 0xffffffffu : ((1u << cw) - 1u);
+            m = 0;
+            for (int r = 0; r < h; ++r) {
+                unsigned int t = ((unsigned int)(mask >> (2 * r * cw)) | (unsigned int)(mask >> ((2 * r + 1) * cw))) & rowmask;
+                t = (t | (t >> 1)) & 0x55555555u;   // bit 2j: either cell column of tile j ...
+                t = (t | (t >> 1)) & 0x33333333u;   // ... compressed to the low w bits
+                t = (t | (t >> 2)) & 0x0f0f0f0fu;
+                t = (t | (t >> 4)) & 0x00ff00ffu;
+                t = (t | (t >> 8)) & 0x0000ffffu;
+                m |= t << (r * w);
+            }
+        } else {
+            m = (unsigned int)mask & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));   // n <= kCoopThreshold = 32
+        }
         while (m) {
             const int k = __ffs((int)m) - 1;
             m &= m - 1;
             const int r = (int)(((float)k + 0.5f) * inv_w);   // k / w, exact for k < 64
-            f((y0 + r - g.row_begin) * g.tw + x0 + (k - r * w), i);
+            const int c = k - r * w;
+            int q;
+            if (cells) {
+                const int cw = 2 * w, b00 = 2 * r * cw + 2 * c;
+                q = (int)((mask >> b00) & 3ull) | ((int)((mask >> (b00 + cw)) & 3ull) << 2);
+            } else {
+                q = edge_blocks(edges, c, r, w, y1 - y0);
+            }
+            f((y0 + r - g.row_begin) * g.tw + x0 + c, i, q);
         }
     }
     unsigned long long bigmask = __ballot(big);
@@ -145,11 +220,13 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
         const int by0 = __shfl(y0, src), by1 = __shfl(y1, src);
         const unsigned long long bm = ((unsigned long long)(unsigned)__shfl((int)(mask >> 32), src) << 32) |
                                       (unsigned)__shfl((int)(mask & 0xffffffffu), src);
+        const int be = __shfl(edges, src);
         const int64_t bi = base + (threadIdx.x & ~63) + src;
         const int w = bx1 - bx0, cnt = w * (by1 - by0);
         for (int k = lane; k < cnt; k += 64) {
-            const int y = by0 + k / w, x = bx0 + k % w;
-            if (cnt > 64 || ((bm >> k) & 1ull)) f((y - g.row_begin) * g.tw + x, bi);
+            const int r = k / w, c = k % w;
+            if (cnt > 64 || ((bm >> k) & 1ull))
+                f((by0 + r - g.row_begin) * g.tw + bx0 + c, bi, edge_blocks(be, c, r, w, by1 - by0));
         }
     }
 }
@@ -163,21 +240,21 @@ __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const flo
                                                int32_t *tiles_per_gauss, unsigned int *s_on_grid, F &&f) {
     for (int64_t base = i0; base < i1; base += kHistThreads) {
         const int64_t i = base + threadIdx.x;
-        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
         bool on_grid = false;
         unsigned long long mask = ~0ull;
         if (i < i1) {
             const int2 r = reinterpret_cast<const int2 *>(radii)[i];
             if (r.x > 0 && r.y > 0) {
                 const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
-                on_grid = tile_bbox(m, r, g, x0, x1, y0, y1);
+                on_grid = bin_box(m, r, g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
-                if (masks && n > 1) mask = masks[i];
+                if (masks && (n > 1 || g.pack)) mask = masks[i];
             }
             if (tiles_per_gauss) tiles_per_gauss[i] = n;
         }
         if (s_on_grid) count_on_grid(on_grid, s_on_grid);
-        walk_boxes(base, x0, x1, y0, y1, n, g, mask, f);
+        walk_boxes(base, x0, x1, y0, y1, n, edges, g, mask, f);
     }
 }
 
@@ -199,7 +276,7 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
     for (int64_t base = i0; base < i1; base += kHistThreads) {
         const int64_t i = base + threadIdx.x;
-        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
         bool on_grid = false;
         unsigned long long mask = ~0ull;
         if (i < i1) {
@@ -211,16 +288,20 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
             depths[i] = o.d;
             reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
             if (o.r0 > 0 && o.r1 > 0) {
-                on_grid = tile_bbox(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1);
+                on_grid = bin_box(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
                 if (masks) {
-                    mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], x0, x1, y0, y1, g.ts);
+                    if (g.pack && n <= 16 && n > 0)   // per half-tile cell (the 16x16 blocks of a 32-px bin)
+                        mask = clip_cells(reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], 2 * x0, 2 * x1,
+                                                     2 * y0, 2 * y1, g.ts >> 1), edges, x1 - x0, y1 - y0);
+                    else
+                        mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], x0, x1, y0, y1, g.ts);
                     masks[i] = mask;
                 }
             }
         }
         count_on_grid(on_grid, &s_on_grid);
-        walk_boxes(base, x0, x1, y0, y1, n, g, mask, [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
+        walk_boxes(base, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
@@ -240,7 +321,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
     for_each_isect(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid,
-                   [&](int t, int64_t) { atomicAdd(&s_cnt[t], 1u); });
+                   [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
@@ -403,9 +484,10 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
         s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect(i0, i1, means2d, radii, masks, g, nullptr, nullptr, [&](int t, int64_t i) {
+    for_each_isect(i0, i1, means2d, radii, masks, g, nullptr, nullptr, [&](int t, int64_t i, int q) {
         const uint32_t slot = atomicAdd(&s_cur[t], 1u);
-        const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
+        const uint32_t low = g.pack ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
+        const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | low;
         if ((int64_t)slot < M) keys[slot] = key;
     });
 }
@@ -445,6 +527,60 @@ __device__ __forceinline__ int next_pow2(int n) {
 constexpr int kMaxBuckets = 2048;  // bucket-array cap (8 KB of counters: two 8192-key workgroups fit a CU)
 constexpr int kBucketFallback = 512;  // a bucket this crowded (identical depths en masse) sends the tile to the bitonic path
 
+// Split frames: a bin's sorted list, still in LDS (low word of s_out[i] = id << 4 | block bits), leaves
+// as the four lists of its 16x16 blocks (ms::BlockLists).  Thread t holds entries e * THREADS + t: ballot
+// + prefix count per (round, wave, block), one wave-wide scan per block over the E * THREADS / 64 counts,
+// then every entry drops into its place.  Order is kept; nothing is tested again.
+// s_w: 260 words of scratch.  Called by every thread of the workgroup (two barriers inside).
+template <int THREADS, int E>
+__device__ __forceinline__ void emit_block_lists(const uint64_t *s_out, int F, int n, int start, int bin, int bin_w,
+                                                 const ms::BlockLists &out, uint32_t *s_w) {
+    constexpr int NW = THREADS / 64, NI = E * NW;
+    static_assert(NI <= 64 && NW >= 4, "one wave scans the counts of one block");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int base = 4 * start;
+    uint32_t word[E];
+    unsigned short rank[E][4];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * THREADS + tid;
+        word[e] = i < F ? (uint32_t)s_out[i] : 0u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned long long m = __ballot((word[e] >> b) & 1u);
+            rank[e][b] = (unsigned short)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (lane == 0) s_w[b * 64 + e * NW + w] = (uint32_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if (w < 4) {
+        const uint32_t v = lane < NI ? s_w[w * 64 + lane] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane < NI) s_w[w * 64 + lane] = incl - v;
+        if (lane == 63) s_w[256 + w] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if ((word[e] >> b) & 1u)
+                out.block_ids[base + b * n + (int)s_w[b * 64 + e * NW + w] + (int)rank[e][b]] = (int32_t)(word[e] >> 4);
+    if (tid < 4) {
+        const int by = bin / bin_w, bx = bin - by * bin_w;
+        const int x = 2 * bx + (tid & 1), y = 2 * by + (tid >> 1);
+        if (x < out.tw16 && y < out.th16)
+            reinterpret_cast<int2 *>(out.block_ranges)[y * out.tw16 + x] =
+                make_int2(base + tid * n, base + tid * n + (int)s_w[256 + tid]);
+    }
+    if (tid == 0) out.bin_more[bin] = F < n ? 1 : 0;
+}
+
 template <int THREADS, int E>
 struct SortCfg {
     static constexpr int CAP = THREADS * E;
@@ -457,7 +593,8 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
                                                  int start, int n, int tile,
                                                  int32_t *__restrict__ flatten_ids,
                                                  int64_t *__restrict__ isect_ids,
-                                                 uint64_t *__restrict__ keys_out) {
+                                                 uint64_t *__restrict__ keys_out,
+                                                 const ms::BlockLists *blocks = nullptr, int bin_w = 0) {
     using Cfg = SortCfg<THREADS, E>;
     constexpr int NW = THREADS / 64;
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem);
@@ -573,6 +710,11 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
         bitonic_sort_lds<THREADS>(s_out, P);
     }
     __syncthreads();
+    if (blocks) {   // split frame: block lists instead of the bin's own list
+        if constexpr (E * (THREADS / 64) <= 64)   // (only the small class sorts bins)
+            emit_block_lists<THREADS, E>(s_out, n, n, start, tile, bin_w, *blocks, s_cnt);
+        return;
+    }
     for (int i = tid; i < n; i += THREADS) {
         const uint64_t v = s_out[i];
         if (flatten_ids) flatten_ids[start + i] = (int32_t)(uint32_t)v;
@@ -589,12 +731,24 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restri
                                                          const uint64_t *__restrict__ keys,
                                                          int32_t *__restrict__ flatten_ids,
                                                          int64_t *__restrict__ isect_ids, int64_t cap,
-                                                         int tile_lo) {
+                                                         int tile_lo, ms::BlockLists blocks, int bin_w) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SortCfg<256, 4>::LDS];
     const int tile = tile_lo + blockIdx.x;   // the band's tiles: ranges outside it are empty (or unwritten)
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
-    if (n <= 0 || n > kSmallCap || (int64_t)start + n > cap) return;  // beyond cap: speculative overflow
-    sort_segment_lds<256, 4>(smem, keys, start, n, tile, flatten_ids, isect_ids, nullptr);
+    const bool skip = n <= 0 || (int64_t)start + n > cap;   // beyond cap: speculative overflow
+    if (blocks.block_ids && n <= kSmallCap && skip) {
+        // split frame: this kernel owns the block ranges of every bin that is not heavy -- empty ones too
+        if (threadIdx.x < 4) {
+            const int by = tile / bin_w, bx = tile - by * bin_w;
+            const int x = 2 * bx + (threadIdx.x & 1), y = 2 * by + (threadIdx.x >> 1);
+            if (x < blocks.tw16 && y < blocks.th16)
+                reinterpret_cast<int2 *>(blocks.block_ranges)[y * blocks.tw16 + x] = make_int2(0, 0);
+        }
+        if (threadIdx.x == 0) blocks.bin_more[tile] = 0;
+    }
+    if (skip || n > kSmallCap) return;
+    sort_segment_lds<256, 4>(smem, keys, start, n, tile, flatten_ids, isect_ids, nullptr,
+                             blocks.block_ids ? &blocks : nullptr, bin_w);
 }
 
 template <int E>
@@ -647,7 +801,8 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
                                                      const uint64_t *__restrict__ keys,
                                                      int32_t *__restrict__ flatten_ids,
                                                      int32_t *__restrict__ front_count, int64_t cap,
-                                                     uint32_t fixed_min, int fixed_shift, int front_k) {
+                                                     uint32_t fixed_min, int fixed_shift, int front_k,
+                                                     ms::BlockLists blocks, int bin_w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem_dyn);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + kFrontCap);
@@ -661,7 +816,18 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
     for (int li = blockIdx.x; li < total; li += gridDim.x) {
         const int tile = li < nm ? medium[li] : (li < nm + nl ? large[li - nm] : xl[li - nm - nl]);
         const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
-        if ((int64_t)start + n > cap) continue;   // speculative overflow: the frame is redone (uniform)
+        if ((int64_t)start + n > cap) {   // speculative overflow: the frame is redone (uniform)
+            if (blocks.block_ids) {       // ... but its rasteriser must find ranges it can walk
+                if (tid < 4) {
+                    const int by = tile / bin_w, bx = tile - by * bin_w;
+                    const int x = 2 * bx + (tid & 1), y = 2 * by + (tid >> 1);
+                    if (x < blocks.tw16 && y < blocks.th16)
+                        reinterpret_cast<int2 *>(blocks.block_ranges)[y * blocks.tw16 + x] = make_int2(0, 0);
+                }
+                if (tid == 0) blocks.bin_more[tile] = 0;
+            }
+            continue;
+        }
         const uint64_t *kin = keys + start;
         // A. depth-bit range: the camera's [near, far] when the caller knows it (every surviving
         //    depth lies inside, so the pass over the keys is saved), else the tile's own min / max
@@ -762,7 +928,9 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
         for (int e = 0; e < kFrontCap / THREADS; ++e)
             if (dest[e] >= 0) s_out[dest[e]] = kk[e];
         __syncthreads();
-        for (int i = tid; i < F; i += THREADS) flatten_ids[start + i] = (int32_t)(uint32_t)s_out[i];
+        if (blocks.block_ids) emit_block_lists<THREADS, kFrontCap / THREADS>(s_out, F, n, start, tile, bin_w, blocks, s_cnt);
+        else
+            for (int i = tid; i < F; i += THREADS) flatten_ids[start + i] = (int32_t)(uint32_t)s_out[i];
         if (tid == 0) front_count[tile] = F;
         __syncthreads();   // LDS is reused by the next list entry
     }
@@ -926,6 +1094,11 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->redo_count = (int32_t *)(ws + p.off_redo_count);
     out->front_threshold = kFrontK;
     out->keys = nullptr;  // the caller knows where it put them
+    out->bin_more = nullptr;
+    out->bin_w = 0;
+    out->packed = 0;
+    out->row_lo = 0;
+    out->row_hi = 0x7fffffff;
 }
 
 extern "C" size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h) {
@@ -960,7 +1133,7 @@ extern "C" int ms_isect_tiles_count(int64_t N, const float *means2d, const int32
     int32_t *medium = (int32_t *)(ws + p.off_medium);
     int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
     uint32_t *on_grid = (uint32_t *)(ws + p.off_on_grid);
-    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end, 0, 0, 0};
 
     if (p.T_local > 0) {
         if (p.lds_bytes > 48 * 1024)
@@ -1012,7 +1185,11 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
     int32_t *medium = (int32_t *)(ws + p.off_medium);
     int32_t *large = (int32_t *)(ws + p.off_large), *xl = (int32_t *)(ws + p.off_xl);
     uint32_t *on_grid = (uint32_t *)(ws + p.off_on_grid);
-    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
+    // block masks (bit 2): entries carry the 2x2 half-tile blocks they reach; bits 3 / 4: the half-tile
+    // grid has an odd number of columns / rows (2 tile_w - 1, 2 tile_h - 1)
+    const bool pack = (tight & 4) && (tight & 1) && opacities && (tile_size & 1) == 0 && N < (1ll << 28);
+    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end, pack ? 1 : 0, 2 * tile_w - ((tight >> 3) & 1),
+                 2 * tile_h - ((tight >> 4) & 1)};
     unsigned long long *masks = ((tight & 1) && opacities) ? (unsigned long long *)(ws + p.off_mask) : nullptr;
     const ms::ProjParams P = ms::make_proj_params(fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, radius_clip,
                                                   scales_are_log, opacities != nullptr);
@@ -1036,7 +1213,8 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
               int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
               const int32_t *tile_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
               uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
-              hipStream_t stream) {
+              hipStream_t stream, const ms::BlockLists *blocks = nullptr) {
+    const ms::BlockLists bl = blocks ? *blocks : ms::BlockLists{nullptr, nullptr, nullptr, 0, 0};
     Plan p;
     const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
     MS_REQUIRE(fits, MS_ERR_TOO_LARGE, "isect_emit: band too large for LDS");
@@ -1046,8 +1224,10 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
     const uint32_t *hist = (const uint32_t *)(ws + p.off_hist);
     const int32_t *medium = (const int32_t *)(ws + p.off_medium);
     const int32_t *large = (const int32_t *)(ws + p.off_large), *xl = (const int32_t *)(ws + p.off_xl);
-    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end};
-    const unsigned long long *masks = tight ? (const unsigned long long *)(ws + p.off_mask) : nullptr;
+    const bool pack = (tight & 4) && (tight & 1) && (tile_size & 1) == 0 && N < (1ll << 28);
+    const Grid g{tile_size, tile_w, tile_h, row_begin, row_end, pack ? 1 : 0, 2 * tile_w - ((tight >> 3) & 1),
+                 2 * tile_h - ((tight >> 4) & 1)};
+    const unsigned long long *masks = (tight & 1) ? (const unsigned long long *)(ws + p.off_mask) : nullptr;
     const bool spec = info_dev != nullptr;
     const int64_t max_count = spec ? 0 : host_info[1], n_medium = spec ? 0 : host_info[2],
                   n_large = spec ? 0 : host_info[3], n_xl = spec ? 0 : host_info[4];
@@ -1082,16 +1262,20 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             }
             // a tile of (tile_size/16)^2 blocks needs that many times the front of one block (up to the LDS room)
             const int blocks_per_tile = ((tile_size + 15) / 16) * ((tile_size + 15) / 16);
-            const int front_k = min(kFrontK * blocks_per_tile, 2048);   // (3072: 1-3 % slower, no fewer clean-ups on the BASELINE scenes)
+            // split frames (bl): 1280 of a 32-px bin's nearest entries saturate its four blocks on the BASELINE
+            // scenes (1024: one bin of config 3 falls short; 2048: +9 us).  A caller that saw the clean-up pass
+            // run asks for deeper fronts (lazy bits 1-2: front level, x2 each, up to the LDS room).
+            int front_k = bl.block_ids ? 1280 : min(kFrontK * blocks_per_tile, 2048);
+            front_k = min(front_k << ((lazy >> 1) & 3), kFrontCap);   // (3072: 1-3 % slower, no fewer clean-ups on the BASELINE scenes)
             hipLaunchKernelGGL(k_tile_front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift,
-                               front_k);
+                               front_k, bl, tile_w);
             MS_LAUNCH_CHECK();
         }
         if (p.T_local > 0)
             hipLaunchKernelGGL(k_tile_sort_small, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
-                               sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w);
+                               sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w, bl, tile_w);
         MS_LAUNCH_CHECK();
         return MS_OK;
     }
@@ -1119,7 +1303,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
     }
     if (p.T_local > 0)
         hipLaunchKernelGGL(k_tile_sort_small, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
-                           sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w);
+                           sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w, bl, tile_w);
     MS_LAUNCH_CHECK();
     if (n_xl > 0) {  // exact mode only: a speculative frame with XL tiles is redone by the caller
         if (int rc = allow_big_lds(k_xl_chunk_sort)) return rc;
@@ -1182,6 +1366,22 @@ extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, 
     return emit_impl(N, means2d, radii, depths, tight, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
                      row_begin, row_end, workspace, workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity,
                      sort_keys, nullptr, flatten_ids, nullptr, (hipStream_t)stream_);
+}
+
+int ms::isect_emit_bins(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int bin_w,
+                        int bin_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
+                        const int32_t *bin_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
+                        int flags, int lazy, float depth_near, float depth_far, uint64_t *sort_keys,
+                        const ms::BlockLists *out, void *stream_) {
+    MS_REQUIRE(N > 0 && cap > 0 && cap <= 0x1fffffffll && (info_dev || host_info), MS_ERR_INVALID_ARG,
+               "isect_emit_bins: bad N / capacity / info");
+    if (int rc = check_grid(32, bin_w, bin_h, row_begin, row_end)) return rc;
+    MS_REQUIRE(workspace && bin_ranges && means2d && radii && depths && sort_keys && out && out->block_ranges &&
+                   out->block_ids && out->bin_more,
+               MS_ERR_INVALID_ARG, "isect_emit_bins: null pointer");
+    return emit_impl(N, means2d, radii, depths, flags, lazy | 1, depth_near, depth_far, 32, bin_w, bin_h, row_begin,
+                     row_end, workspace, workspace_bytes, bin_ranges, host_info, info_dev, cap, sort_keys, nullptr,
+                     nullptr, nullptr, (hipStream_t)stream_, out);
 }
 
 extern "C" int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_w,

@@ -42,6 +42,12 @@ struct LazyLists {
     int32_t *redo_flag, *redo_list, *redo_count;
     int front_threshold;
     const uint64_t *keys;   // the scatter's unsorted (depth_bits << 32 | id) keys, for the clean-up pass
+    // split frames (rasterize_fwd_split): the lists above belong to 32-px bins; the rasteriser walks
+    // per-block lists cut from them and flags the BIN (bin_more: its list was longer than its front)
+    const int32_t *bin_more;
+    int bin_w;
+    int packed;             // key / list words are id << 4 | block bits
+    int row_lo, row_hi;     // split frames: the band in 16-px block rows (the clean-up leaves other rows alone)
 };
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
 
@@ -52,6 +58,29 @@ int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means
                   int W, int H, int tile_size, int tile_row_begin, int tile_row_end, const int32_t *tile_ranges,
                   const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
                   const LazyLists *lazy, void *after_raster_event, void *stream);
+
+// Block lists of a split frame (ms_render_fwd): what the sort kernels of 32-px bins write instead of
+// flatten_ids.  Bin `b` with list [start, start + n) owns block_ids[4 start, 4 (start + n)): its block q
+// (2x2 per bin, q = 2 dy + dx) gets [4 start + q n, ... + count_q), and block_ranges holds that pair for
+// every 16x16 block of the image; bin_more[b] = the list was longer than its sorted front.
+struct BlockLists {
+    int32_t *block_ranges, *block_ids, *bin_more;
+    int tw16, th16;
+};
+// binning.hip: scatter + sorts on the bin grid, writing block lists (info_dev != null: sync-free frame
+// against `cap` entries, host_info = the previous frame's record or null)
+int isect_emit_bins(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int bin_w, int bin_h,
+                    int row_begin, int row_end, void *workspace, size_t workspace_bytes, const int32_t *bin_ranges,
+                    const int64_t *host_info, const int64_t *info_dev, int64_t cap, int flags, int lazy, float depth_near,
+                    float depth_far, uint64_t *sort_keys, const BlockLists *out, void *stream);
+
+// Split frame: the block lists cut from 32-px bins are rasterised per 16x16 block and cleaned up per
+// bin.  Rows are BLOCK rows.
+int rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const float *means2d, const float *conics,
+                        const void *colors, int color_dtype, int CDIM, const float *opacities,
+                        const float *backgrounds, int W, int H, int block_row_begin, int block_row_end,
+                        const int32_t *bin_ranges, const BlockLists *lists, float *render_colors,
+                        const LazyLists *lazy, void *after_raster_event, void *stream);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -13,7 +13,8 @@
 namespace {
 
 struct WsLayout {
-    size_t off_isect, isect_bytes, off_means2d, off_conics, off_depths, off_radii, off_ranges, off_info, total;
+    size_t off_isect, isect_bytes, off_means2d, off_conics, off_depths, off_radii, off_ranges, off_info, off_bin_ranges,
+        off_bin_more, total;
 };
 
 WsLayout ws_layout(int64_t N, int tw, int th) {
@@ -27,6 +28,8 @@ WsLayout ws_layout(int64_t N, int tw, int th) {
     L.off_radii = o;   o += ms::align_up(n * 8, 256);
     L.off_ranges = o;  o += ms::align_up(T * 8, 256);
     L.off_info = o;    o += 256;
+    L.off_bin_ranges = o; o += ms::align_up(T * 8, 256);   // split frames: ranges / flags of the 32-px bins
+    L.off_bin_more = o;   o += ms::align_up(T * 4, 256);
     L.total = o;
     return L;
 }
@@ -37,6 +40,15 @@ WsLayout ws_layout(int64_t N, int tw, int th) {
 static int ms_lazy_enabled() {
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_LAZY_SORT");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+
+// MOJOSPLAT_SPLIT=0: bin on the rasteriser's own 16-px tiles instead of 32-px bins cut into block lists
+static int ms_split_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_SPLIT");
         return e ? atoi(e) != 0 : 1;
     }();
     return v;
@@ -59,6 +71,12 @@ extern "C" int ms_render_workspace_layout(int64_t N, int tile_w, int tile_h, siz
 extern "C" size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch) {
     const size_t m = (size_t)(M > 0 ? M : 1);
     return ms::align_up(m * 8, 256) * (with_merge_scratch ? 2 : 1) + ms::align_up(m * 4, 256);
+}
+
+// split frames: keys 8 M | list words 4 M | block lists 16 M
+static size_t split_isect_bytes(int64_t M) {
+    const size_t m = (size_t)(M > 0 ? M : 1);
+    return ms::align_up(m * 8, 256) + ms::align_up(m * 4, 256) + ms::align_up(m * 16, 256);
 }
 
 extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,
@@ -96,9 +114,18 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     // rasterise were enqueued speculatively, bit 1 = the large sort class was among them
     // lazy sorting (binning.hip, k_tile_front): not for a differentiable frame, whose backward walks
     // the full lists by position
-    const int lazy = (render_alphas || last_ids || !opacities || CDIM > 4 || (resume & MS_RENDER_FULL_SORT)) ? 0 : ms_lazy_enabled();
+    // (bits 1-2 of `lazy`: the front level the caller asked for, see MS_RENDER_FRONT_LEVEL)
+    const int lazy = (render_alphas || last_ids || !opacities || CDIM > 4 || (resume & MS_RENDER_FULL_SORT))
+                         ? 0 : (ms_lazy_enabled() ? 1 | (((resume >> 9) & 3) << 1) : 0);
+    // split frame (binning.hip, emit_block_lists): bin on 32-px bins, rasterise the 16x16-block lists cut
+    // from them (a band that starts or ends inside a bin row bins that whole row).  The frame is the same
+    // either way.
+    const bool split = lazy && tile_size == 16 && N > 0 && N < (1ll << 28) && r1 > r0 && ms_split_enabled();
+    const int bw = (tw + 1) / 2, bh = (th + 1) / 2, b0 = r0 / 2, b1 = (r1 + 1) / 2;
+    const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0);
+    int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
     ms::LazyLists lazy_lists;
-    if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, tw, th, &lazy_lists);
+    if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, split ? bw : tw, split ? bh : th, &lazy_lists);
     bool speculated = false;
     if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);
@@ -113,10 +140,11 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
             mirror = nullptr;
         }
         if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
-                                            cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f, tile_size, r0, r1,
-                                            /*tight | ranges for the band only=*/1 | 2, means2d, conics, depths,
-                                            radii, ws + L.off_isect, L.isect_bytes, ranges, info,
-                                            (int64_t *)mirror, stream))
+                                            cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,
+                                            split ? 32 : tile_size, split ? b0 : r0, split ? b1 : r1,
+                                            /*tight | ranges for the band only (| block masks)=*/split ? bin_flags : 1 | 2,
+                                            means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
+                                            split ? bin_ranges : ranges, info, (int64_t *)mirror, stream))
             return rc;
         mark(1);
         host_info[7] = 0;
@@ -127,11 +155,30 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         // then wait for the size record -- the GPU never idles on the hand-off.  Every kernel
         // clamps to `cap`, so an overflowing frame writes nothing out of bounds; it is detected
         // in the finishing half and redone on the exact path.
-        const int64_t cap = isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0;
+        const int64_t cap = split ? (isect_bytes > 768 ? (int64_t)((isect_bytes - 768) / 28) : 0)
+                                  : (isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0);
         if (sync_event && isect_buf && cap > 0 && N > 0) {   // (an empty set has null inputs: exact path, M = 0)
-            const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
+            const int64_t cmax = split ? 0x1fffffffll : 0x7fffffffll;
+            const int64_t c = cap > cmax ? cmax : cap;
             uint64_t *keys = (uint64_t *)isect_buf;
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
+            if (split) {
+                const ms::BlockLists lists{ranges, (int32_t *)((char *)ids + ms::align_up((size_t)c * 4, 256)), bin_more, tw, th};
+                if (int rc = ms::isect_emit_bins(N, means2d, radii, depths, bw, bh, b0, b1, ws + L.off_isect,
+                                                 L.isect_bytes, bin_ranges, prev, info, c, bin_flags, lazy,
+                                                 near_plane, far_plane, keys, &lists, stream))
+                    return rc;
+                mark(2);
+                lazy_lists.keys = keys;
+                // (a 16-px grid holds ~1.7x the entries of the 32-px bins it was cut from)
+                if (int rc = ms::rasterize_fwd_split(N, c, prev[0] > 0 ? prev[0] * 17 / 10 : c, means2d, conics, colors,
+                                                     color_dtype, CDIM, opacities, backgrounds, W, H, r0, r1,
+                                                     bin_ranges, &lists, render_colors, &lazy_lists,
+                                                     stage_events ? stage_events[3] : nullptr, stream))
+                    return rc;
+                host_info[7] = 1 | 8;
+                if (phase == MS_RENDER_BEGIN) return MS_OK;
+            } else {
             if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                          ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
                                                          /*tight=*/opacities != nullptr, lazy, near_plane, far_plane, keys, ids, stream))
@@ -144,6 +191,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                                            stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0);
+            }
         }
         if (phase == MS_RENDER_BEGIN) return MS_OK;
     }
@@ -154,8 +202,9 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         else MS_HIP(hipStreamSynchronize(stream));
         speculated = (host_info[7] & 1) != 0;
         if (speculated) {
-            const int64_t cap = (int64_t)((isect_bytes - 512) / 12);
-            const int64_t c = cap > 0x7fffffffll ? 0x7fffffffll : cap;
+            const int64_t cap = split ? (int64_t)((isect_bytes - 768) / 28) : (int64_t)((isect_bytes - 512) / 12);
+            const int64_t cmax = split ? 0x1fffffffll : 0x7fffffffll;
+            const int64_t c = cap > cmax ? cmax : cap;
             const int64_t Ms = host_info[0];
             const bool large_ok = lazy || host_info[3] == 0 || (host_info[7] & 2);  // large class sorted iff launched
             if (Ms > 0 && Ms <= c && (lazy || host_info[4] == 0) && large_ok) return MS_OK;  // the common case
@@ -176,7 +225,9 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         if (!speculated) { mark(2); mark(3); }
         return MS_OK;
     }
-    const size_t need = ms_render_isect_bytes(M, n_xl > 0 && !lazy);
+    MS_REQUIRE(!split || M <= 0x1fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld bin entries (set MOJOSPLAT_SPLIT=0)",
+               (long long)M);
+    const size_t need = split ? split_isect_bytes(M) : ms_render_isect_bytes(M, n_xl > 0 && !lazy);
     host_info[5] = (int64_t)need;
     host_info[7] |= 4;  // the lists the caller may read back are in the EXACT layout (below)
     MS_REQUIRE(isect_buf && isect_bytes >= need, MS_ERR_WORKSPACE,
@@ -188,6 +239,19 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     const bool merge = n_xl > 0 && !lazy;
     uint64_t *tmp = merge ? (uint64_t *)(ib + key_bytes) : nullptr;
     int32_t *ids = (int32_t *)(ib + key_bytes * (merge ? 2 : 1));
+    if (split) {
+        const int64_t c = M > 0 ? M : 1;
+        const ms::BlockLists lists{ranges, (int32_t *)((char *)ids + ms::align_up((size_t)M * 4, 256)), bin_more, tw, th};
+        if (int rc = ms::isect_emit_bins(N, means2d, radii, depths, bw, bh, b0, b1, ws + L.off_isect, L.isect_bytes,
+                                         bin_ranges, host_info, nullptr, c, bin_flags, lazy, near_plane, far_plane,
+                                         keys, &lists, stream))
+            return rc;
+        if (!speculated) mark(2);
+        lazy_lists.keys = keys;
+        return ms::rasterize_fwd_split(N, c, M * 17 / 10, means2d, conics, colors, color_dtype, CDIM, opacities,
+                                       backgrounds, W, H, r0, r1, bin_ranges, &lists, render_colors, &lazy_lists,
+                                       (!speculated && stage_events) ? stage_events[3] : nullptr, stream);
+    }
     if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
                                      L.isect_bytes, ranges, host_info, /*tight=*/opacities != nullptr, lazy, near_plane, far_plane,
                                      keys, tmp, ids, nullptr, stream))

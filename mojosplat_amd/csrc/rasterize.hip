@@ -296,15 +296,20 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
         if (!any_live) break;
     }
 
-    if (end < end_all) {  // wave-uniform; only heavy tiles of a lazily sorted frame get here
+    int redo_tile = end < end_all ? tile : -1;  // wave-uniform; only heavy tiles of a lazily sorted frame
+    if (A.lazy.bin_more) {   // split frame: this block's list was cut from the front of its 32-px bin
+        const int bin = (tile_y >> 1) * A.lazy.bin_w + (tile_x >> 1);
+        if (A.lazy.bin_more[bin]) redo_tile = bin;
+    }
+    if (redo_tile >= 0) {
         bool alive = false;
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) alive = alive || __any(thr[qi] < kInf);
         if (alive) {
             // pixels outlived the sorted front: the clean-up kernel redoes the whole tile (and
             // overwrites what is stored below); once per tile, whichever wave gets there first
-            if (lane == 0 && atomicExch(&A.lazy.redo_flag[tile], 1) == 0)
-                A.lazy.redo_list[atomicAdd(A.lazy.redo_count, 1)] = tile;
+            if (lane == 0 && atomicExch(&A.lazy.redo_flag[redo_tile], 1) == 0)
+                A.lazy.redo_list[atomicAdd(A.lazy.redo_count, 1)] = redo_tile;
         }
     }
 
@@ -362,6 +367,10 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
         const uint64_t *kin = A.lazy.keys + start;
         for (int sub = 0; sub < A.nsub; ++sub) {
             const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
+            if (A.lazy.packed) {   // a bin at the edge of a band: only the block rows inside it (uniform)
+                const int brow = tile_y * A.nsx + sub_y;
+                if (brow < A.lazy.row_lo || brow >= A.lazy.row_hi) continue;
+            }
             const int q = w;  // one quad per wave
             const int ox = sub_x * 16 + lx + (q & 1) * 8, oy = sub_y * 16 + ly + (q >> 1) * 8;
             const int X = tile_x * A.ts + ox, Y = tile_y * A.ts + oy;
@@ -491,13 +500,16 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                 for (int e0 = 0; e0 < F; e0 += 256) {
                     __syncthreads();
                     if (e0 + tid < F) {
-                        const int g = min(max((int)(unsigned int)s_key[e0 + tid], 0), A.n_gauss - 1);
+                        const unsigned int word = (unsigned int)s_key[e0 + tid];
+                        const int g = min(max((int)(A.lazy.packed ? word >> 4 : word), 0), A.n_gauss - 1);
                         const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
                         const float ca = A.conics[3 * g], cb = A.conics[3 * g + 1], cc = A.conics[3 * g + 2];
                         const float op = A.opacities[g];
                         s_pa[tid] = make_float4(m.x, m.y, -0.5f * kLog2e * ca, -kLog2e * cb);
                         // opacity below 1/255 can never blend: log2 -> -inf keeps alpha at 0
-                        s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold ? __log2f(op) : -kInf, 0.f, 0.f);
+                        // (split frames: nor can an entry that is not on this block's list)
+                        const bool listed = !A.lazy.packed || ((word >> sub) & 1u);
+                        s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold && listed ? __log2f(op) : -kInf, 0.f, 0.f);
 #pragma unroll
                         for (int k = 0; k < CP; ++k)
                             s_pc[tid * CP + k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
@@ -568,6 +580,12 @@ int launch_fwd(const RasterArgs &A, hipStream_t stream, void *after_raster_event
     return MS_OK;
 }
 
+template <typename ColorT>
+void launch_redo(const RasterArgs &A, hipStream_t stream) {
+    if (A.cdim == 3) hipLaunchKernelGGL((k_tile_redo<3, ColorT>), dim3(64), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL((k_tile_redo<4, ColorT>), dim3(64), dim3(256), 0, stream, A);
+}
+
 }  // namespace
 
 // density_hint: intersections the band is expected to hold (the exact M when the caller knows it, the
@@ -592,7 +610,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.backgrounds = backgrounds; A.tile_ranges = tile_ranges; A.flatten_ids = flatten_ids;
     A.render_colors = render_colors; A.render_alphas = render_alphas; A.last_ids = last_ids;
     if (lazy) A.lazy = *lazy;
-    else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0x7fffffff};
     A.W = W; A.H = H; A.ts = tile_size;
     A.tw = (W + tile_size - 1) / tile_size;
     const int th = (H + tile_size - 1) / tile_size;
@@ -642,4 +660,63 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
     return ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                              tile_size, tile_row_begin, tile_row_end, tile_ranges, flatten_ids, render_colors,
                              render_alphas, last_ids, nullptr, nullptr, stream);
+}
+
+int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const float *means2d, const float *conics,
+                            const void *colors, int color_dtype, int CDIM, const float *opacities,
+                            const float *backgrounds, int W, int H, int block_row_begin, int block_row_end,
+                            const int32_t *bin_ranges, const ms::BlockLists *lists, float *render_colors,
+                            const ms::LazyLists *lazy, void *after_raster_event, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(N > 0 && cap > 0 && cap <= 0x1fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd_split: bad N/cap");
+    MS_REQUIRE(W > 0 && H > 0 && CDIM >= 1 && CDIM <= 4, MS_ERR_INVALID_ARG, "rasterize_fwd_split: bad sizes");
+    MS_REQUIRE(color_dtype == MS_COLOR_F32 || color_dtype == MS_COLOR_F16, MS_ERR_INVALID_ARG,
+               "rasterize_fwd_split: unknown colour dtype %d", color_dtype);
+    MS_REQUIRE(means2d && conics && colors && opacities && bin_ranges && lists && lists->block_ranges &&
+                   lists->block_ids && lists->bin_more && render_colors && lazy && lazy->keys,
+               MS_ERR_INVALID_ARG, "rasterize_fwd_split: null pointer");
+    MS_REQUIRE(((uintptr_t)means2d & 7) == 0, MS_ERR_INVALID_ARG, "rasterize_fwd_split: means2d must be 8-byte aligned");
+    const int tw16 = (W + 15) / 16, th16 = (H + 15) / 16, bw = (W + 31) / 32;
+    const int r0 = block_row_begin, r1 = block_row_end;
+    MS_REQUIRE(r0 >= 0 && r0 <= r1 && r1 <= th16, MS_ERR_INVALID_ARG, "rasterize_fwd_split: bad block rows [%d,%d) of %d",
+               r0, r1, th16);
+    if (r1 == r0) {
+        if (after_raster_event) (void)hipEventRecord((hipEvent_t)after_raster_event, stream);
+        return MS_OK;
+    }
+    RasterArgs A;
+    A.means2d = means2d; A.conics = conics; A.colors = colors; A.opacities = opacities;
+    A.backgrounds = backgrounds; A.tile_ranges = lists->block_ranges; A.flatten_ids = lists->block_ids;
+    A.render_colors = render_colors; A.render_alphas = nullptr; A.last_ids = nullptr;
+    A.lazy = *lazy;
+    A.lazy.front_count = nullptr;   // block lists are walked to their end; the bin's flag says whether that was all
+    A.lazy.bin_more = lists->bin_more;
+    A.lazy.bin_w = bw;
+    A.lazy.packed = 0;
+    A.W = W; A.H = H; A.ts = 16; A.tw = tw16; A.nsx = 1; A.nsub = 1; A.cdim = CDIM;
+    A.tile0 = r0 * tw16;
+    const int64_t blocks = (int64_t)(r1 - r0) * tw16;
+    A.parts = 1;
+    if (blocks < 16384) {   // as rasterize_fwd
+        const int64_t per_block = density_hint / blocks;
+        A.parts = per_block > 1500 ? 1 : per_block > 150 ? 2 : 4;
+    }
+    A.nblocks = (int)blocks * A.parts;
+    A.max_isects = (int)(4 * cap);
+    A.n_gauss = (int)(N < 0x7fffffffll ? N : 0x7fffffffll);
+    if (int rc = color_dtype == MS_COLOR_F16 ? launch_fwd<__half>(A, stream, after_raster_event)
+                                              : launch_fwd<float>(A, stream, after_raster_event))
+        return rc;
+    // clean-up per BIN, from the scatter's unsorted keys (words id << 4 | blocks)
+    RasterArgs B = A;
+    B.tile_ranges = bin_ranges; B.flatten_ids = nullptr;
+    B.ts = 32; B.tw = bw; B.nsx = 2; B.nsub = 4;
+    B.max_isects = (int)cap;
+    B.lazy.packed = 1;
+    B.lazy.row_lo = r0;
+    B.lazy.row_hi = r1;
+    if (color_dtype == MS_COLOR_F16) launch_redo<__half>(B, stream);
+    else launch_redo<float>(B, stream);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
 }

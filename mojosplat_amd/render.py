@@ -11,6 +11,7 @@ Beyond the reference: ``features`` of shape (N, K, 3) together with ``sh_degree`
 spherical-harmonic coefficients and are evaluated per view (sh.py) -- the TODO at
 render.py:83 carried out.
 """
+import time
 from typing import Optional
 
 import torch
@@ -29,48 +30,66 @@ _STAGE_HOOK = None
 
 
 # ---- binning granularity -------------------------------------------------------------------------
-# The frame does not depend on the tile size: a pixel blends the same Gaussians in the same order
-# whatever grid they were binned on, and the rasteriser works in 16x16 blocks inside any tile
-# (measured bit-identical for 16 / 32 / 64 px at every BASELINE config).  What the tile size moves
-# is cost: coarser bins mean fewer (Gaussian, tile) pairs to scatter and sort (config 5: 38 M at
-# 16 px, 9.9 M at 64 px) but every block then stages a longer, less relevant list.  Dense scenes win
-# big from coarse bins (config 5: 1.62 -> 0.74 ms at 64 px, config 4: 0.85 -> 0.62 ms at 32 px), sparse
-# ones lose (config 3: 0.29 -> 0.72 ms at 32 px).  So: the first frame of a scene (same N and image
-# size) is binned on the caller's tile size; its intersections per tile decide the rest.
-_BIN_CHOICE = {}            # (device, N, W, H, tile_size) -> bin size for the following frames
-_DENSE_PER_TILE = 800       # (tight) intersections per 16-px tile from which coarse bins pay
-_MANY_TILES = 16384         # grids this large have the parallelism to absorb 64-px bins
+# The frame does not depend on the grid the Gaussians are binned on: a pixel blends the same Gaussians
+# in the same order whatever the bins, and the rasteriser works in 16x16 blocks inside any tile
+# (bit-identical for every mode below at every BASELINE config; tests/test_hip_fused.py).  What the
+# grid moves is cost, by up to 2x either way:
+#   16  the library's default for 16-px tiles: 32-px bins whose sorted lists are cut into per-block
+#       lists (a "split" frame) -- best while Gaussians are small against a tile (config 3: 0.26 ms
+#       against 0.31 at plain 32 px and 0.62 at 64);
+#   32 / 64  plain coarse bins, every block walks its bin's whole list -- best for dense scenes of
+#       larger footprints (config 5: 1.18 / 1.08 / 0.77 ms at 16 / 32 / 64; config 4: 0.69 / 0.64 / 0.66).
+# No density rule separates these cases reliably, so the first frames of a scene (same device, N and
+# image size) are a measurement: each mode renders one warm-up frame and two timed ones (host clock
+# around a synchronised call), the fastest is kept, and the race is run again every _REPROBE_EVERY
+# frames because scenes drift.  64 px is only tried when 32 px did not already lose clearly.
+_BIN_CHOICE = {}            # (device, N, W, H) -> _BinTuner
+_BIN_MODES = (16, 32, 64)
+_REPROBE_EVERY = 1024
+_SKIP_COARSER = 1.15        # 32 px slower than 16 px by this factor: do not try 64
 
 
-_REPROBE_EVERY = 256        # a scene drifts (camera moves): one frame in 256 is binned at 16 px again
+class _BinTuner:
+    def __init__(self):
+        self.choice = None
+        self.frames = 0
+        self._start_race()
+
+    def _start_race(self):
+        self.times = {}
+        self.queue = [(m, k > 0) for m in _BIN_MODES for k in range(3)]   # (mode, timed?)
+
+    def next(self):
+        """-> (bin size of this frame, whether to time it)."""
+        if not self.queue:
+            self.frames += 1
+            if self.frames % _REPROBE_EVERY == 0:
+                self._start_race()
+            else:
+                return self.choice, False
+        return self.queue[0]
+
+    def done(self, mode, seconds):
+        """The frame `next()` announced has been rendered (seconds: None when it was not timed)."""
+        if not self.queue or self.queue[0][0] != mode:
+            return
+        self.queue.pop(0)
+        if seconds is not None:
+            self.times[mode] = min(seconds, self.times.get(mode, seconds))
+        if 16 in self.times and 32 in self.times and self.times[32] > _SKIP_COARSER * self.times[16]:
+            self.queue = [q for q in self.queue if q[0] != 64]
+        if not self.queue:
+            self.choice = min(self.times, key=self.times.get)
 
 
-def _bin_size(means3d, camera, tile_size):
+def _tuner(means3d, camera, tile_size):
     if tile_size != TILE_SIZE:
-        return tile_size    # an explicit non-default tile size is honoured as given
-    key = (means3d.device, means3d.shape[0], camera.W, camera.H, tile_size)
-    entry = _BIN_CHOICE.get(key)
-    if entry is None:
-        return tile_size
-    entry[1] += 1
-    if entry[1] % _REPROBE_EVERY == 0:
-        return tile_size
-    return entry[0]
-
-
-def _note_density(means3d, camera, tile_size, bin_size, m):
-    if tile_size != TILE_SIZE or bin_size != tile_size:
-        return              # only frames binned at the default size are evidence
-    tiles = (-(-camera.H // tile_size)) * (-(-camera.W // tile_size))
-    choice = tile_size
-    if m >= _DENSE_PER_TILE * tiles:
-        choice = 64 if tiles >= _MANY_TILES else 32
-    key = (means3d.device, means3d.shape[0], camera.W, camera.H, tile_size)
-    entry = _BIN_CHOICE.get(key)
-    if entry is None:
-        _BIN_CHOICE[key] = [choice, 0]
-    else:
-        entry[0] = choice
+        return None         # an explicit non-default tile size is honoured as given
+    key = (means3d.device, means3d.shape[0], camera.W, camera.H)
+    t = _BIN_CHOICE.get(key)
+    if t is None:
+        t = _BIN_CHOICE[key] = _BinTuner()
+    return t
 
 
 @torch.no_grad()
@@ -119,12 +138,19 @@ def render_gaussians(
         if sh_degree is not None and features.shape[-1] > 3:
             colors, bg = features[..., :3], bg[:3]  # the reference's placeholder (render.py:82-87)
         evs = _STAGE_HOOK() if _STAGE_HOOK is not None else None
-        bin_size = _bin_size(means3d, camera, tile_size)
-        bands = lds_row_bands(camera.H, camera.W, bin_size)
+        bands = lds_row_bands(camera.H, camera.W, tile_size)
         if len(bands) == 1:
-            img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, bin_size,
+            tuner = _tuner(means3d, camera, tile_size)
+            bin_size, timed = (tile_size, False) if tuner is None else tuner.next()
+            if timed:
+                torch.cuda.synchronize(means3d.device)
+                t0 = time.perf_counter()
+            img, _ = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, bin_size,
                                     stage_events=evs)
-            _note_density(means3d, camera, tile_size, bin_size, m)
+            if tuner is not None:
+                if timed:
+                    torch.cuda.synchronize(means3d.device)
+                tuner.done(bin_size, time.perf_counter() - t0 if timed else None)
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer

@@ -121,6 +121,17 @@ def test_multi_view_batch_equals_single_views(device):
     assert not torch.equal(batch[0], batch[4])
 
 
+@pytest.fixture
+def default_grid_only():
+    """render_gaussians without its race between binning granularities: every frame on the default grid."""
+    from mojosplat_amd import render as R
+    old, R._BIN_MODES = R._BIN_MODES, (16,)
+    R._BIN_CHOICE.clear()
+    yield
+    R._BIN_MODES = old
+    R._BIN_CHOICE.clear()
+
+
 def _stack_scene(n, z_lo, z_hi, opacity, device, seed=0):
     """n big faint Gaussians piled up in front of the camera: every tile of a 64x64 image holds
     thousands of entries and none of them comes close to saturating a pixel."""
@@ -143,7 +154,7 @@ def _stack_scene(n, z_lo, z_hi, opacity, device, seed=0):
     (6000, 5.0, 5.0, 0.004, False),      # ONE depth, ~2000 per tile: one crowded bucket = the whole list = the front
     (16000, 5.0, 5.0, 0.0055, True),     # ONE depth, > 4096 per tile: no front fits; the clean-up narrows by index
     (3000, 4.0, 4.0001, 0.02, False)])   # a handful of depth values, saturating late
-def test_lazy_sorting_clean_up_pass(device, n, z_lo, z_hi, opacity, falls_back):
+def test_lazy_sorting_clean_up_pass(device, default_grid_only, n, z_lo, z_hi, opacity, falls_back):
     """ms_render_fwd sorts only the front (~1024 nearest entries) of a heavy tile; here that front
     cannot saturate the pixels, so every tile goes through the clean-up kernel (chunked selection,
     including the narrowing into crowded buckets when thousands of entries share one depth).  The
@@ -167,6 +178,36 @@ def test_lazy_sorting_clean_up_pass(device, n, z_lo, z_hi, opacity, falls_back):
     if falls_back:
         assert _fused._dev_state(sc["means3d"].device, 0).get("full_sort")
     _fused._state.clear()   # do not leak the fallback into other tests
+
+
+def test_lazy_front_levels(device, default_grid_only):
+    """One heavy 32-px bin (2000 faint specks) whose default sorted front is too short: the lane sees the
+    clean-up pass run once and asks for fronts twice as deep -- which hold the whole list -- instead of
+    giving up on lazy sorting.  Every frame on the way equals the fully sorted per-stage path."""
+    from mojosplat_amd.rasterization import rasterize_gaussians_hip
+    from mojosplat_amd.utils import Camera
+    gen = torch.Generator().manual_seed(5)
+    n, z = 2000, 5.0
+    px = 6.0 + 20.0 * torch.rand(n, 2, generator=gen)
+    means = torch.cat([(px - 64.0) * z / 60.0, z + 0.5 * torch.rand(n, 1, generator=gen)], 1)
+    sc = dict(means3d=means, scales=torch.full((n, 3), -2.3), quats=torch.nn.functional.normalize(torch.randn(n, 4, generator=gen), dim=1),
+              opacities=0.005 * (0.9 + 0.2 * torch.rand(n, generator=gen)), features=torch.rand(n, 3, generator=gen))
+    sc = {k: v.to(device) for k, v in sc.items()}
+    cam = Camera(R=torch.eye(3, device=device), T=torch.zeros(3, device=device), H=128, W=128, fx=60.0, fy=60.0,
+                 cx=64.0, cy=64.0)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+    ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, cam.H, cam.W, 16, backend="hip")
+    ref = rasterize_gaussians_hip(m2, con, g[4], g[3], bg, ranges, ids, cam, 16)
+    _fused._state.clear()
+    levels = []
+    for _ in range(5):
+        assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, backend="hip"), ref)
+        st = _fused._dev_state(sc["means3d"].device, 0)
+        levels.append((st.get("front_level", 0), bool(st.get("full_sort"))))
+    assert levels[0] == (0, False) and levels[-1] == (1, False), levels
+    _fused._state.clear()
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -255,7 +296,7 @@ def test_sharded_rehearsal_assembles_the_frame(device, world):
 def test_frame_does_not_depend_on_the_binning_granularity(device):
     """A pixel blends the same Gaussians in the same order whatever tile grid they were binned on, so
     16 / 32 / 64-px bins (the rasteriser works in 16x16 blocks inside any tile) give the same frame bit
-    for bit -- which is what lets render_gaussians pick coarse bins for dense scenes on its own."""
+    for bit -- which is what lets render_gaussians pick the fastest grid for a scene on its own."""
     from mojosplat_amd import render as R
     sc, cam = randscene_v1(60_000, 512, 384, ell=-2.6, seed=41, device=device)
     bg = torch.tensor(BACKGROUND_V1, device=device)
@@ -265,21 +306,17 @@ def test_frame_does_not_depend_on_the_binning_granularity(device):
         _fused._state.clear()
         for _ in range(2):
             assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, tile_size=ts, backend="hip"), ref), ts
-    # the automatic choice: dense -> coarse bins from the second frame on, same pixels
+    # the automatic choice: a race between the modes over the first frames, same pixels throughout
     _fused._state.clear()
     R._BIN_CHOICE.clear()
-    old = R._DENSE_PER_TILE
     try:
-        R._DENSE_PER_TILE = 10          # make this small scene count as dense
-        a = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
-        assert list(R._BIN_CHOICE.values())[0][0] == 32
-        b = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
-        assert torch.equal(a, ref) and torch.equal(b, ref)
-        R._DENSE_PER_TILE = 10 ** 9     # sparse: stays on the caller's tile size
-        R._BIN_CHOICE.clear()
-        ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
-        assert list(R._BIN_CHOICE.values())[0][0] == 16
+        seen = set()
+        for _ in range(12):
+            tuner = R._tuner(g[0], cam, 16)
+            seen.add(tuner.next()[0])
+            assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, backend="hip"), ref)
+        (tuner,) = R._BIN_CHOICE.values()
+        assert seen >= {16, 32} and not tuner.queue and tuner.choice in seen
     finally:
-        R._DENSE_PER_TILE = old
         R._BIN_CHOICE.clear()
         _fused._state.clear()

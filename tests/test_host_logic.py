@@ -192,3 +192,31 @@ def test_c_abi_argument_validation_returns_status_codes():
     assert frame(r0=1, r1=0) == INVALID and "band" in err()
     assert frame(wsb=8) == WORKSPACE and "workspace" in err()
     assert L.ms_render_workspace_bytes(N, 1, 1) >= L.ms_isect_workspace_bytes(N, 1, 1)
+
+
+def test_bin_tuner_races_the_modes_and_keeps_the_fastest():
+    """render.py's binning-granularity race: one warm-up + two timed frames per mode, 64 px skipped when
+    32 px already lost clearly, re-run every _REPROBE_EVERY frames."""
+    from mojosplat_amd import render as R
+
+    def race(t, cost):
+        order = []
+        while t.queue:
+            mode, timed = t.next()
+            order.append((mode, timed))
+            t.done(mode, cost[mode] if timed else None)
+        return order
+
+    t = R._BinTuner()
+    order = race(t, {16: 1.0, 32: 0.8, 64: 0.9})
+    assert order == [(m, k > 0) for m in (16, 32, 64) for k in range(3)]
+    assert t.choice == 32 and t.next() == (32, False)
+    t = R._BinTuner()
+    order = race(t, {16: 1.0, 32: 1.5, 64: 0.1})       # 64 is never tried
+    assert [m for m, _ in order] == [16] * 3 + [32] * 3 and t.choice == 16
+    # a stale done() (another mode than announced) is ignored; the race comes round again
+    t.done(64, 0.0)
+    assert t.choice == 16
+    for _ in range(R._REPROBE_EVERY - 1):
+        assert t.next() == (16, False)
+    assert t.next() == (16, False) and t.queue     # the first frame of the next race: warm-up at 16
