@@ -123,10 +123,11 @@ __device__ __forceinline__ void count_on_grid(bool on_grid, unsigned int *s_on_g
 // on the half-tile grid -- the lists must hold exactly what 16-px tiles would -- and reports in `edges`
 // which outer half-columns / half-rows of the box lie outside that finer box (bit 0 left, 1 right, 2 top,
 // 3 bottom).
+template <bool PACK>
 __device__ __forceinline__ bool bin_box(float2 m, int2 r, const Grid &g, int &x0, int &x1, int &y0, int &y1,
                                         int &edges) {
     edges = 0;
-    if (!g.pack) return tile_bbox(m, r, g, x0, x1, y0, y1);
+    if constexpr (!PACK) return tile_bbox(m, r, g, x0, x1, y0, y1);
     const Grid gc{g.ts >> 1, g.cw, g.ch, 0, g.ch, 0, 0, 0};
     int cx0, cx1, cy0, cy1;
     const bool on = tile_bbox(m, r, gc, cx0, cx1, cy0, cy1);
@@ -169,7 +170,7 @@ __device__ __forceinline__ unsigned long long clip_cells(unsigned long long m, i
 // (index base + threadIdx.x, n = 0 if it has none); F(local_tile, gaussian_index) is called for
 // every tile of every box.  Small boxes are walked by their own lane, big ones by the whole wave.
 // Must be reached by all lanes of the wave (ballot / shuffles inside).
-template <class F>
+template <bool PACK, class F>
 __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0, int y1, int n, int edges,
                                            const Grid &g, unsigned long long mask, F &&f) {
     const int lane = threadIdx.x & 63;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
         const int w = x1 - x0;
         const float inv_w = 1.0f / (float)w;
         unsigned int m;
-        const bool cells = g.pack && n <= 16;   // `mask` is per half-tile cell (2w cells per row): fold to tiles
+        const bool cells = PACK && n <= 16;   // `mask` is per half-tile cell (2w cells per row): fold to tiles
         if (cells) {
             const int cw = 2 * w, h = y1 - y0;
             const unsigned int rowmask = cw >= 32 ? 0xffffffffu : ((1u << cw) - 1u);
@@ -207,7 +208,7 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
                 const int cw = 2 * w, b00 = 2 * r * cw + 2 * c;
                 q = (int)((mask >> b00) & 3ull) | ((int)((mask >> (b00 + cw)) & 3ull) << 2);
             } else {
-                q = edge_blocks(edges, c, r, w, y1 - y0);
+                q = PACK ? edge_blocks(edges, c, r, w, y1 - y0) : 0xf;
             }
             f((y0 + r - g.row_begin) * g.tw + x0 + c, i, q);
         }
@@ -220,20 +221,20 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
         const int by0 = __shfl(y0, src), by1 = __shfl(y1, src);
         const unsigned long long bm = ((unsigned long long)(unsigned)__shfl((int)(mask >> 32), src) << 32) |
                                       (unsigned)__shfl((int)(mask & 0xffffffffu), src);
-        const int be = __shfl(edges, src);
+        const int be = PACK ? __shfl(edges, src) : 0;
         const int64_t bi = base + (threadIdx.x & ~63) + src;
         const int w = bx1 - bx0, cnt = w * (by1 - by0);
         for (int k = lane; k < cnt; k += 64) {
             const int r = k / w, c = k % w;
             if (cnt > 64 || ((bm >> k) & 1ull))
-                f((by0 + r - g.row_begin) * g.tw + bx0 + c, bi, edge_blocks(be, c, r, w, by1 - by0));
+                f((by0 + r - g.row_begin) * g.tw + bx0 + c, bi, PACK ? edge_blocks(be, c, r, w, by1 - by0) : 0xf);
         }
     }
 }
 
 // Walk every (Gaussian, tile) pair of one chunk; F(local_tile, gaussian_index).
 // Small boxes are walked by their own lane, big ones by the whole wave.
-template <class F>
+template <bool PACK, class F>
 __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const float *means2d,
                                                const int32_t *radii, const unsigned long long *masks,
                                                const Grid &g,
@@ -247,20 +248,21 @@ __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const flo
             const int2 r = reinterpret_cast<const int2 *>(radii)[i];
             if (r.x > 0 && r.y > 0) {
                 const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
-                on_grid = bin_box(m, r, g, x0, x1, y0, y1, edges);
+                on_grid = bin_box<PACK>(m, r, g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
-                if (masks && (n > 1 || g.pack)) mask = masks[i];
+                if (masks && (n > 1 || PACK)) mask = masks[i];
             }
             if (tiles_per_gauss) tiles_per_gauss[i] = n;
         }
         if (s_on_grid) count_on_grid(on_grid, s_on_grid);
-        walk_boxes(base, x0, x1, y0, y1, n, edges, g, mask, f);
+        walk_boxes<PACK>(base, x0, x1, y0, y1, n, edges, g, mask, f);
     }
 }
 
 // Fused projection + tile counting (the first two kernels of a frame in one): every lane projects
 // its Gaussian (project_device.hpp), stores the projected record, and counts the tiles of its box
 // in the workgroup's LDS histogram.  Same chunking as k_isect_hist / k_isect_scatter.
+template <bool PACK>
 __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
@@ -288,10 +290,10 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
             depths[i] = o.d;
             reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
             if (o.r0 > 0 && o.r1 > 0) {
-                on_grid = bin_box(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
+                on_grid = bin_box<PACK>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
                 if (masks) {
-                    if (g.pack && n <= 16 && n > 0)   // per half-tile cell (the 16x16 blocks of a 32-px bin)
+                    if (PACK && n <= 16 && n > 0)   // per half-tile cell (the 16x16 blocks of a 32-px bin)
                         mask = clip_cells(reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], 2 * x0, 2 * x1,
                                                      2 * y0, 2 * y1, g.ts >> 1), edges, x1 - x0, y1 - y0);
                     else
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
             }
         }
         count_on_grid(on_grid, &s_on_grid);
-        walk_boxes(base, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
+        walk_boxes<PACK>(base, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid,
+    for_each_isect<false>(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid,
                    [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
@@ -471,6 +473,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
     }
 }
 
+template <bool PACK>
 __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
@@ -484,9 +487,9 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
         s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect(i0, i1, means2d, radii, masks, g, nullptr, nullptr, [&](int t, int64_t i, int q) {
+    for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, [&](int t, int64_t i, int q) {
         const uint32_t slot = atomicAdd(&s_cur[t], 1u);
-        const uint32_t low = g.pack ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
+        const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
         const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | low;
         if ((int64_t)slot < M) keys[slot] = key;
     });
@@ -539,16 +542,16 @@ __device__ __forceinline__ void emit_block_lists(const uint64_t *s_out, int F, i
     static_assert(NI <= 64 && NW >= 4, "one wave scans the counts of one block");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int base = 4 * start;
-    uint32_t word[E];
-    unsigned short rank[E][4];
+    uint32_t ranks[E];   // 4 x 8 bits: the entry's rank among its wave's entries of each block
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = e * THREADS + tid;
-        word[e] = i < F ? (uint32_t)s_out[i] : 0u;
+        const uint32_t word = i < F ? (uint32_t)s_out[i] : 0u;
+        ranks[e] = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const unsigned long long m = __ballot((word[e] >> b) & 1u);
-            rank[e][b] = (unsigned short)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned long long m = __ballot((word >> b) & 1u);
+            ranks[e] |= __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << (8 * b);
             if (lane == 0) s_w[b * 64 + e * NW + w] = (uint32_t)__popcll(m);
         }
     }
@@ -566,11 +569,16 @@ __device__ __forceinline__ void emit_block_lists(const uint64_t *s_out, int F, i
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < E; ++e)
+    for (int e = 0; e < E; ++e) {
+        const int i = e * THREADS + tid;
+        if (i >= F) break;
+        const uint32_t word = (uint32_t)s_out[i];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-            if ((word[e] >> b) & 1u)
-                out.block_ids[base + b * n + (int)s_w[b * 64 + e * NW + w] + (int)rank[e][b]] = (int32_t)(word[e] >> 4);
+            if ((word >> b) & 1u)
+                out.block_ids[base + b * n + (int)s_w[b * 64 + e * NW + w] + (int)((ranks[e] >> (8 * b)) & 0xffu)] =
+                    (int32_t)(word >> 4);
+    }
     if (tid < 4) {
         const int by = bin / bin_w, bx = bin - by * bin_w;
         const int x = 2 * bx + (tid & 1), y = 2 * by + (tid >> 1);
@@ -727,6 +735,7 @@ constexpr int kSmallCap = SortCfg<256, 4>::CAP;     // 1024: one 256-thread work
 constexpr int kMediumCap = SortCfg<1024, 8>::CAP;   // 8192: 1024 threads, 80 KB LDS
 constexpr int kLargeCap = SortCfg<1024, 16>::CAP;   // 16384: 1024 threads, 144 KB LDS
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restrict__ tile_ranges,
                                                          const uint64_t *__restrict__ keys,
                                                          int32_t *__restrict__ flatten_ids,
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restri
     const int tile = tile_lo + blockIdx.x;   // the band's tiles: ranges outside it are empty (or unwritten)
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
     const bool skip = n <= 0 || (int64_t)start + n > cap;   // beyond cap: speculative overflow
-    if (blocks.block_ids && n <= kSmallCap && skip) {
+    if (SPLIT && n <= kSmallCap && skip) {
         // split frame: this kernel owns the block ranges of every bin that is not heavy -- empty ones too
         if (threadIdx.x < 4) {
             const int by = tile / bin_w, bx = tile - by * bin_w;
@@ -747,8 +756,8 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restri
         if (threadIdx.x == 0) blocks.bin_more[tile] = 0;
     }
     if (skip || n > kSmallCap) return;
-    sort_segment_lds<256, 4>(smem, keys, start, n, tile, flatten_ids, isect_ids, nullptr,
-                             blocks.block_ids ? &blocks : nullptr, bin_w);
+    sort_segment_lds<256, 4>(smem, keys, start, n, tile, flatten_ids, isect_ids, nullptr, SPLIT ? &blocks : nullptr,
+                             bin_w);
 }
 
 template <int E>
@@ -793,6 +802,7 @@ constexpr int kFrontLogNB = 10;
 static_assert((1 << kFrontLogNB) == kFrontNB, "bucket count");
 constexpr size_t kFrontLds = (size_t)kFrontCap * 8 + (size_t)kFrontNB * 4 + 64 * 4 + 16;
 
+template <bool SPLIT>
 __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__restrict__ medium,
                                                      const int32_t *__restrict__ large,
                                                      const int32_t *__restrict__ xl,
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
         const int tile = li < nm ? medium[li] : (li < nm + nl ? large[li - nm] : xl[li - nm - nl]);
         const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
         if ((int64_t)start + n > cap) {   // speculative overflow: the frame is redone (uniform)
-            if (blocks.block_ids) {       // ... but its rasteriser must find ranges it can walk
+            if (SPLIT) {       // ... but its rasteriser must find ranges it can walk
                 if (tid < 4) {
                     const int by = tile / bin_w, bx = tile - by * bin_w;
                     const int x = 2 * bx + (tid & 1), y = 2 * by + (tid >> 1);
@@ -928,7 +938,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
         for (int e = 0; e < kFrontCap / THREADS; ++e)
             if (dest[e] >= 0) s_out[dest[e]] = kk[e];
         __syncthreads();
-        if (blocks.block_ids) emit_block_lists<THREADS, kFrontCap / THREADS>(s_out, F, n, start, tile, bin_w, blocks, s_cnt);
+        if constexpr (SPLIT) emit_block_lists<THREADS, kFrontCap / THREADS>(s_out, F, n, start, tile, bin_w, blocks, s_cnt);
         else
             for (int i = tid; i < F; i += THREADS) flatten_ids[start + i] = (int32_t)(uint32_t)s_out[i];
         if (tid == 0) front_count[tile] = F;
@@ -1195,9 +1205,10 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
                                                   scales_are_log, opacities != nullptr);
     {   // also for N == 0 (one workgroup that walks nothing): the histogram row and the on-grid slot the
         // scans read must exist
+        auto kernel = pack ? k_project_hist<true> : k_project_hist<false>;
         if (p.lds_bytes > 48 * 1024)
-            if (int rc = allow_big_lds(k_project_hist)) return rc;
-        hipLaunchKernelGGL(k_project_hist, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
+            if (int rc = allow_big_lds(kernel)) return rc;
+        hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
                            quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks);
         MS_LAUNCH_CHECK();
     }
@@ -1232,11 +1243,14 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
     const int64_t max_count = spec ? 0 : host_info[1], n_medium = spec ? 0 : host_info[2],
                   n_large = spec ? 0 : host_info[3], n_xl = spec ? 0 : host_info[4];
 
-    if (p.lds_bytes > 48 * 1024)
-        if (int rc = allow_big_lds(k_isect_scatter)) return rc;
-    hipLaunchKernelGGL(k_isect_scatter, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d,
-                       radii, depths, masks, g, p.chunk, hist, tile_ranges, cap, sort_keys);
-    MS_LAUNCH_CHECK();
+    {
+        auto kernel = pack ? k_isect_scatter<true> : k_isect_scatter<false>;
+        if (p.lds_bytes > 48 * 1024)
+            if (int rc = allow_big_lds(kernel)) return rc;
+        hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
+                           g, p.chunk, hist, tile_ranges, cap, sort_keys);
+        MS_LAUNCH_CHECK();
+    }
 
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
                   "sort class thresholds out of sync");
@@ -1244,7 +1258,8 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
         // heavy tiles: sorted front only (k_tile_front); everything else as usual
         static_assert(kFrontK == kSmallCapDecl, "the front kernel takes over exactly where the small class ends");
         if (spec || n_medium + n_large + n_xl > 0) {
-            if (int rc = allow_big_lds(k_tile_front)) return rc;
+            auto front = bl.block_ids ? k_tile_front<true> : k_tile_front<false>;
+            if (int rc = allow_big_lds(front)) return rc;
             const int64_t heavy = n_medium + n_large + n_xl;
             const unsigned grid = spec ? (unsigned)min(p.T, 1024) : (unsigned)(heavy < 1024 ? heavy : 1024);
             // all surviving depths lie in the camera's (near, far): fixed order-preserving buckets
@@ -1267,14 +1282,15 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             // run asks for deeper fronts (lazy bits 1-2: front level, x2 each, up to the LDS room).
             int front_k = bl.block_ids ? 1280 : min(kFrontK * blocks_per_tile, 2048);
             front_k = min(front_k << ((lazy >> 1) & 3), kFrontCap);   // (3072: 1-3 % slower, no fewer clean-ups on the BASELINE scenes)
-            hipLaunchKernelGGL(k_tile_front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
+            hipLaunchKernelGGL(front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift,
                                front_k, bl, tile_w);
             MS_LAUNCH_CHECK();
         }
         if (p.T_local > 0)
-            hipLaunchKernelGGL(k_tile_sort_small, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
+            hipLaunchKernelGGL(bl.block_ids ? k_tile_sort_small<true> : k_tile_sort_small<false>,
+                               dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
                                sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w, bl, tile_w);
         MS_LAUNCH_CHECK();
         return MS_OK;
@@ -1302,7 +1318,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
         MS_LAUNCH_CHECK();
     }
     if (p.T_local > 0)
-        hipLaunchKernelGGL(k_tile_sort_small, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
+        hipLaunchKernelGGL(k_tile_sort_small<false>, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
                            sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w, bl, tile_w);
     MS_LAUNCH_CHECK();
     if (n_xl > 0) {  // exact mode only: a speculative frame with XL tiles is redone by the caller
