@@ -137,7 +137,7 @@ def main():
     if world == 1:
         # render_gaussians settles its binning granularity by racing the modes over a scene's first
         # frames (render.py, _BinTuner): let that finish before the W warm-up steps, untimed
-        for _ in range(16):
+        for _ in range(24):
             step()
             tuners = list(render_mod._BIN_CHOICE.values())
             if tuners and not tuners[0].queue:

@@ -138,6 +138,12 @@ int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
  * (ms_render_fwd); M and tile_ranges count the kept pairs, isect_info[6] still counts bounding
  * boxes.  The per-Gaussian reach masks stay in the workspace: the emit that follows a tight count
  * MUST pass tight = 1 (and tight = 0 after ms_isect_tiles_count or a non-tight count).
+ * Bit 2 (value 4, with bit 0, even tile_size, N < 2^28): BLOCK MASKS, what ms_render_fwd's split frames
+ * bin with.  The tile box of a Gaussian is derived from its gsplat box on the HALF-tile grid (bits 3 / 4:
+ * that grid has 2 tile_w - 1 columns / 2 tile_h - 1 rows), reach masks are kept per half-tile cell, and
+ * every emitted key carries `id << 4 | blocks` in its low word (blocks: the 2x2 half-tile blocks of
+ * the tile, bit 2 dy + dx, that hold exactly what a grid of half-size tiles would list there).  The
+ * emit that follows must pass the same bits.
  *
  * lazy != 0 on the emit calls: LAZY SORTING, also for pixel-only callers.  Tiles of more than 1024
  * entries get only their front (about the 1024 nearest entries) selected and sorted; the workspace
@@ -145,7 +151,8 @@ int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
  * depth_near / depth_far (> 0, the camera planes every surviving depth lies between) let the
  * selection use fixed depth buckets and skip a pass; 0, 0 = unknown.  Only ms_render_fwd's
  * rasteriser understands such lists (it redoes a tile whose front did not saturate its pixels);
- * pass lazy = 0 for lists that anyone else reads.  MOJOSPLAT_LAZY_SORT=0 in the environment makes
+ * pass lazy = 0 for lists that anyone else reads.  Bits 1-2 of `lazy`: front level, fronts 2^level
+ * times as deep (up to the 4096 entries of LDS room).  MOJOSPLAT_LAZY_SORT=0 in the environment makes
  * ms_render_fwd sort fully. */
 int ms_project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
                            const float *quats, const float *opacities, const float *viewmat, float fx,
@@ -237,7 +244,9 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  * intermediates.  Projection outputs, tile ranges and the sorted list live in caller-owned
  * scratch:
  *   workspace  : ms_render_workspace_bytes(N, tile_w, tile_h) bytes, fixed per (N, image);
- *   isect_buf  : ms_render_isect_bytes(M, merge) bytes, data dependent.  If it is too small
+ *   isect_buf  : ms_render_isect_bytes(M, merge) bytes, data dependent (M = host_info[0]; a split
+ *                frame -- tile_size 16, plain forward, see below -- counts the entries of its 32-px
+ *                bins and needs 28 bytes for each: keys, list words, 4 block lists).  If it is too small
  *                the call returns MS_ERR_WORKSPACE with host_info[5] = bytes needed and all
  *                M-independent work done; grow the buffer and call again with resume = 1.
  *   host_info  : HOST memory (pinned), i64[8]; receives isect_info (see
@@ -258,6 +267,12 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  *                library's own slot between BEGIN and FINISH.
  *   stage_events: NULL, or 4 hipEvent_t recorded on `stream` at: start, after projection,
  *                after binning, after rasterisation (for in-situ kernel timing).
+ * SPLIT FRAMES.  A plain forward frame (no render_alphas / last_ids, CDIM <= 4) at tile_size 16 over the
+ * whole image or a band of >= 16 tile rows is binned on 32-px bins with block masks (see `tight`), and
+ * the sort kernels cut every bin's sorted list into the lists of its four 16x16 blocks, which is what
+ * the rasteriser walks: 40 % fewer (Gaussian, bin) pairs to scatter and sort, the same pairs to
+ * rasterise, the same frame bit for bit.  MOJOSPLAT_SPLIT=0 in the environment bins such frames on
+ * 16-px tiles directly.
  * [tile_row_begin, tile_row_end) restricts binning and rasterisation to a band of tile rows
  * (0, tile_h = whole image); render_colors always addresses the FULL image.
  * Whole-image calls: no bounding box on the grid yields a ZERO image (reference render.py:73-76),

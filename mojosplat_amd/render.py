@@ -11,7 +11,6 @@ Beyond the reference: ``features`` of shape (N, K, 3) together with ``sh_degree`
 spherical-harmonic coefficients and are evaluated per view (sh.py) -- the TODO at
 render.py:83 carried out.
 """
-import time
 from typing import Optional
 
 import torch
@@ -40,13 +39,16 @@ _STAGE_HOOK = None
 #   32 / 64  plain coarse bins, every block walks its bin's whole list -- best for dense scenes of
 #       larger footprints (config 5: 1.18 / 1.08 / 0.77 ms at 16 / 32 / 64; config 4: 0.69 / 0.64 / 0.66).
 # No density rule separates these cases reliably, so the first frames of a scene (same device, N and
-# image size) are a measurement: each mode renders one warm-up frame and two timed ones (host clock
-# around a synchronised call), the fastest is kept, and the race is run again every _REPROBE_EVERY
-# frames because scenes drift.  64 px is only tried when 32 px did not already lose clearly.
+# image size) are a measurement: each mode renders one warm-up frame and _TIMED_FRAMES timed ones (a
+# pair of events on the launch stream around a synchronised call; the fastest counts), the fastest
+# mode is kept, and the race is run again every _REPROBE_EVERY frames, or as soon as a frame's
+# intersection count has moved by a quarter, because scenes drift.  64 px is only tried when 32 px did
+# not already lose clearly.
 _BIN_CHOICE = {}            # (device, N, W, H) -> _BinTuner
 _BIN_MODES = (16, 32, 64)
 _REPROBE_EVERY = 1024
-_SKIP_COARSER = 1.15        # 32 px slower than 16 px by this factor: do not try 64
+_TIMED_FRAMES = 4
+_SKIP_COARSER = 1.10        # 32 px slower than 16 px by this factor: do not try 64
 
 
 class _BinTuner:
@@ -56,8 +58,8 @@ class _BinTuner:
         self._start_race()
 
     def _start_race(self):
-        self.times = {}
-        self.queue = [(m, k > 0) for m in _BIN_MODES for k in range(3)]   # (mode, timed?)
+        self.times, self.counts = {}, {}
+        self.queue = [(m, k > 0) for m in _BIN_MODES for k in range(1 + _TIMED_FRAMES)]   # (mode, timed?)
 
     def next(self):
         """-> (bin size of this frame, whether to time it)."""
@@ -69,11 +71,21 @@ class _BinTuner:
                 return self.choice, False
         return self.queue[0]
 
-    def done(self, mode, seconds):
-        """The frame `next()` announced has been rendered (seconds: None when it was not timed)."""
-        if not self.queue or self.queue[0][0] != mode:
+    def done(self, mode, seconds, m=None):
+        """The frame `next()` announced has been rendered (seconds: None when it was not timed; m: its
+        intersection count)."""
+        if not self.queue:
+            # a different scene behind the same (device, N, image size): the count of the chosen mode has
+            # moved by more than a quarter since the race -> race again from the next frame on
+            ref = self.counts.get(mode)
+            if mode == self.choice and m is not None and ref and abs(m - ref) > 0.25 * ref:
+                self._start_race()
+            return
+        if self.queue[0][0] != mode:
             return
         self.queue.pop(0)
+        if m is not None:
+            self.counts[mode] = m
         if seconds is not None:
             self.times[mode] = min(seconds, self.times.get(mode, seconds))
         if 16 in self.times and 32 in self.times and self.times[32] > _SKIP_COARSER * self.times[16]:
@@ -144,13 +156,17 @@ def render_gaussians(
             bin_size, timed = (tile_size, False) if tuner is None else tuner.next()
             if timed:
                 torch.cuda.synchronize(means3d.device)
-                t0 = time.perf_counter()
-            img, _ = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, bin_size,
+                start, end = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                start.record()
+            img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, bin_size,
                                     stage_events=evs)
             if tuner is not None:
+                seconds = None
                 if timed:
-                    torch.cuda.synchronize(means3d.device)
-                tuner.done(bin_size, time.perf_counter() - t0 if timed else None)
+                    end.record()
+                    end.synchronize()
+                    seconds = start.elapsed_time(end) * 1e-3
+                tuner.done(bin_size, seconds, m)
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer

@@ -28,8 +28,8 @@ CFG = {
 }
 
 
-def timed(fn, iters=10, warm=2):
-    for _ in range(warm):
+def timed(fn, iters=100, warm=16):
+    for _ in range(warm):   # (render_gaussians races its binning modes over a scene's first frames)
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -94,6 +94,9 @@ def main():
             out["bands8_eq_full"] = bool(torch.equal(frame, img))
             del frame, st, img2, key, tile_of, full
             out["ms_fwd"] = round(timed(lambda: ms.render_gaussians(*g, cam, background_color=bg, backend="hip")), 3)
+            from mojosplat_amd import render as R
+            tuner = [t for k, t in R._BIN_CHOICE.items() if k[1:] == (N, W, H)][0]
+            out["bin_px"], out["race_ms"] = tuner.choice, {k: round(v * 1e3, 4) for k, v in tuner.times.items()}
             out["fps"] = round(1e3 / out["ms_fwd"], 1)
             out["GBps_alg"] = round((96 * N + (78 if fp16 else 84) * out["M"] + 12 * th * tw + 12 * H * W)
                                     / (out["ms_fwd"] * 1e-3) / 1e9, 1)

@@ -311,7 +311,7 @@ def test_frame_does_not_depend_on_the_binning_granularity(device):
     R._BIN_CHOICE.clear()
     try:
         seen = set()
-        for _ in range(12):
+        for _ in range(3 * (1 + R._TIMED_FRAMES) + 1):
             tuner = R._tuner(g[0], cam, 16)
             seen.add(tuner.next()[0])
             assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, backend="hip"), ref)

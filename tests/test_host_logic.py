@@ -195,7 +195,7 @@ def test_c_abi_argument_validation_returns_status_codes():
 
 
 def test_bin_tuner_races_the_modes_and_keeps_the_fastest():
-    """render.py's binning-granularity race: one warm-up + two timed frames per mode, 64 px skipped when
+    """render.py's binning-granularity race: one warm-up + a few timed frames per mode, 64 px skipped when
     32 px already lost clearly, re-run every _REPROBE_EVERY frames."""
     from mojosplat_amd import render as R
 
@@ -209,11 +209,22 @@ def test_bin_tuner_races_the_modes_and_keeps_the_fastest():
 
     t = R._BinTuner()
     order = race(t, {16: 1.0, 32: 0.8, 64: 0.9})
-    assert order == [(m, k > 0) for m in (16, 32, 64) for k in range(3)]
+    per_mode = 1 + R._TIMED_FRAMES
+    assert order == [(m, k > 0) for m in (16, 32, 64) for k in range(per_mode)]
     assert t.choice == 32 and t.next() == (32, False)
     t = R._BinTuner()
     order = race(t, {16: 1.0, 32: 1.5, 64: 0.1})       # 64 is never tried
-    assert [m for m, _ in order] == [16] * 3 + [32] * 3 and t.choice == 16
+    assert [m for m, _ in order] == [16] * per_mode + [32] * per_mode and t.choice == 16
+    # a frame whose intersection count has drifted from the race's restarts it
+    t2 = R._BinTuner()
+    while t2.queue:
+        mode, timed = t2.next()
+        t2.done(mode, {16: 1.0, 32: 2.0}[mode] if timed else None, 1000)
+    assert t2.choice == 16
+    t2.done(*t2.next()[:1], None, 1100)
+    assert not t2.queue
+    t2.done(*t2.next()[:1], None, 2000)
+    assert t2.queue and t2.next() == (16, False)
     # a stale done() (another mode than announced) is ignored; the race comes round again
     t.done(64, 0.0)
     assert t.choice == 16
