@@ -54,6 +54,17 @@ static int ms_split_enabled() {
     return v;
 }
 
+// most bin entries a split frame may hold (4 block-list slots each must fit int32 offsets); the
+// environment can lower it so that tests reach the restart on 16-px tiles
+static int64_t ms_split_max_entries() {
+    static const int64_t v = [] {
+        const char *e = getenv("MOJOSPLAT_SPLIT_MAX_ENTRIES");
+        const long long n = e ? atoll(e) : 0;
+        return (int64_t)(n > 0 && n < 0x1fffffffll ? n : 0x1fffffffll);
+    }();
+    return v;
+}
+
 extern "C" size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h) {
     if (tile_w <= 0 || tile_h <= 0 || (int64_t)tile_w * tile_h >= (1ll << 30)) return 0;
     return ws_layout(N, tile_w, tile_h).total;
@@ -79,7 +90,7 @@ static size_t split_isect_bytes(int64_t M) {
     return ms::align_up(m * 8, 256) + ms::align_up(m * 4, 256) + ms::align_up(m * 16, 256);
 }
 
-extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const float *scales, int scales_are_log,
                              const float *quats, const float *opacities, const void *colors,
                              int color_dtype, int CDIM, const float *viewmat, float fx, float fy,
                              float cx, float cy, int W, int H, float eps2d, float near_plane,
@@ -98,6 +109,8 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th, MS_ERR_INVALID_ARG,
                "render_fwd: bad tile row band [%d,%d) of %d", tile_row_begin, tile_row_end, th);
     const int r0 = tile_row_begin, r1 = tile_row_end;
+    // (bit 4 of host_info[7]: this frame was restarted without the split, see below; its redo must agree)
+    if (phase == MS_RENDER_RESUME && (host_info[7] & 16)) no_split = 1;
     const WsLayout L = ws_layout(N, tw, th);
     MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_fwd: workspace %zu < %zu", workspace_bytes,
                L.total);
@@ -123,7 +136,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
     // Thin bands (a rank's share of a frame cut 8 ways) stay on 16-px bins: their cost is the walk over all
     // Gaussians and the largest bin's front, which 32-px bins make longer (1080p, 9 rows: 151 vs 163 us).
     const bool split = lazy && tile_size == 16 && N > 0 && N < (1ll << 28) && r1 > r0 &&
-                       (r1 - r0 >= 16 || (r0 == 0 && r1 == th)) && ms_split_enabled();
+                       (r1 - r0 >= 16 || (r0 == 0 && r1 == th)) && !no_split && ms_split_enabled();
     const int bw = (tw + 1) / 2, bh = (th + 1) / 2, b0 = r0 / 2, b1 = (r1 + 1) / 2;
     const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0);
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
@@ -150,7 +163,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                                             split ? bin_ranges : ranges, info, (int64_t *)mirror, stream))
             return rc;
         mark(1);
-        host_info[7] = 0;
+        host_info[7] = no_split ? 16 : 0;
         if (!mirror) MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         if (sync_event) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
@@ -161,7 +174,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         const int64_t cap = split ? (isect_bytes > 768 ? (int64_t)((isect_bytes - 768) / 28) : 0)
                                   : (isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0);
         if (sync_event && isect_buf && cap > 0 && N > 0) {   // (an empty set has null inputs: exact path, M = 0)
-            const int64_t cmax = split ? 0x1fffffffll : 0x7fffffffll;
+            const int64_t cmax = split ? ms_split_max_entries() : 0x7fffffffll;
             const int64_t c = cap > cmax ? cmax : cap;
             uint64_t *keys = (uint64_t *)isect_buf;
             int32_t *ids = (int32_t *)((char *)isect_buf + ms::align_up((size_t)c * 8, 256));
@@ -193,7 +206,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                                            render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr,
                                            stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
-            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0);
+            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0);
             }
         }
         if (phase == MS_RENDER_BEGIN) return MS_OK;
@@ -206,7 +219,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         speculated = (host_info[7] & 1) != 0;
         if (speculated) {
             const int64_t cap = split ? (int64_t)((isect_bytes - 768) / 28) : (int64_t)((isect_bytes - 512) / 12);
-            const int64_t cmax = split ? 0x1fffffffll : 0x7fffffffll;
+            const int64_t cmax = split ? ms_split_max_entries() : 0x7fffffffll;
             const int64_t c = cap > cmax ? cmax : cap;
             const int64_t Ms = host_info[0];
             const bool large_ok = lazy || host_info[3] == 0 || (host_info[7] & 2);  // large class sorted iff launched
@@ -228,8 +241,12 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
         if (!speculated) { mark(2); mark(3); }
         return MS_OK;
     }
-    MS_REQUIRE(!split || M <= 0x1fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld bin entries (set MOJOSPLAT_SPLIT=0)",
-               (long long)M);
+    if (split && M > ms_split_max_entries())   // 4 M block-list slots would not fit int32: the frame again, on 16-px tiles
+        return render_fwd_impl(1, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
+                               fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, tile_row_begin,
+                               tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
+                               (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids,
+                               speculated ? nullptr : stage_events, sync_event, stream_);
     const size_t need = split ? split_isect_bytes(M) : ms_render_isect_bytes(M, n_xl > 0 && !lazy);
     host_info[5] = (int64_t)need;
     host_info[7] |= 4;  // the lists the caller may read back are in the EXACT layout (below)
@@ -267,4 +284,19 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                                    (!speculated && stage_events) ? stage_events[3] : nullptr, stream))
         return rc;
     return MS_OK;
+}
+
+extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                             const float *quats, const float *opacities, const void *colors,
+                             int color_dtype, int CDIM, const float *viewmat, float fx, float fy,
+                             float cx, float cy, int W, int H, float eps2d, float near_plane,
+                             float far_plane, int tile_size, int tile_row_begin, int tile_row_end,
+                             const float *backgrounds, void *workspace, size_t workspace_bytes, void *isect_buf,
+                             size_t isect_bytes, int64_t *host_info, int resume,
+                             float *render_colors, float *render_alphas, int32_t *last_ids,
+                             void **stage_events, void *sync_event, void *stream_) {
+    return render_fwd_impl(0, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat, fx,
+                           fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, tile_row_begin, tile_row_end,
+                           backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info, resume,
+                           render_colors, render_alphas, last_ids, stage_events, sync_event, stream_);
 }

@@ -79,6 +79,24 @@ def test_band_calls_assemble_the_full_frame(device):
     assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True).wait(), ref)
 
 
+def test_split_frames_on_bands_that_cut_through_bin_rows(device):
+    """Bands of >= 16 tile rows are split frames (32-px bins cut into block lists) even when they start
+    or end in the middle of a bin row: the bins of that row are binned whole, only the band's blocks are
+    rasterised (and cleaned up).  Thin bands run on 16-px bins.  Together: the whole-image frame."""
+    sc, cam = randscene_v1(80_000, 640, 720, ell=-2.7, seed=12, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    ref = stagewise(sc, cam, bg, 16)
+    th = -(-cam.H // 16)
+    assert th == 45
+    for bands in ([(0, 17), (17, 34), (34, 45)], [(0, 21), (21, 45)], [(0, 16), (16, 33), (33, 45)]):
+        frame = torch.full((cam.H, cam.W, 3), -1.0, device=device)
+        for _ in range(2):   # exact path, then sync-free
+            for band in bands:
+                _fused.render_fwd_hip(*g, cam, bg, 16, row_range=band, out=frame)
+            assert torch.equal(frame, ref), bands
+
+
 def test_band_call_reports_frame_level_on_grid_count(device):
     """isect_info[6]: Gaussians touching the FULL tile grid, the same from every band (also an empty
     one) -- what lets each rank apply the zeros-image rule without a collective."""
@@ -320,3 +338,31 @@ def test_frame_does_not_depend_on_the_binning_granularity(device):
     finally:
         R._BIN_CHOICE.clear()
         _fused._state.clear()
+
+
+def test_split_frame_restarts_on_16px_tiles_when_its_bins_hold_too_much(device):
+    """A split frame whose 32-px bins hold more entries than 4 block-list slots each can index (2^29;
+    lowered to 1000 through the environment here, in a fresh process since the library reads it once)
+    is started again on 16-px tiles -- also across the grow-the-buffer redo -- and gives the same frame."""
+    import os, subprocess, sys
+    code = """
+import torch, mojosplat_amd as ms
+from mojosplat_amd import _fused
+from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
+dev = torch.device("cuda", 0)
+sc, cam = randscene_v1(30000, 480, 320, ell=-2.8, seed=77, device=dev)
+bg = torch.tensor(BACKGROUND_V1, device=dev)
+g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, cam.H, cam.W, 16, backend="hip")
+ref = ms.rasterize_gaussians(m2, con, g[4], g[3], bg, ranges, ids, cam, tile_size=16, backend="hip")
+for i in range(4):
+    img, m = _fused.render_fwd_hip(*g, cam, bg, 16)
+    assert torch.equal(img, ref), i
+    assert m > 1000 and int(_fused._dev_state(dev, 0)["host"][7]) & 16, (i, m)
+print("OK")
+"""
+    env = dict(os.environ, MOJOSPLAT_SPLIT_MAX_ENTRIES="1000")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
