@@ -873,7 +873,21 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
             const uint32_t b = (d > kmin ? d - kmin : 0u) >> shift;
             return (int)min(b, (uint32_t)(kFrontNB - 1));
         };
-        for (int i = tid; i < n; i += THREADS) atomicAdd(&s_cnt[bucket_of(kin[i])], 1u);
+        // (both passes over the keys fetch kLoads keys per thread before touching them: one memory round trip
+        // per kLoads * THREADS keys instead of one per THREADS -- the kernel lasts as long as its largest
+        // list takes, and that was 2 x n / THREADS dependent round trips)
+        constexpr int kLoads = SPLIT ? 8 : 4;   // (4: the plain variant stays within 64 VGPRs, 8 waves/SIMD)
+        for (int i0 = 0; i0 < n; i0 += kLoads * THREADS) {
+            uint32_t d[kLoads];
+#pragma unroll
+            for (int u = 0; u < kLoads; ++u) {
+                const int i = i0 + u * THREADS + tid;
+                d[u] = (uint32_t)(kin[min(i, n - 1)] >> 32);   // (unconditional: the loads of a batch issue together)
+            }
+#pragma unroll
+            for (int u = 0; u < kLoads; ++u)
+                if (i0 + u * THREADS + tid < n) atomicAdd(&s_cnt[bucket_of((uint64_t)d[u] << 32)], 1u);
+        }
         __syncthreads();
         // scan: thread t owns buckets 2t, 2t+1
         const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
@@ -910,10 +924,19 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
         __syncthreads();
         const int bstar = s_sel[0], F = s_sel[1];
         // C. select
-        for (int i = tid; i < n; i += THREADS) {
-            const uint64_t k = kin[i];
-            const int b = bucket_of(k);
-            if (b <= bstar) s_out[atomicAdd(&s_cnt[b], 1u)] = k;   // s_cnt[b] becomes the END of bucket b
+        for (int i0 = 0; i0 < n; i0 += kLoads * THREADS) {
+            uint64_t k[kLoads];
+#pragma unroll
+            for (int u = 0; u < kLoads; ++u) {
+                const int i = i0 + u * THREADS + tid;
+                k[u] = kin[min(i, n - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kLoads; ++u) {
+                const int b = bucket_of(k[u]);
+                if (i0 + u * THREADS + tid < n && b <= bstar)
+                    s_out[atomicAdd(&s_cnt[b], 1u)] = k[u];   // s_cnt[b] becomes the END of bucket b
+            }
         }
         __syncthreads();
         // rank inside the bucket; keys are distinct, so ranks are a permutation

@@ -10,7 +10,8 @@ for wl in sys.argv[1:] or ["cfg3"]:
     N, W, H, ell, fp16 = WORKLOADS[wl]
     sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=dev)
     m2, con, dep, rad = ms.project_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], cam, backend="hip")
-    ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, H, W, 16, backend="hip")
+    ts = int(os.environ.get("TS", "16"))
+    ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, H, W, ts, backend="hip")
     n = (ranges[..., 1] - ranges[..., 0]).flatten().float()
     qs = torch.tensor([0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0], device=dev)
     print(wl, "tiles", n.numel(), "M", int(n.sum()), "quantiles", [int(v) for v in torch.quantile(n, qs)],
