@@ -478,7 +478,8 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
     Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
-    const int32_t *__restrict__ tile_ranges, int64_t M, uint64_t *__restrict__ keys) {
+    const int32_t *__restrict__ tile_ranges, int64_t M, uint64_t *__restrict__ keys,
+    uint32_t *__restrict__ wg_depth) {
     extern __shared__ uint32_t s_cur[];
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     const int band0 = g.row_begin * g.tw;
@@ -487,12 +488,32 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
         s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
+    // depth bits (order preserving for the positive depths that survive) of everything this workgroup
+    // emits: k_tile_front spreads its buckets over the frame's range
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
     for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, [&](int t, int64_t i, int q) {
         const uint32_t slot = atomicAdd(&s_cur[t], 1u);
         const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
-        const uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | low;
+        const uint32_t dbits = __float_as_uint(depths[i]);
+        dmin = min(dmin, dbits);
+        dmax = max(dmax, dbits);
+        const uint64_t key = ((uint64_t)dbits << 32) | low;
         if ((int64_t)slot < M) keys[slot] = key;
     });
+    if (wg_depth) {
+        uint32_t *s_depth = s_cur + T_local + 1;   // (the 16 spare bytes every binning kernel's LDS block ends with)
+        __syncthreads();                           // (the cursors are done with)
+        if (threadIdx.x == 0) { s_depth[0] = 0xffffffffu; s_depth[1] = 0u; }
+        __syncthreads();
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d));
+            dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_depth[0], dmin); atomicMax(&s_depth[1], dmax); }
+        __syncthreads();
+        if (threadIdx.x == 0) { wg_depth[2 * blockIdx.x] = s_depth[0]; wg_depth[2 * blockIdx.x + 1] = s_depth[1]; }
+    }
 }
 
 // ---- per-tile sort in LDS -------------------------------------------------------------
@@ -812,7 +833,8 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
                                                      int32_t *__restrict__ flatten_ids,
                                                      int32_t *__restrict__ front_count, int64_t cap,
                                                      uint32_t fixed_min, int fixed_shift, int front_k,
-                                                     ms::BlockLists blocks, int bin_w) {
+                                                     ms::BlockLists blocks, int bin_w,
+                                                     const uint32_t *__restrict__ wg_depth, int n_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem_dyn);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + kFrontCap);
@@ -823,6 +845,33 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
     const int nm = info_dev ? (int)info_dev[2] : nm_host, nl = info_dev ? (int)info_dev[3] : nl_host;
     const int nx = info_dev ? (int)info_dev[4] : nx_host;
     const int total = nm + nl + nx;
+    if ((int)blockIdx.x >= total) return;   // (uniform; a sync-free launch is sized for the worst case)
+    // The frame's own depth range (per-workgroup min / max left by the scatter) beats the camera planes:
+    // the scene fills a fraction of (near, far), and buckets that are several times finer make the
+    // ranking inside a bucket as many times shorter.
+    if (wg_depth) {
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        for (int j = tid; j < n_wg; j += THREADS) {
+            lo = min(lo, wg_depth[2 * j]);
+            hi = max(hi, wg_depth[2 * j + 1]);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+        }
+        if (lane == 0) { s_red[w] = lo; s_red[16 + w] = hi; }
+        __syncthreads();
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) { lo = min(lo, s_red[ww]); hi = max(hi, s_red[16 + ww]); }
+        __syncthreads();
+        if (hi >= lo) {
+            const uint32_t span = hi - lo;
+            const int bits = span ? 32 - __clz(span) : 0;
+            fixed_min = lo;
+            fixed_shift = max(0, bits - kFrontLogNB);
+        }
+    }
     for (int li = blockIdx.x; li < total; li += gridDim.x) {
         const int tile = li < nm ? medium[li] : (li < nm + nl ? large[li - nm] : xl[li - nm - nl]);
         const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
@@ -1046,7 +1095,7 @@ struct Plan {
     int T, T_local;
     size_t lds_bytes;
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
-        off_redo_list, off_redo_count, total;
+        off_redo_list, off_redo_count, off_depth_wg, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -1071,6 +1120,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_redo_flag = o;  o += ms::align_up((size_t)p.T * 4, 256);  //   tiles whose front did not saturate them
     p.off_redo_list = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_redo_count = o; o += 256;
+    p.off_depth_wg = o;   o += ms::align_up((size_t)kMaxG * 8, 256);   // per-workgroup depth-bit min / max (k_isect_scatter)
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -1271,7 +1321,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
-                           g, p.chunk, hist, tile_ranges, cap, sort_keys);
+                           g, p.chunk, hist, tile_ranges, cap, sort_keys, lazy ? (uint32_t *)(ws + p.off_depth_wg) : nullptr);
         MS_LAUNCH_CHECK();
     }
 
@@ -1308,7 +1358,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             hipLaunchKernelGGL(front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift,
-                               front_k, bl, tile_w);
+                               front_k, bl, tile_w, (const uint32_t *)(ws + p.off_depth_wg), p.G);
             MS_LAUNCH_CHECK();
         }
         if (p.T_local > 0)
