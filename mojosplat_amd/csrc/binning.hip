@@ -766,8 +766,9 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(const int32_t *__restri
     const int tile = tile_lo + blockIdx.x;   // the band's tiles: ranges outside it are empty (or unwritten)
     const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
     const bool skip = n <= 0 || (int64_t)start + n > cap;   // beyond cap: speculative overflow
-    if (SPLIT && n <= kSmallCap && skip) {
-        // split frame: this kernel owns the block ranges of every bin that is not heavy -- empty ones too
+    if (SPLIT && (skip || n > kSmallCap)) {
+        // split frame: empty ranges for every bin this kernel does not sort (the front kernel, launched after
+        // it, overwrites those of the heavy bins)
         if (threadIdx.x < 4) {
             const int by = tile / bin_w, bx = tile - by * bin_w;
             const int x = 2 * bx + (threadIdx.x & 1), y = 2 * by + (threadIdx.x >> 1);
@@ -1327,6 +1328,14 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
 
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
                   "sort class thresholds out of sync");
+    // Split frames: the small-class kernel goes FIRST and writes empty block ranges for every bin it does not
+    // sort itself; the front kernel, launched after it, overwrites those of the heavy bins it reaches.  The
+    // rasteriser must never walk unwritten ranges, whatever a sync-free frame turns out to hold.
+    if (bl.block_ids && p.T_local > 0) {
+        hipLaunchKernelGGL(k_tile_sort_small<true>, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
+                           sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w, bl, tile_w);
+        MS_LAUNCH_CHECK();
+    }
     if (lazy) {
         // heavy tiles: sorted front only (k_tile_front); everything else as usual
         static_assert(kFrontK == kSmallCapDecl, "the front kernel takes over exactly where the small class ends");
@@ -1361,9 +1370,8 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                                front_k, bl, tile_w, (const uint32_t *)(ws + p.off_depth_wg), p.G);
             MS_LAUNCH_CHECK();
         }
-        if (p.T_local > 0)
-            hipLaunchKernelGGL(bl.block_ids ? k_tile_sort_small<true> : k_tile_sort_small<false>,
-                               dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
+        if (p.T_local > 0 && !bl.block_ids)
+            hipLaunchKernelGGL(k_tile_sort_small<false>, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
                                sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w, bl, tile_w);
         MS_LAUNCH_CHECK();
         return MS_OK;
@@ -1462,8 +1470,8 @@ int ms::isect_emit_bins(int64_t N, const float *means2d, const int32_t *radii, c
                         const int32_t *bin_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
                         int flags, int lazy, float depth_near, float depth_far, uint64_t *sort_keys,
                         const ms::BlockLists *out, void *stream_) {
-    MS_REQUIRE(N > 0 && cap > 0 && cap <= 0x1fffffffll && (info_dev || host_info), MS_ERR_INVALID_ARG,
-               "isect_emit_bins: bad N / capacity / info");
+    MS_REQUIRE(N > 0 && cap > 0 && cap <= 0x1fffffffll && (info_dev || host_info) && (lazy & 1), MS_ERR_INVALID_ARG,
+               "isect_emit_bins: bad N / capacity / info (block lists come from lazily sorted bins only)");
     if (int rc = check_grid(32, bin_w, bin_h, row_begin, row_end)) return rc;
     MS_REQUIRE(workspace && bin_ranges && means2d && radii && depths && sort_keys && out && out->block_ranges &&
                    out->block_ids && out->bin_more,
