@@ -95,6 +95,16 @@ def test_split_frames_on_bands_that_cut_through_bin_rows(device):
             for band in bands:
                 _fused.render_fwd_hip(*g, cam, bg, 16, row_range=band, out=frame)
             assert torch.equal(frame, ref), bands
+    # the same through the pipelined multi-GPU entry point (each rank's band on a lane stream, two frames
+    # in flight), rehearsed rank by rank on this one GPU
+    from mojosplat_amd.distributed import band_plan, render_gaussians_sharded
+    for world in (2, 3):
+        rows, bands = band_plan(th, world)
+        for r, (r0, r1) in enumerate(bands):
+            a = render_gaussians_sharded(*g, cam, background_color=bg, async_op=True, rehearse=(r, world))
+            b = render_gaussians_sharded(*g, cam, background_color=bg, async_op=True, rehearse=(r, world))
+            y0, y1 = r0 * 16, min(r1 * 16, cam.H)
+            assert torch.equal(a.wait()[y0:y1], ref[y0:y1]) and torch.equal(b.wait()[y0:y1], ref[y0:y1]), (world, r)
 
 
 def test_band_call_reports_frame_level_on_grid_count(device):
