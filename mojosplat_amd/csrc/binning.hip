@@ -819,8 +819,8 @@ __global__ __launch_bounds__(1024, (E <= 8 ? 8 : 4)) void k_tile_sort_list(const
 constexpr int kFrontK = 1024;
 constexpr int kFrontCap = 4096;   // LDS room for selected keys (32 KB)
 constexpr int kFrontThreads = 512;           // more workgroups in flight than with 1024 (heavy tiles are latency bound)
-constexpr int kFrontNB = 2 * kFrontThreads;  // two buckets per thread in the scan
-constexpr int kFrontLogNB = 10;
+constexpr int kFrontNB = 4 * kFrontThreads;  // four buckets per thread in the scan
+constexpr int kFrontLogNB = 11;
 static_assert((1 << kFrontLogNB) == kFrontNB, "bucket count");
 constexpr size_t kFrontLds = (size_t)kFrontCap * 8 + (size_t)kFrontNB * 4 + 64 * 4 + 16;
 
@@ -939,9 +939,12 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
                 if (i0 + u * THREADS + tid < n) atomicAdd(&s_cnt[bucket_of((uint64_t)d[u] << 32)], 1u);
         }
         __syncthreads();
-        // scan: thread t owns buckets 2t, 2t+1
-        const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-        uint32_t incl = c0 + c1;
+        // scan: thread t owns kBpt consecutive buckets
+        constexpr int kBpt = kFrontNB / THREADS;
+        uint32_t c[kBpt], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kBpt; ++j) { c[j] = s_cnt[kBpt * tid + j]; sum += c[j]; }
+        uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
@@ -951,26 +954,25 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
         if (lane == 63) s_red[w] = incl;
         if (tid == 0) { s_sel[0] = -1; s_sel[1] = 0; }
         __syncthreads();
-        uint32_t run = incl - (c0 + c1);
+        uint32_t run = incl - sum;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww)
             if (ww < w) run += s_red[ww];
-        const uint32_t e0 = run, e1 = run + c0, i1 = e1 + c1;   // exclusive prefixes of the two buckets, inclusive of the 2nd
         // b* = the bucket whose inclusive prefix first reaches kFrontK (n > kFrontK, so it exists);
         // if that would overflow the LDS room, stop one bucket earlier (possibly with nothing:
         // >= kFrontCap entries at one depth -- the clean-up kernel takes such a tile)
         // (front_k: kFrontK per 16x16 block of the tile; a tile shorter than that is selected whole)
         const uint32_t want = min((uint32_t)front_k, (uint32_t)n);
-        if (c0 && e0 < want && e1 >= want) {
-            if (e1 <= (uint32_t)kFrontCap) { s_sel[0] = 2 * tid; s_sel[1] = (int)e1; }
-            else { s_sel[0] = 2 * tid - 1; s_sel[1] = (int)e0; }
+#pragma unroll
+        for (int j = 0; j < kBpt; ++j) {
+            const uint32_t e = run, i = run + c[j];   // exclusive / inclusive prefix of bucket kBpt * tid + j
+            if (c[j] && e < want && i >= want) {
+                if (i <= (uint32_t)kFrontCap) { s_sel[0] = kBpt * tid + j; s_sel[1] = (int)i; }
+                else { s_sel[0] = kBpt * tid + j - 1; s_sel[1] = (int)e; }
+            }
+            s_cnt[kBpt * tid + j] = e;
+            run = i;
         }
-        if (c1 && e1 < want && i1 >= want) {
-            if (i1 <= (uint32_t)kFrontCap) { s_sel[0] = 2 * tid + 1; s_sel[1] = (int)i1; }
-            else { s_sel[0] = 2 * tid; s_sel[1] = (int)e1; }
-        }
-        s_cnt[2 * tid] = e0;
-        s_cnt[2 * tid + 1] = e1;
         __syncthreads();
         const int bstar = s_sel[0], F = s_sel[1];
         // C. select
