@@ -1345,7 +1345,15 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             auto front = bl.block_ids ? k_tile_front<true> : k_tile_front<false>;
             if (int rc = allow_big_lds(front)) return rc;
             const int64_t heavy = n_medium + n_large + n_xl;
-            const unsigned grid = spec ? (unsigned)min(p.T, 1024) : (unsigned)(heavy < 1024 ? heavy : 1024);
+            // (sync-free frame: the previous frame's heavy-tile count sizes the launch; the kernel strides over
+            // the list, so a low guess only costs parallelism)
+            int64_t guess = 1024;
+            if (spec && host_info) {
+                const int64_t prev_heavy = host_info[2] + host_info[3] + host_info[4];
+                guess = prev_heavy > 0 ? prev_heavy + prev_heavy / 4 + 16 : 1024;
+            }
+            const unsigned grid = spec ? (unsigned)min((int64_t)min(p.T, 1024), guess)
+                                       : (unsigned)(heavy < 1024 ? heavy : 1024);
             // all surviving depths lie in the camera's (near, far): fixed order-preserving buckets
             uint32_t fixed_min = 0;
             int fixed_shift = -1;
