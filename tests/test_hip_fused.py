@@ -262,6 +262,32 @@ def test_fused_path_fuzz_against_stagewise(device, seed):
     _fused._state.clear()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_row_bands_fuzz_against_stagewise(device, seed):
+    """Random scenes cut into random tile-row bands (1-5 of them, any heights: split frames on bands that
+    start or end inside a bin row, thin bands on 16-px bins, one-row bands), every band rendered into one
+    framebuffer, twice (exact, then sync-free): the per-stage frame, bit for bit."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    r = lambda lo, hi: lo + (hi - lo) * torch.rand(1, generator=g).item()
+    N = int(10 ** r(3.0, 5.0))
+    W, H = int(r(100, 800)), int(r(260, 900))
+    sc, cam = randscene_v1(N, W, H, ell=r(-4.0, -2.0), seed=100 + seed, device=device)
+    sc["opacities"] = (sc["opacities"] * r(0.05, 1.0)).clamp(max=1.0)
+    bg = torch.tensor([r(0, 1), r(0, 1), r(0, 1)], device=device)
+    want = stagewise(sc, cam, bg, 16)
+    th = -(-H // 16)
+    k = 1 + int(r(0, 4.999))
+    cuts = sorted({0, th, *[int(r(1, th)) for _ in range(k - 1)]})
+    bands = list(zip(cuts[:-1], cuts[1:]))
+    args = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    frame = torch.full((H, W, 3), -1.0, device=device)
+    for _ in range(2):
+        for band in bands:
+            _fused.render_fwd_hip(*args, cam, bg, 16, row_range=band, out=frame)
+        assert torch.equal(frame, want), (N, W, H, bands)
+    _fused._state.clear()
+
+
 def test_fused_path_edge_cases(device):
     """Empty input, a single screen-filling Gaussian (its box exceeds the 64-tile reach mask and is
     walked by whole waves), 1 / 4 / 8 colour channels (lazy sorting only exists for <= 4),
