@@ -23,6 +23,11 @@
 //   k_tile_sort_list  work lists of tiles with <= 8192 (74 KB LDS, two per CU) and <= 16384
 //                     entries (136 KB); fixed-size persistent grids on sync-free frames
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
+//   k_tile_front      lazily sorted frames (ms_render_fwd): only the nearest ~1024 entries of a heavy tile
+//                     are selected and sorted; the rasteriser flags tiles whose pixels outlive them
+//   <PACK> / <SPLIT>  kernel variants of split frames: 32-px bins whose keys carry the 4 block bits of
+//                     their entry and whose sorted lists leave the sort kernels as four 16x16-block
+//                     lists (emit_block_lists)
 #include <string.h>
 
 #include "project_device.hpp"
