@@ -160,8 +160,9 @@ class _Frame:
         heavy = int(host[2]) + int(host[3]) + int(host[4])
         if not self.own:
             same_shape = st.get("shape") == self.shape
-            if not same_shape:
-                st["full_sort"], st["front_level"] = False, 0
+            memo = st.setdefault("learnt", {})   # shape -> (full_sort, front_level): a lane that alternates between
+            if not same_shape:                   # shapes (render.py's race between grids) does not learn them anew
+                st["full_sort"], st["front_level"] = memo.get(self.shape, (False, 0))
             elif (rc == 0 and not (int(host[7]) & 4) and int(host[5]) > 0 and not st.get("full_sort")
                   and st.get("prev_level") == st.get("front_level", 0)):
                 if int(host[5]) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
@@ -169,6 +170,9 @@ class _Frame:
                 else:
                     st["front_level"] = st.get("front_level", 0) + 1
             st["shape"], st["prev_level"] = self.shape, (self.level if not self.mode & FULL_SORT else None)
+            memo[self.shape] = (bool(st.get("full_sort")), int(st.get("front_level", 0)))
+            if len(memo) > 64:
+                memo.pop(next(iter(memo)))
         lazy = LAZY_SORT and not self.own and self.head[8] <= 4 and not st.get("full_sort")
         st["speculate"] = lazy or int(host[4]) == 0
         if info is not None:
@@ -201,6 +205,15 @@ class _Frame:
             ids_off = align(8 * cap)
         ids = view(isect, ids_off, M, torch.int32, (M,)) if M > 0 else torch.empty(0, dtype=torch.int32, device=self.dev)
         return means2d, conics, radii, ranges, ids
+
+
+def forget_learning(dev):
+    """Drop what the lanes of `dev` have learnt about sorting modes (full sorts / front levels per frame
+    shape): called when the scene behind a shape has visibly changed."""
+    for (d, _), st in _state.items():
+        if d == dev and not st.get("busy"):
+            st.pop("learnt", None)
+            st["full_sort"], st["front_level"], st["shape"] = False, 0, None
 
 
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,

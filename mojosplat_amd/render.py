@@ -73,25 +73,28 @@ class _BinTuner:
 
     def done(self, mode, seconds, m=None):
         """The frame `next()` announced has been rendered (seconds: None when it was not timed; m: its
-        intersection count)."""
+        (intersection count, frame kind)).  -> True when the scene has drifted and a new race starts."""
         if not self.queue:
             # a different scene behind the same (device, N, image size): the count of the chosen mode has
-            # moved by more than a quarter since the race -> race again from the next frame on
-            ref = self.counts.get(mode)
-            if mode == self.choice and m is not None and ref and abs(m - ref) > 0.25 * ref:
-                self._start_race()
-            return
+            # moved by more than a quarter since it was first seen -> race again from the next frame on.
+            # (`m` = (count, kind of frame): a lane that falls back from lazily sorted 32-px bins to fully
+            # sorted 16-px tiles counts different things; like is compared with like.)
+            if mode == self.choice and m is not None:
+                ref = self.counts.setdefault((mode, m[1]), m[0])
+                if ref and abs(m[0] - ref) > 0.25 * ref:
+                    self._start_race()
+                    return True
+            return False
         if self.queue[0][0] != mode:
-            return
+            return False
         self.queue.pop(0)
-        if m is not None:
-            self.counts[mode] = m
         if seconds is not None:
             self.times[mode] = min(seconds, self.times.get(mode, seconds))
         if 16 in self.times and 32 in self.times and self.times[32] > _SKIP_COARSER * self.times[16]:
             self.queue = [q for q in self.queue if q[0] != 64]
         if not self.queue:
             self.choice = min(self.times, key=self.times.get)
+        return False
 
 
 def _tuner(means3d, camera, tile_size):
@@ -158,15 +161,18 @@ def render_gaussians(
                 torch.cuda.synchronize(means3d.device)
                 start, end = (torch.cuda.Event(enable_timing=True) for _ in range(2))
                 start.record()
+            info = {}
             img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, bin_size,
-                                    stage_events=evs)
+                                    stage_events=evs, info=info)
             if tuner is not None:
                 seconds = None
                 if timed:
                     end.record()
                     end.synchronize()
                     seconds = start.elapsed_time(end) * 1e-3
-                tuner.done(bin_size, seconds, m)
+                if tuner.done(bin_size, seconds, (m, info["flags"] & 8)):
+                    from ._fused import forget_learning
+                    forget_learning(means3d.device)   # a new scene: the lanes' sorting modes are re-learnt too
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer

@@ -238,6 +238,32 @@ def test_lazy_front_levels(device, default_grid_only):
     _fused._state.clear()
 
 
+def test_binning_race_settles_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
+    """A pile of faint Gaussians: the lazily sorted split frame fails its fronts and the lane falls back to
+    full sorts on 16-px tiles, which count other things than 32-px bins do.  The race between the binning
+    grids must run once all the same (its drift detector compares like with like, and a lane keeps what it
+    learnt about a grid while the race visits the others), every frame exact."""
+    from mojosplat_amd import render as R
+    sc, cam = _stack_scene(4000, 4.0, 6.0, 0.005, device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    ref = stagewise(sc, cam, bg, 16)
+    _fused._state.clear()
+    R._BIN_CHOICE.clear()
+    races = []
+    start = R._BinTuner._start_race
+    try:
+        R._BinTuner._start_race = lambda self: (races.append(1), start(self))[1]
+        for _ in range(60):
+            assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, backend="hip"), ref)
+        (tuner,) = R._BIN_CHOICE.values()
+        assert len(races) == 1 and not tuner.queue, len(races)
+    finally:
+        R._BinTuner._start_race = start
+        R._BIN_CHOICE.clear()
+        _fused._state.clear()
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_fused_path_fuzz_against_stagewise(device, seed):
     """Random scenes through every shortcut of the fused path at once -- tight binning, lazily sorted

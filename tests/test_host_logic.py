@@ -219,11 +219,13 @@ def test_bin_tuner_races_the_modes_and_keeps_the_fastest():
     t2 = R._BinTuner()
     while t2.queue:
         mode, timed = t2.next()
-        t2.done(mode, {16: 1.0, 32: 2.0}[mode] if timed else None, 1000)
+        t2.done(mode, {16: 1.0, 32: 2.0}[mode] if timed else None, (1000, 8))
     assert t2.choice == 16
-    t2.done(*t2.next()[:1], None, 1100)
+    assert not t2.done(*t2.next()[:1], None, (1000, 8)) and not t2.done(*t2.next()[:1], None, (1100, 8))
     assert not t2.queue
-    t2.done(*t2.next()[:1], None, 2000)
+    # another kind of frame (the lane fell back to full sorts on 16-px tiles) counts something else: no drift
+    assert not t2.done(*t2.next()[:1], None, (1700, 0)) and not t2.queue
+    assert t2.done(*t2.next()[:1], None, (2000, 8))
     assert t2.queue and t2.next() == (16, False)
     # a stale done() (another mode than announced) is ignored; the race comes round again
     t.done(64, 0.0)
