@@ -11,6 +11,7 @@ Beyond the reference: ``features`` of shape (N, K, 3) together with ``sh_degree`
 spherical-harmonic coefficients and are evaluated per view (sh.py) -- the TODO at
 render.py:83 carried out.
 """
+import math
 from typing import Optional
 
 import torch
@@ -44,7 +45,7 @@ _STAGE_HOOK = None
 # mode is kept, and the race is run again every _REPROBE_EVERY frames, or as soon as a frame's
 # intersection count has moved by a quarter, because scenes drift.  64 px is only tried when 32 px did
 # not already lose clearly.
-_BIN_CHOICE = {}            # (device, N, W, H) -> _BinTuner
+_BIN_CHOICE = {}            # (device, N to ~9 %, W, H) -> _BinTuner
 _BIN_MODES = (16, 32, 64)
 _REPROBE_EVERY = 1024
 _TIMED_FRAMES = 4
@@ -100,10 +101,21 @@ class _BinTuner:
 def _tuner(means3d, camera, tile_size):
     if tile_size != TILE_SIZE:
         return None         # an explicit non-default tile size is honoured as given
-    key = (means3d.device, means3d.shape[0], camera.W, camera.H)
+    # (scene sizes within ~9 % of each other share a race: a stream of frames whose N creeps must not race
+    # anew on every frame; the drift detector takes care of real changes)
+    n = means3d.shape[0]
+    key = (means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H)
     t = _BIN_CHOICE.get(key)
     if t is None:
+        if len(_BIN_CHOICE) >= 64:
+            _BIN_CHOICE.pop(next(iter(_BIN_CHOICE)))
         t = _BIN_CHOICE[key] = _BinTuner()
+        # a scene that has grown or shrunk into the next size class starts from its neighbour's verdict
+        # (the next scheduled race, or the drift detector, revisits it)
+        near = [o for k, o in _BIN_CHOICE.items() if o is not t and o.choice is not None and not o.queue
+                and (k[0], k[2], k[3]) == (key[0], key[2], key[3]) and abs(k[1] - key[1]) <= 3]
+        if near:
+            t.choice, t.times, t.queue = near[-1].choice, dict(near[-1].times), []
     return t
 
 

@@ -95,7 +95,7 @@ def main():
             del frame, st, img2, key, tile_of, full
             out["ms_fwd"] = round(timed(lambda: ms.render_gaussians(*g, cam, background_color=bg, backend="hip")), 3)
             from mojosplat_amd import render as R
-            tuner = [t for k, t in R._BIN_CHOICE.items() if k[1:] == (N, W, H)][0]
+            tuner = R._tuner(g[0], cam, 16)
             out["bin_px"], out["race_ms"] = tuner.choice, {k: round(v * 1e3, 4) for k, v in tuner.times.items()}
             out["fps"] = round(1e3 / out["ms_fwd"], 1)
             out["GBps_alg"] = round((96 * N + (78 if fp16 else 84) * out["M"] + 12 * th * tw + 12 * H * W)
