@@ -238,6 +238,21 @@ def test_lazy_front_levels(device, default_grid_only):
     _fused._state.clear()
 
 
+@pytest.mark.parametrize("n,z_hi,opacity", [(4000, 6.0, 0.005), (6000, 4.0, 0.004)])
+def test_clean_up_pass_with_fp16_colours(device, default_grid_only, n, z_hi, opacity):
+    """The per-bin clean-up kernel of a split frame in its fp16-colour variant (fp32 accumulation as everywhere)."""
+    sc, cam = _stack_scene(n, 4.0, z_hi, opacity, device)
+    sc["features"] = sc["features"].half()
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    ref = stagewise(sc, cam, bg.half(), 16)
+    _fused._state.clear()
+    for _ in range(3):
+        img = ms.render_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"], cam,
+                                  background_color=bg.half(), backend="hip")
+        assert torch.equal(img, ref)
+    _fused._state.clear()
+
+
 def test_binning_race_settles_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
     """A pile of faint Gaussians: the lazily sorted split frame fails its fronts and the lane falls back to
     full sorts on 16-px tiles, which count other things than 32-px bins do.  The race between the binning
