@@ -49,6 +49,7 @@ _BIN_CHOICE = {}            # (device, N to ~9 %, W, H) -> _BinTuner
 _BIN_MODES = (16, 32, 64)
 _REPROBE_EVERY = 1024
 _TIMED_FRAMES = 4
+_MIN_SETTLED = 64           # frames a verdict stands before a drifting count may start the next race
 _SKIP_COARSER = 1.10        # 32 px slower than 16 px by this factor: do not try 64
 
 
@@ -59,7 +60,7 @@ class _BinTuner:
         self._start_race()
 
     def _start_race(self):
-        self.times, self.counts = {}, {}
+        self.times, self.counts, self.settled = {}, {}, 0
         self.queue = [(m, k > 0) for m in _BIN_MODES for k in range(1 + _TIMED_FRAMES)]   # (mode, timed?)
 
     def next(self):
@@ -80,9 +81,13 @@ class _BinTuner:
             # moved by more than a quarter since it was first seen -> race again from the next frame on.
             # (`m` = (count, kind of frame): a lane that falls back from lazily sorted 32-px bins to fully
             # sorted 16-px tiles counts different things; like is compared with like.)
+            self.settled += 1
             if mode == self.choice and m is not None:
                 ref = self.counts.setdefault((mode, m[1]), m[0])
                 if ref and abs(m[0] - ref) > 0.25 * ref:
+                    if self.settled < _MIN_SETTLED:   # two scenes taking turns behind one key: do not race on
+                        self.counts[(mode, m[1])] = m[0]   # every switch; follow the count instead
+                        return False
                     self._start_race()
                     return True
             return False
