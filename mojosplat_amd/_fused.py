@@ -8,6 +8,7 @@ needs more).  The per-stage entry points stay available for callers that want th
 intermediates (project_gaussians / bin_gaussians_to_tiles / rasterize_gaussians).
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -40,6 +41,8 @@ def _grow(st, key, nbytes, dev, slack=1.0):
             torch.cuda.synchronize(dev)
         buf = torch.empty(int(nbytes * slack) + 256, dtype=torch.uint8, device=dev)
         st[key] = buf
+        if key == "ws":
+            st["shape"] = None   # fresh memory: the clean-up count the next frame reports is garbage
     return buf
 
 
@@ -90,8 +93,9 @@ class _Frame:
             ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
         self.ws, self.grid = ws, (N, tw, th)
         r0, r1 = (0, th) if row_range is None else row_range
-        # what the lane's sorting mode (below) was learnt on: scene size, grid and band
-        self.shape = (N, tw, th, r0, r1)
+        # what the lane's sorting mode (below) was learnt on: scene size class (N to ~9 %: the clean-up count
+        # the library reports one frame later lives at an offset that depends on the grid only), grid and band
+        self.shape = (round(math.log2(N) * 8) if N > 0 else -1, tw, th, r0, r1)
         # sorting mode of this frame, fixed for both of its halves: lazily sorted fronts of the lane's
         # current depth level, or full sorts once the lane has given up on them
         self.level = int(st.get("front_level", 0))

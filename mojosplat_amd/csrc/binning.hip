@@ -1132,12 +1132,14 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_large = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
     p.off_on_grid = o; o += ms::align_up((size_t)kMaxG * 4, 256);
-    p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
     p.off_front = o;      o += ms::align_up((size_t)p.T * 4, 256);  // lazy sorting: sorted-front length per tile
     p.off_redo_flag = o;  o += ms::align_up((size_t)p.T * 4, 256);  //   tiles whose front did not saturate them
     p.off_redo_list = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_redo_count = o; o += 256;
     p.off_depth_wg = o;   o += ms::align_up((size_t)kMaxG * 8, 256);   // per-workgroup depth-bit min / max (k_isect_scatter)
+    // (the only N-dependent block comes last: everything above -- the clean-up count among it, which a caller
+    // reads back one frame later -- stays where it is when the scene grows or shrinks on a fixed grid)
+    p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }

@@ -64,3 +64,20 @@ for i in range(100):
         assert torch.equal(img, stagewise(gi, cam0)), i
 torch.cuda.synchronize()
 print(f"creeping N: {(time.perf_counter() - t0) / 100 * 1e3:.3f} ms/frame, {len(R._BIN_CHOICE)} races", flush=True)
+
+# 4. the same with a scene whose lazily sorted fronts fail (the lane must keep its fall-back to full sorts
+#    although N changes from frame to frame)
+R._BIN_CHOICE.clear()
+sc4, cam4 = randscene_v1(240_000, 1280, 720, ell=-4.0, seed=3, device=dev)
+g4 = (sc4["means3d"], sc4["scales"], sc4["quats"], sc4["opacities"], sc4["features"])
+for i in range(30):
+    ms.render_gaussians(*tuple(t[:200_000] for t in g4), cam4, background_color=bg)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(100):
+    n = int(200_000 * (1 + 0.0005 * i))
+    gi = tuple(t[:n] for t in g4)
+    img = ms.render_gaussians(*gi, cam4, background_color=bg)
+    if i % 33 == 5:
+        assert torch.equal(img, stagewise(gi, cam4)), i
+torch.cuda.synchronize()
+print(f"creeping N, failing fronts: {(time.perf_counter() - t0) / 100 * 1e3:.3f} ms/frame", flush=True)
