@@ -1,7 +1,6 @@
 """Headline benchmark: frames/s of the forward render path on synthetic random-Gaussian scenes.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one `render_gaussians(..., backend="hip")` forward (project -> bin/sort -> rasterise)
 of the whole frame, inputs resident in HBM.  N=1 workload = BASELINE config 3's forward
@@ -9,25 +8,37 @@ of the whole frame, inputs resident in HBM.  N=1 workload = BASELINE config 3's 
 as tile-row bands, one band per rank, + an RCCL all-gather of the framebuffer (strong scaling:
 total work per step is fixed).  Rank 0 prints ONE JSON line.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process,
+before anything in this process has touched a GPU), relays rank 0's JSON line and exits with the
+child's return code; launched under torch.distributed.run it is simply one of the ranks.
+
+After the timed loop the frame that was timed is VERIFIED: rendered once more through the same
+call and compared bit for bit with the per-stage path (project -> bin -> rasterise through the
+per-stage C entry points: gsplat-exact, fully sorted lists), and -- N=1 -- against the C oracle's
+frame under the test-suite's bar (tests/helpers.py check_image_strict).  A mismatch fails the run.
+
 `roofline` prices the dominant kernel (the tile rasteriser) with SURVEY.md 8(d)'s algorithmic
 bytes (40 B/intersection + 8 B/tile + 12 B/pixel) over its average duration measured with HIP
 events on the launch stream inside the timed region (the two events that bracket the kernel, on
 every 8th frame of a run of >= 64 steps, since each event between two kernels costs the GPU a bubble;
-the project / bin split comes from a short untimed pass with all four stage events).  `cpu_baseline` times the scalar C oracle
-(1 core) on ONE frame of the same workload on this box's host.
+the project / bin split comes from a short untimed pass with all four stage events).  The
+intersection count M is that of the lists the timed kernel is GIVEN (tight binning drops pairs that
+cannot blend; `algorithmic_bytes_gsplat_M` keeps round 1's figure on gsplat's M for comparison).
+`cpu_baseline` times the scalar C oracle (1 core) on frames of the same workload on this box's host
+and, beside it, the package's backend="torch" projection on CPU tensors (the reference's CPU path).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 WORKLOADS = {
     # name: (N, W, H, ell, fp16 colours)
@@ -41,25 +52,61 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle leg of the verification")
     ap.add_argument("--extras", action="store_true",
-                    help="also time the multi-view batch entry point (runs two views concurrently, so it "
-                         "is kept out of the default run whose rocprof kernel averages must match)")
-    args = ap.parse_args()
+                    help="N=1: also time the multi-view batch entry point and config 5 (kept out of the default "
+                         "run, whose rocprof kernel averages must match the timed workload); N>1 runs always "
+                         "report config 5 (the config BASELINE names for 8 GPUs) under `extras`")
+    ap.add_argument("--no-extras", action="store_true", help="N>1: skip the config-5 leg")
+    return ap.parse_args(argv)
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the ranks as a child process.
+    Nothing in THIS process has initialised a GPU (torch is not even imported yet)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for out in proc.stdout:          # relay; rank 0's JSON line is printed once more, last
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("[bench] the ranks exited 0 without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
     # Rehearsal only (the N > 1 path on a single-GPU box): MOJOSPLAT_BENCH_REHEARSE=1 puts every rank
     # on device 0 and uses gloo, which moves device tensors; RCCL refuses two ranks on one device.
     rehearse = os.environ.get("MOJOSPLAT_BENCH_REHEARSE") == "1"
@@ -75,41 +122,74 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     import mojosplat_amd as ms
-    from mojosplat_amd import _hip, render as render_mod
+    from mojosplat_amd import _fused, _hip, render as render_mod
     from mojosplat_amd.distributed import render_gaussians_sharded
     from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
 
     _hip.lib()  # hard failure if the HIP library is missing: nothing below has a CPU fallback
-    N, W, H, ell, fp16 = WORKLOADS[args.workload]
-    sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=dev)
-    if fp16:
-        sc["features"] = sc["features"].half()
     bg = torch.tensor(BACKGROUND_V1, device=dev)
-    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    in_flight = []
+    mode = {"async": True}
 
-    # one untimed pass through the per-stage API for the workload's statistics (N, M, T)
-    m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
-    ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, H, W, 16, backend="hip")
-    M, T = int(ids.numel()), int(ranges.shape[0] * ranges.shape[1])
-    del m2, con, dep, rad, ids, ranges
+    def barrier():
+        if world > 1:
+            while in_flight:
+                in_flight.pop(0).wait()
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    if world == 1:
-        def step():
-            return ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
-    else:
+    def load(name):
+        N, W, H, ell, fp16 = WORKLOADS[name]
+        sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=dev)
+        if fp16:
+            sc["features"] = sc["features"].half()
+        return sc, cam, (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+
+    def make_step(g, cam):
+        if world == 1:
+            return lambda: ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+
         # frames are independent: frame k's framebuffer all-gather (RCCL's stream) overlaps frame
         # k+1's render; a frame is consumed (its gather awaited) one step later.  The closing
         # barrier() drains the last one, so exactly K complete frames are inside the timed region.
-        in_flight = []
-        mode = {"async": True}
-
         def step():
             if not mode["async"]:
                 return render_gaussians_sharded(*g, cam, background_color=bg)
             in_flight.append(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True))
             if len(in_flight) > 1:
-                in_flight.pop(0).wait()
+                return in_flight.pop(0).wait()
+        return step
 
+    def stagewise(g, cam):
+        """The per-stage path: gsplat-exact binning, fully sorted lists.  -> (image, M, T)."""
+        m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+        ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, cam.H, cam.W, 16, backend="hip")
+        img = ms.rasterize_gaussians(m2, con, g[4], g[3], bg.to(g[4].dtype), ranges, ids, cam, tile_size=16,
+                                     backend="hip")
+        return img, int(ids.numel()), int(ranges.shape[0] * ranges.shape[1])
+
+    def timed_fps(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return steps / float(t.item())
+
+    N, W, H, ell, fp16 = WORKLOADS[args.workload]
+    sc, cam, g = load(args.workload)
+    step = make_step(g, cam)
+
+    # one untimed pass through the per-stage API: the workload's statistics (N, M, T) and the frame the
+    # timed path has to reproduce
+    ref_img, M, T = stagewise(g, cam)
+
+    if world > 1:
         # one probe frame before anything is timed: should the pipelined path raise on this node
         # (it cannot be rehearsed with RCCL on the single-GPU build box), every rank falls back to
         # the blocking gather -- the decision is agreed on with an all-reduce so ranks never diverge
@@ -127,24 +207,14 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         mode["async"] = bool(flag.item())
 
-    def barrier():
-        if world > 1:
-            while in_flight:
-                in_flight.pop(0).wait()
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    # render_gaussians picks its binning granularity from the previous frame's size record (render.py,
+    # bin_rule): the first frame of a scene is a split frame, the second already runs on the rule's grid
+    for _ in range(3):
+        step()
     binning = None
     if world == 1:
-        # render_gaussians settles its binning granularity by racing the modes over a scene's first
-        # frames (render.py, _BinTuner): let that finish before the W warm-up steps, untimed
-        for _ in range(24):
-            step()
-            tuners = list(render_mod._BIN_CHOICE.values())
-            if tuners and not tuners[0].queue:
-                binning = {"chosen_bin_px": tuners[0].choice,
-                           "race_ms": {str(k): round(v * 1e3, 4) for k, v in tuners[0].times.items()}}
-                break
+        binning = {"chosen_bin_px": render_mod._bin_mode.get(render_mod._bin_key(g[0], cam), 16),
+                   "how": "rule on the previous frame's size record (footprint diameter, density); no timing"}
     for _ in range(args.warmup):
         step()
 
@@ -154,7 +224,6 @@ def main():
     # kernels costs the GPU a ~6 us bubble -- and the full stage breakdown comes from a short
     # untimed pass afterwards.
     stage_events = []
-    pool = []
 
     def make_events(n):
         out = []
@@ -204,6 +273,23 @@ def main():
     dt = time.perf_counter() - t0
     render_mod._STAGE_HOOK = None
 
+    # ---- verification of the timed path (untimed) -------------------------------------------------
+    if world == 1:
+        img = step()
+    else:
+        img = render_gaussians_sharded(*g, cam, background_color=bg)    # blocking form of the same frame
+    max_abs = float((img.float() - ref_img.float()).abs().max())
+    verified = bool(torch.equal(img, ref_img))
+    # the lists the timed kernel was given: the frame's tile (or block) ranges still sit in lane 0's workspace
+    m_lists = None
+    if world == 1:
+        try:
+            px = binning["chosen_bin_px"]   # 16 = split frame: the ranges are those of the 16x16-block lists
+            m_lists = _fused.last_frame_list_entries(dev, N, -(-W // px), -(-H // px))
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] list-entry count unavailable: {e!r}", file=sys.stderr)
+    del ref_img
+
     breakdown = []
     if world == 1:   # untimed: all four stage boundaries
         extra = make_events(20)
@@ -219,9 +305,12 @@ def main():
         render_mod._STAGE_HOOK = None
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    vflag = torch.tensor([1 if verified else 0], device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vflag, op=dist.ReduceOp.MIN)
     dt = float(t.item())
+    verified = bool(vflag.item())
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
 
@@ -234,11 +323,60 @@ def main():
                 v = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for evs in breakdown]
                 stage_us[n] = sum(v) / len(v)
 
-    out = None
+    # ---- extras: config 5 (the config BASELINE names for 8 GPUs) ----------------------------------
+    extras = None
+    if args.workload != "cfg5" and (world > 1 or args.extras) and not args.no_extras:
+        del sc, g
+        torch.cuda.empty_cache()
+        sc5, cam5, g5 = load("cfg5")
+        step5 = make_step(g5, cam5)
+        for _ in range(3):
+            step5()
+        fps5 = timed_fps(step5, 30, 5)
+        extras = {"cfg5": {"workload": "cfg5: randscene-v1 N=5000000 3840x2160 ell=-4.0 seed=42 forward",
+                           "frames_per_s": round(fps5, 2), "n_gpus": world, "steps": 30, "scaling": "strong"}}
+        if world > 1:
+            # the same frame on ONE GPU in the same run (rank 0 renders the whole frame, the others wait):
+            # the denominator of config 5's speed-up, and the frame the banded one must equal
+            img5 = render_gaussians_sharded(*g5, cam5, background_color=bg)
+            one = None
+            if rank == 0:
+                full5 = ms.render_gaussians(*g5, cam5, background_color=bg, backend="hip")
+                extras["cfg5"]["bands_equal_single_gpu_frame"] = bool(torch.equal(img5, full5))
+                for _ in range(5):
+                    ms.render_gaussians(*g5, cam5, background_color=bg, backend="hip")
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                for _ in range(30):
+                    ms.render_gaussians(*g5, cam5, background_color=bg, backend="hip")
+                torch.cuda.synchronize()
+                one = 30 / (time.perf_counter() - tb)
+                extras["cfg5"]["frames_per_s_1_gpu_same_run"] = round(one, 2)
+                extras["cfg5"]["speedup_vs_1_gpu"] = round(fps5 / one, 3)
+                verified = verified and extras["cfg5"]["bands_equal_single_gpu_frame"]
+            barrier()
+        elif args.extras:
+            # not the headline: the multi-view entry point (16 cameras per call, two views in flight)
+            sc, cam, g = load(args.workload)
+            cams = [cam] * 16
+            ms.render_gaussians_batch(*g, cams, background_color=bg)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(4):
+                ms.render_gaussians_batch(*g, cams, background_color=bg)
+            torch.cuda.synchronize()
+            extras["multi_view_batch16_views_per_s"] = round(64 / (time.perf_counter() - tb), 1)
+        del sc5, g5
+        torch.cuda.empty_cache()
+
+    rc = 0
     if rank == 0:
-        b_raster = (40 - (6 if fp16 else 0)) * M + 8 * T + 12 * H * W
+        per_m = 40 - (6 if fp16 else 0)
+        m_kernel = m_lists if m_lists is not None else M
+        b_raster = per_m * m_kernel + 8 * T + 12 * H * W
+        b_raster_gsplat = per_m * M + 8 * T + 12 * H * W
         if band_stats is not None:   # N > 1: the kernel timed is rank 0's band
-            b_raster = (40 - (6 if fp16 else 0)) * band_stats["M"] + 8 * band_stats["T"] + 12 * band_stats["px"]
+            b_raster = b_raster_gsplat = per_m * band_stats["M"] + 8 * band_stats["T"] + 12 * band_stats["px"]
         b_frame = 96 * N + (84 - (6 if fp16 else 0)) * M + 12 * T + 12 * H * W
         roofline = None
         if "raster" in stage_us:
@@ -251,27 +389,24 @@ def main():
                         "achieved": round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "algorithmic_bytes": b_raster,
+                        "intersections_in_kernel_lists": m_kernel,
+                        "algorithmic_bytes_gsplat_M": b_raster_gsplat,
+                        "frac_gsplat_M": round(b_raster_gsplat / (stage_us["raster"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "avg_kernel_us": round(stage_us["raster"], 1), "instrumented_launches": len(stage_events),
-                        "alpha_evals": 256 * M,
+                        "alpha_evals": 256 * m_kernel,
                         "frame": {"algorithmic_bytes": b_frame,
                                   "achieved": round(b_frame / (ms_per_step * 1e-3) / 1e9, 1),
                                   "frac": round(b_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                         "stage_us": {k: round(v, 1) for k, v in stage_us.items()}}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(sc, cam, W, H, BACKGROUND_V1, args.workload)
-        extras = None
-        if world == 1 and args.extras:
-            # not the headline: the same scene through the multi-view entry point (16 cameras per
-            # call, two views in flight on two streams), reported beside the single-call rate
-            cams = [cam] * 16
-            ms.render_gaussians_batch(*g, cams, background_color=bg)
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(4):
-                ms.render_gaussians_batch(*g, cams, background_color=bg)
-            torch.cuda.synchronize()
-            extras = {"multi_view_batch16_views_per_s": round(64 / (time.perf_counter() - tb), 1)}
+        verification = {"bit_identical_to_stagewise": verified, "max_abs_vs_stagewise": max_abs}
+        if world == 1 and not (args.no_cpu_baseline and args.no_verify):
+            sc, cam, g = load(args.workload)
+            cpu, oracle_check = cpu_baseline(sc, cam, W, H, BACKGROUND_V1, args.workload,
+                                             img if not args.no_verify else None, not args.no_cpu_baseline)
+            if oracle_check is not None:
+                verification["oracle"] = oracle_check
+                verified = verified and oracle_check["unexplained_px"] == 0
         out = {
             "metric": "frames/sec at 1M Gaussians 1920x1080 fwd; achieved HBM GB/s vs peak",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -282,37 +417,87 @@ def main():
                        "gaussians": N, "intersections": M, "tiles": T, "tile_size": 16, "binning": binning,
                        "colour_dtype": "f16" if fp16 else "f32",
                        "parallelism": "single GPU" if world == 1 else f"{world} tile-row bands + RCCL all-gather" + (", gather of frame k overlapped with render of frame k+1" if mode["async"] else " (blocking)")},
+            "verified": verified, "max_abs_vs_stagewise": max_abs, "verification": verification,
+            "rccl": None if world == 1 else {"world": dist.get_world_size(), "backend": dist.get_backend(),
+                                             "devices": "all ranks on cuda:0 (rehearsal)" if rehearse else "one per rank"},
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(out), flush=True)
+        if not verified:
+            print("[bench] VERIFICATION FAILED: the timed frame differs from the per-stage path / the oracle",
+                  file=sys.stderr, flush=True)
+            rc = 3
     if world > 1:
+        code = torch.tensor([rc], device=dev)
+        dist.all_reduce(code, op=dist.ReduceOp.MAX)
+        rc = int(code.item())
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
-def cpu_baseline(sc, cam, W, H, bg, workload):
+def cpu_baseline(sc, cam, W, H, bg, workload, gpu_img, timed):
     """The scalar C oracle (kind 'port', 1 core) on a bounded sample of the same workload: whole
     frames of the scene (its first <= 1M Gaussians), repeated until ~10 s of CPU work, reported
-    as frames/s of that sample (stated in `sample`)."""
+    as frames/s of that sample (stated in `sample`); beside it the package's backend='torch'
+    projection (the reference's CPU path, mojosplat/projection.py:285-346 restated) on CPU tensors.
+    gpu_img: the timed path's frame, checked here against the oracle's (None: skipped).
+    -> (cpu_baseline record or None, oracle check record or None)"""
     import numpy as np
+    import torch
 
     import oracle
     cpu = {k: v.float().cpu().numpy() for k, v in sc.items()}
     vm = cam.view_matrix.cpu().numpy()
-    n = min(len(cpu["means3d"]), 1_000_000)
-    args = tuple(cpu[k][:n] for k in ("means3d", "scales", "quats", "opacities", "features"))
-    frames, t0 = 0, time.perf_counter()
-    while True:
-        _, aux = oracle.render_fwd(*args, vm, cam.fx, cam.fy, cam.cx, cam.cy, W, H,
-                                   background=np.array(bg, np.float32))
-        frames += 1
-        dt = time.perf_counter() - t0
-        if dt >= 10.0 or frames >= 8:
-            break
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} frame(s) of {workload} restricted to its first {n} Gaussians "
-                      f"(M={aux['M']}), oracle/gsplat_oracle.c, {dt:.1f} s of CPU work",
-            "host_cpus": os.cpu_count()}
+    n_all = len(cpu["means3d"])
+    n = min(n_all, 1_000_000)
+    full = tuple(cpu[k] for k in ("means3d", "scales", "quats", "opacities", "features"))
+    bgn = np.array(bg, np.float32)
+
+    check = None
+    if gpu_img is not None:
+        # all host threads here: this is the checker, not the baseline
+        ref, aux = oracle.render_fwd(*full, vm, cam.fx, cam.fy, cam.cx, cam.cy, W, H, background=bgn, margin=True)
+        diff = np.abs(gpu_img.float().cpu().numpy() - ref).max(-1)
+        bad = diff > 1e-4
+        sens = aux["margin"] < 1e-4          # a branch of the walk within 1e-4 of its threshold
+        check = {"max_abs": float(diff.max()), "px_beyond_1e-4": int(bad.sum()),
+                 "explained_by_branch_margin": int((bad & sens).sum()), "unexplained_px": int((bad & ~sens).sum()),
+                 "max_abs_where_no_branch_is_close": float(diff[~sens].max()), "margin_eps": 1e-4,
+                 "what": "GPU frame (its own projection) vs oracle.render_fwd end to end, tests/helpers.py rule"}
+    rec = None
+    if timed:
+        args = tuple(a[:n] for a in full)
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            _, aux = oracle.render_fwd(*args, vm, cam.fx, cam.fy, cam.cx, cam.cy, W, H, background=bgn, threads=1)
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt >= 10.0 or frames >= 8:
+                break
+        # the reference's CPU path: backend="torch" projection on CPU tensors at this workload's N
+        from mojosplat_amd.projection import project_gaussians
+        tcpu = [torch.from_numpy(a) for a in full[:4]]
+        ccam = type(cam)(R=cam.R.cpu(), T=cam.T.cpu(), H=cam.H, W=cam.W, fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy,
+                         near=cam.near, far=cam.far)
+        project_gaussians(*[t[:1000] for t in tcpu], ccam, backend="torch")   # warm-up
+        reps, tt0 = 0, time.perf_counter()
+        while True:
+            project_gaussians(*tcpu, ccam, backend="torch")
+            reps += 1
+            tdt = time.perf_counter() - tt0
+            if tdt >= 5.0 or reps >= 5:
+                break
+        rec = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{frames} frame(s) of {workload} restricted to its first {n} Gaussians "
+                         f"(M={aux['M']}), oracle/gsplat_oracle.c, {dt:.1f} s of CPU work",
+               "host_cpus": os.cpu_count(),
+               "torch_backend": {"stage": "projection only (backend='torch' on CPU tensors; the reference's CPU "
+                                          "path has no rasteriser and a Python-loop binning)",
+                                 "gaussians": n_all, "seconds_per_call": round(tdt / reps, 4), "calls": reps,
+                                 "gaussians_per_s": round(n_all * reps / tdt, 1),
+                                 "torch_num_threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count()}}
+    return rec, check
 
 
 if __name__ == "__main__":

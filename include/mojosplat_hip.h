@@ -21,7 +21,11 @@
  *
  * Conventions (same as the reference's op convention, projection.py:438-454):
  *   - destination passing: the caller (PyTorch) owns and pre-allocates every buffer,
- *     including scratch; the library never allocates device memory and keeps no state;
+ *     including scratch; the library never allocates device memory and keeps no per-frame or
+ *     per-scene state.  What it does keep, process-wide and thread-safe: the thread-local
+ *     error string, three environment switches read once (MOJOSPLAT_LAZY_SORT, MOJOSPLAT_SPLIT,
+ *     MOJOSPLAT_SPLIT_MAX_ENTRIES) and a mutex-guarded table of the (device, kernel) pairs whose
+ *     dynamic-LDS ceiling it has already raised (hipFuncSetAttribute);
  *   - all pointers are DEVICE pointers unless a parameter says "host"; tensors are
  *     contiguous row-major with the layouts written next to each parameter;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); the per-stage

@@ -10,6 +10,7 @@ intermediates (project_gaussians / bin_gaussians_to_tiles / rasterize_gaussians)
 import ctypes
 import math
 import os
+import threading
 
 import torch
 
@@ -19,6 +20,10 @@ from .projection import EPS2D
 LAZY_SORT = os.environ.get("MOJOSPLAT_LAZY_SORT", "1") != "0"  # mirrors csrc/pipeline.hip
 
 _state = {}  # (device, lane) -> dict(ws, isect, host, ev); lane 0 = the plain single-frame path
+# Host threads that render on the same device share that device's cached scratch: whole frames
+# (render_fwd_hip) take this lock, so they run one after the other instead of racing on it.  (Split-phase
+# frames -- begin/finish on lanes -- are driven by one thread by design.)
+_frame_lock = threading.RLock()
 
 
 def _dev_state(dev, lane=0):
@@ -211,15 +216,6 @@ class _Frame:
         return means2d, conics, radii, ranges, ids
 
 
-def forget_learning(dev):
-    """Drop what the lanes of `dev` have learnt about sorting modes (full sorts / front levels per frame
-    shape): called when the scene behind a shape has visibly changed."""
-    for (d, _), st in _state.items():
-        if d == dev and not st.get("busy"):
-            st.pop("learnt", None)
-            st["full_sort"], st["front_level"], st["shape"] = False, 0, None
-
-
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
                    stage_events=None, row_range=None, out=None, lane=0, info=None):
     """-> (image (H,W,C) f32, M).  `background` may be None.  stage_events: None or a list of 4
@@ -229,8 +225,24 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
     `lane` selects an independent set of scratch buffers (frames in flight at the same time each
     need their own).  `info`: optional dict, receives `on_grid` = number of Gaussians touching the
     FULL tile grid (band-independent)."""
-    return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                  stage_events, row_range, out, lane).finish(WHOLE, info)
+    with _frame_lock:
+        return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
+                      stage_events, row_range, out, lane).finish(WHOLE, info)
+
+
+def last_frame_list_entries(dev, N, tile_w, tile_h, lane=0):
+    """Sum of the list lengths the rasteriser of the LAST frame on (dev, lane) was given, read back from the
+    tile ranges the frame left in its workspace (for a split frame: the 16x16-block lists cut from its 32-px
+    bins).  tile_w x tile_h = the grid of that frame's tile size.  Synchronises; for benchmarks / tests."""
+    st = _state.get((dev, lane))
+    if st is None or st.get("ws") is None:
+        raise RuntimeError("no frame has been rendered on this lane")
+    off = (ctypes.c_size_t * 6)()
+    _hip.check(_hip.lib().ms_render_workspace_layout(N, tile_w, tile_h, off), "ms_render_workspace_layout")
+    torch.cuda.synchronize(dev)
+    nb = tile_w * tile_h * 8
+    r = st["ws"][off[4]:off[4] + nb].view(torch.int32).view(tile_h, tile_w, 2)
+    return int((r[..., 1] - r[..., 0]).clamp_min(0).sum())
 
 
 def render_begin_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,

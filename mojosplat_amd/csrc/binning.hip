@@ -30,6 +30,9 @@
 //                     lists (emit_block_lists)
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "project_device.hpp"
 
 namespace {
@@ -1152,16 +1155,22 @@ int check_grid(int tile_size, int tw, int th, int row_begin, int row_end) {
     return MS_OK;
 }
 
-// raise a kernel's dynamic-LDS ceiling to the full 160 KB once per process
+// raise a kernel's dynamic-LDS ceiling to the full 160 KB: once per (device, kernel) -- the attribute
+// belongs to the function as loaded on the CURRENT device -- remembered in a small table under a mutex
+// (host threads rendering on several devices of one process share it)
 template <class K>
 int allow_big_lds(K kernel) {
-    static const void *seen[8];
-    static int n_seen = 0;
+    struct Seen { int dev; const void *fn; };
+    static std::mutex mu;
+    static std::vector<Seen> seen;
     const void *f = reinterpret_cast<const void *>(kernel);
-    for (int i = 0; i < n_seen; ++i)
-        if (seen[i] == f) return MS_OK;
+    int dev = -1;
+    MS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Seen &e : seen)
+        if (e.dev == dev && e.fn == f) return MS_OK;
     MS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-    if (n_seen < 8) seen[n_seen++] = f;
+    seen.push_back({dev, f});
     return MS_OK;
 }
 

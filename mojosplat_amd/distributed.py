@@ -166,20 +166,25 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     # asynchronous HIP path: band on a lane stream (ms_render_fwd BEGIN, no host wait).  Streams
     # are addressed by handle and ordered with events; torch's current stream is never switched
     # (the context managers would cost more host time than the band's kernels take to launch).
-    from ._fused import _lane_streams, render_begin_hip
+    from ._fused import _Frame, _lane_streams
     cur = torch.cuda.current_stream(dev)
     lanes = _lane_streams(dev)
     lane = _turn.get(dev, 0)
     _turn[dev] = 1 - lane
     s = lanes[lane]
-    s.wait_stream(cur)  # inputs (and whatever the caller enqueued before) are ready
     full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
     from . import render as _render   # bench.py's in-situ kernel timing hook (None otherwise)
     evs = _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None
-    frame = render_begin_hip(means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                             row_range=_band_of(bands[rank], th), out=full, lane=1 + lane, stream=s.cuda_stream,
-                             stage_events=evs)
-    for t in (means3d, scales, quats, opacities, features, bg, full):
+    # Marshal first (non-fp32 / strided inputs and the view matrix are copied by kernels enqueued on the
+    # CURRENT stream), then make the lane wait for the current stream, then enqueue the band on the lane:
+    # everything the band reads -- the caller's tensors and the marshalled copies -- is ordered before it.
+    frame = _Frame(means3d, scales, quats, opacities, features, camera, bg, tile_size, evs,
+                   _band_of(bands[rank], th), full, 1 + lane, s.cuda_stream)
+    s.wait_stream(cur)
+    frame.begin()
+    # tensors allocated on the current stream and used on the lane: the caching allocator must not hand
+    # their memory out again before the lane is done with it
+    for t in (means3d, scales, quats, opacities, features, bg, full) + tuple(x for x in frame.keep[:-1] if x is not None):
         t.record_stream(s)
 
     def finalize():

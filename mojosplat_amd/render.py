@@ -12,6 +12,8 @@ spherical-harmonic coefficients and are evaluated per view (sh.py) -- the TODO a
 render.py:83 carried out.
 """
 import math
+import os
+import threading
 from typing import Optional
 
 import torch
@@ -32,96 +34,86 @@ _STAGE_HOOK = None
 # ---- binning granularity -------------------------------------------------------------------------
 # The frame does not depend on the grid the Gaussians are binned on: a pixel blends the same Gaussians
 # in the same order whatever the bins, and the rasteriser works in 16x16 blocks inside any tile
-# (bit-identical for every mode below at every BASELINE config; tests/test_hip_fused.py).  What the
-# grid moves is cost, by up to 2x either way:
+# (bit-identical for every mode below at every BASELINE config; tests/test_hip_fused.py,
+# tests/test_hip_configs.py).  What the grid moves is cost, by up to 2x either way
+# (profiles/r01_bin_modes.txt, ms per frame at split / 32 / 64):
 #   16  the library's default for 16-px tiles: 32-px bins whose sorted lists are cut into per-block
-#       lists (a "split" frame) -- best while Gaussians are small against a tile (config 3: 0.26 ms
-#       against 0.31 at plain 32 px and 0.62 at 64);
-#   32 / 64  plain coarse bins, every block walks its bin's whole list -- best for dense scenes of
-#       larger footprints (config 5: 1.18 / 1.08 / 0.77 ms at 16 / 32 / 64; config 4: 0.69 / 0.64 / 0.66).
-# No density rule separates these cases reliably, so the first frames of a scene (same device, N and
-# image size) are a measurement: each mode renders one warm-up frame and _TIMED_FRAMES timed ones (a
-# pair of events on the launch stream around a synchronised call; the fastest counts), the fastest
-# mode is kept, and the race is run again every _REPROBE_EVERY frames, or as soon as a frame's
-# intersection count has moved by a quarter, because scenes drift.  64 px is only tried when 32 px did
-# not already lose clearly.
-_BIN_CHOICE = {}            # (device, N to ~9 %, W, H) -> _BinTuner
+#       lists (a "split" frame) -- best while footprints are small against a bin (config 3: 0.26 /
+#       0.31 / 0.62; config 2: 0.12 / 0.15 / 0.28);
+#   32 / 64  plain coarse bins, every block walks its bin's whole list -- best once footprints span
+#       several blocks (the block lists of a split frame then hold four copies of everything:
+#       100k Gaussians at l = -3: 0.34 / 0.19 / 0.22) and, the denser the scene, the coarser (lazily
+#       sorted lists are only read ~300-450 entries deep, so binning cost = pairs scattered: config 5
+#       1.18 / 1.08 / 0.77; 1M at l = -3: 0.31 / 0.28 / 0.24; config 4 0.69 / 0.64 / 0.66).
+# The choice is a RULE on two statistics every frame's size record already carries -- no timing, no
+# synchronisation, same answer for the same sequence of scenes: with M pairs on a g-px grid and n
+# Gaussians on the grid, p = M / n pairs per Gaussian give the mean footprint diameter
+# d = g (sqrt(p) - 1) px and the density e = n (d / 16 + 1)^2 / T16 entries per 16-px tile;
+#   d < 24 px:  split frame (32 px when e > 2000);   d >= 24 px:  64 px when e > 600, else 32 px.
+# A frame is binned by the rule applied to the PREVIOUS frame of the same (device, N class, image
+# size); the first one is a split frame.  Thresholds carry a +-10 % dead band so that a scene sitting
+# on one does not flip every frame.  `bin_size=` (or MOJOSPLAT_BIN_PX) overrides the rule;
+# `tune_binning()` measures instead, for callers who want that.
 _BIN_MODES = (16, 32, 64)
-_REPROBE_EVERY = 1024
-_TIMED_FRAMES = 4
-_MIN_SETTLED = 64           # frames a verdict stands before a drifting count may start the next race
-_SKIP_COARSER = 1.10        # 32 px slower than 16 px by this factor: do not try 64
+_D_SPLIT, _E_SPLIT_DENSE, _E_COARSE = 24.0, 2000.0, 600.0
+_DEAD_BAND = 0.10
+_bin_mode = {}            # (device, N to ~9 %, W, H) -> bin px of the next frame
+_bin_lock = threading.Lock()
 
 
-class _BinTuner:
-    def __init__(self):
-        self.choice = None
-        self.frames = 0
-        self._start_race()
-
-    def _start_race(self):
-        self.times, self.counts, self.settled = {}, {}, 0
-        self.queue = [(m, k > 0) for m in _BIN_MODES for k in range(1 + _TIMED_FRAMES)]   # (mode, timed?)
-
-    def next(self):
-        """-> (bin size of this frame, whether to time it)."""
-        if not self.queue:
-            self.frames += 1
-            if self.frames % _REPROBE_EVERY == 0:
-                self._start_race()
-            else:
-                return self.choice, False
-        return self.queue[0]
-
-    def done(self, mode, seconds, m=None):
-        """The frame `next()` announced has been rendered (seconds: None when it was not timed; m: its
-        (intersection count, frame kind)).  -> True when the scene has drifted and a new race starts."""
-        if not self.queue:
-            # a different scene behind the same (device, N, image size): the count of the chosen mode has
-            # moved by more than a quarter since it was first seen -> race again from the next frame on.
-            # (`m` = (count, kind of frame): a lane that falls back from lazily sorted 32-px bins to fully
-            # sorted 16-px tiles counts different things; like is compared with like.)
-            self.settled += 1
-            if mode == self.choice and m is not None:
-                ref = self.counts.setdefault((mode, m[1]), m[0])
-                if ref and abs(m[0] - ref) > 0.25 * ref:
-                    if self.settled < _MIN_SETTLED:   # two scenes taking turns behind one key: do not race on
-                        self.counts[(mode, m[1])] = m[0]   # every switch; follow the count instead
-                        return False
-                    self._start_race()
-                    return True
-            return False
-        if self.queue[0][0] != mode:
-            return False
-        self.queue.pop(0)
-        if seconds is not None:
-            self.times[mode] = min(seconds, self.times.get(mode, seconds))
-        if 16 in self.times and 32 in self.times and self.times[32] > _SKIP_COARSER * self.times[16]:
-            self.queue = [q for q in self.queue if q[0] != 64]
-        if not self.queue:
-            self.choice = min(self.times, key=self.times.get)
-        return False
+def _rule(d, e, k=1.0):
+    if d < _D_SPLIT * k:
+        return 32 if e > _E_SPLIT_DENSE * k else 16
+    return 64 if e > _E_COARSE * k else 32
 
 
-def _tuner(means3d, camera, tile_size):
-    if tile_size != TILE_SIZE:
-        return None         # an explicit non-default tile size is honoured as given
-    # (scene sizes within ~9 % of each other share a race: a stream of frames whose N creeps must not race
-    # anew on every frame; the drift detector takes care of real changes)
+def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int) -> int:
+    """Bin size (16 = split frame, 32, 64) the rule above picks after a frame binned at `mode` that
+    reported `m` (Gaussian, bin) pairs for `on_grid` Gaussians on a W x H image."""
+    if m <= 0 or on_grid <= 0:
+        return mode
+    g = 32 if mode == 16 else mode
+    d = g * (math.sqrt(max(m / on_grid, 1.0)) - 1.0)
+    e = on_grid * (d / 16.0 + 1.0) ** 2 / (math.ceil(W / 16) * math.ceil(H / 16))
+    lo, hi = _rule(d, e, 1.0 - _DEAD_BAND), _rule(d, e, 1.0 + _DEAD_BAND)
+    return lo if lo == hi else mode     # inside a dead band: stay
+
+
+def _bin_key(means3d, camera):
     n = means3d.shape[0]
-    key = (means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H)
-    t = _BIN_CHOICE.get(key)
-    if t is None:
-        if len(_BIN_CHOICE) >= 64:
-            _BIN_CHOICE.pop(next(iter(_BIN_CHOICE)))
-        t = _BIN_CHOICE[key] = _BinTuner()
-        # a scene that has grown or shrunk into the next size class starts from its neighbour's verdict
-        # (the next scheduled race, or the drift detector, revisits it)
-        near = [o for k, o in _BIN_CHOICE.items() if o is not t and o.choice is not None and not o.queue
-                and (k[0], k[2], k[3]) == (key[0], key[2], key[3]) and abs(k[1] - key[1]) <= 3]
-        if near:
-            t.choice, t.times, t.queue = near[-1].choice, dict(near[-1].times), []
-    return t
+    return (means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H)
+
+
+def _env_bin_px():
+    v = os.environ.get("MOJOSPLAT_BIN_PX")
+    if not v:
+        return None
+    if int(v) not in _BIN_MODES:
+        raise ValueError(f"MOJOSPLAT_BIN_PX must be one of {_BIN_MODES}")
+    return int(v)
+
+
+def tune_binning(means3d, scales, quats, opacities, features, camera, background_color=None,
+                 frames: int = 4):
+    """Measure instead of estimate: renders the scene `frames` times per binning mode between stream
+    events (synchronises -- not for a latency-critical loop) -> (best bin size, {mode: seconds}).
+    Pass the result as `render_gaussians(..., bin_size=best)`."""
+    times = {}
+    for mode in _BIN_MODES:
+        best = None
+        for k in range(frames + 1):   # the first frame of a mode warms its scratch up
+            start, end = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+            torch.cuda.synchronize(means3d.device)
+            start.record()
+            render_gaussians(means3d, scales, quats, opacities, features, camera,
+                             background_color=background_color, bin_size=mode)
+            end.record()
+            end.synchronize()
+            if k:
+                t = start.elapsed_time(end) * 1e-3
+                best = t if best is None else min(best, t)
+        times[mode] = best
+    return min(times, key=times.get), times
 
 
 @torch.no_grad()
@@ -136,6 +128,7 @@ def render_gaussians(
     background_color: Optional[torch.Tensor] = None,
     tile_size: int = TILE_SIZE,
     backend: str = "hip",
+    bin_size: Optional[int] = None,   # hip backend, tile_size 16: 16 (split frame) | 32 | 64; None = the rule above
 ) -> torch.Tensor:
     required = [means3d, scales, quats, opacities, features]
     if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in required):
@@ -172,24 +165,28 @@ def render_gaussians(
         evs = _STAGE_HOOK() if _STAGE_HOOK is not None else None
         bands = lds_row_bands(camera.H, camera.W, tile_size)
         if len(bands) == 1:
-            tuner = _tuner(means3d, camera, tile_size)
-            bin_size, timed = (tile_size, False) if tuner is None else tuner.next()
-            if timed:
-                torch.cuda.synchronize(means3d.device)
-                start, end = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-                start.record()
+            # an explicit non-default tile size is honoured as given; so is an explicit bin size
+            explicit = bin_size if bin_size is not None else _env_bin_px()
+            if explicit is not None and explicit not in _BIN_MODES:
+                raise ValueError(f"bin_size must be one of {_BIN_MODES}")
+            key = None
+            if tile_size != TILE_SIZE:
+                mode = tile_size
+            elif explicit is not None:
+                mode = explicit
+            else:
+                key = _bin_key(means3d, camera)
+                with _bin_lock:
+                    mode = _bin_mode.get(key, TILE_SIZE)
             info = {}
-            img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, bin_size,
+            img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, mode,
                                     stage_events=evs, info=info)
-            if tuner is not None:
-                seconds = None
-                if timed:
-                    end.record()
-                    end.synchronize()
-                    seconds = start.elapsed_time(end) * 1e-3
-                if tuner.done(bin_size, seconds, (m, info["flags"] & 8)):
-                    from ._fused import forget_learning
-                    forget_learning(means3d.device)   # a new scene: the lanes' sorting modes are re-learnt too
+            if key is not None:
+                nxt = bin_rule(mode, m, info["on_grid"], camera.W, camera.H)
+                with _bin_lock:
+                    if len(_bin_mode) >= 256 and key not in _bin_mode:
+                        _bin_mode.pop(next(iter(_bin_mode)))
+                    _bin_mode[key] = nxt
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer

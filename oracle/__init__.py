@@ -88,9 +88,23 @@ def bin_tiles(means2d, radii, depths, H, W, tile_size, *, row_begin=0, row_end=N
     return ids, ranges
 
 
+def _row_chunks(H, threads):
+    n = max(1, min(threads, H))
+    step = -(-H // (n * 4)) if n > 1 else H     # 4 chunks per thread: rows are not equally heavy
+    return [(r, min(r + step, H)) for r in range(0, H, step)]
+
+
+def default_threads():
+    """Host threads the rasteriser legs use for big frames (row chunks; ctypes drops the GIL)."""
+    import os
+    return max(1, min(16, (os.cpu_count() or 1)))
+
+
 def rasterize_fwd(means2d, conics, colors, opacities, background, tile_ranges, flatten_ids,
-                  H, W, tile_size, *, f64=False):
-    """-> (colors (H,W,C) f32, alphas (H,W) f32, last_ids (H,W) i32); f64=True -> colors f64 only."""
+                  H, W, tile_size, *, f64=False, margin=False, threads=None):
+    """-> (colors (H,W,C) f32, alphas (H,W) f32, last_ids (H,W) i32[, margin (H,W) f32]);
+    f64=True -> colors f64 only.  margin: see orc_rasterize_fwd_rows.  threads: row chunks run on
+    that many host threads (default: 1 for small frames; the result does not depend on it)."""
     means2d, conics, colors = _f32(means2d), _f32(conics), _f32(colors)
     op = _f32(opacities).reshape(-1)
     N, CD = colors.shape
@@ -99,26 +113,39 @@ def rasterize_fwd(means2d, conics, colors, opacities, background, tile_ranges, f
     ids = _i32(flatten_ids).reshape(-1)
     M = ids.shape[0]
     L = lib()
+    if threads is None:
+        threads = default_threads() if H * W >= 512 * 512 else 1
     args = (ctypes.c_int64(N), ctypes.c_int64(M), _p(means2d), _p(conics), _p(colors),
             ctypes.c_int(CD), _p(op), _p(bg), ctypes.c_int(W), ctypes.c_int(H),
             ctypes.c_int(tile_size), _p(ranges), _p(ids))
+
+    def run(fn, tail):
+        chunks = _row_chunks(H, threads)
+        call = lambda rr: fn(*args, ctypes.c_int(rr[0]), ctypes.c_int(rr[1]), *tail)
+        if len(chunks) == 1:
+            rcs = [call(chunks[0])]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(threads) as ex:
+                rcs = list(ex.map(call, chunks))
+        assert all(rc == 0 for rc in rcs), rcs
+
     if f64:
         out = np.empty((H, W, CD), np.float64)
-        rc = L.orc_rasterize_fwd_f64(*args, _p(out))
-        assert rc == 0, rc
+        run(L.orc_rasterize_fwd_f64_rows, (_p(out),))
         return out
     out = np.empty((H, W, CD), np.float32)
     alphas = np.empty((H, W), np.float32)
     last = np.empty((H, W), np.int32)
-    rc = L.orc_rasterize_fwd(*args, _p(out), _p(alphas), _p(last))
-    assert rc == 0, rc
-    return out, alphas, last
+    mg = np.empty((H, W), np.float32) if margin else None
+    run(L.orc_rasterize_fwd_rows, (_p(out), _p(alphas), _p(last), _p(mg)))
+    return (out, alphas, last, mg) if margin else (out, alphas, last)
 
 
 def render_fwd(means3d, scales, quats, opacities, colors, viewmat, fx, fy, cx, cy, W, H, *,
-               background=None, tile_size=16, near=0.1, far=100.0):
+               background=None, tile_size=16, near=0.1, far=100.0, margin=False, threads=None):
     """Whole forward path with gsplat semantics; mirrors render.py:63-101 incl. the
-    zeros-image-when-no-intersections rule (render.py:73-76)."""
+    zeros-image-when-no-intersections rule (render.py:73-76).  margin=True adds aux['margin']."""
     m2, con, dep, rad = project_fwd(means3d, scales, quats, opacities, viewmat, fx, fy, cx, cy,
                                     W, H, near=near, far=far)
     ids, ranges = bin_tiles(m2, rad, dep, H, W, tile_size)
@@ -126,9 +153,14 @@ def render_fwd(means3d, scales, quats, opacities, colors, viewmat, fx, fy, cx, c
     if ids.size == 0:
         return np.zeros((H, W, C), np.float32), dict(M=0)
     bg = np.zeros((C,), np.float32) if background is None else background
-    img, alphas, last = rasterize_fwd(m2, con, colors, opacities, bg, ranges, ids, H, W, tile_size)
-    return img, dict(M=int(ids.size), means2d=m2, conics=con, depths=dep, radii=rad, ids=ids,
-                     ranges=ranges, alphas=alphas, last_ids=last)
+    res = rasterize_fwd(m2, con, colors, opacities, bg, ranges, ids, H, W, tile_size, margin=margin,
+                        threads=threads)
+    img, alphas, last = res[:3]
+    aux = dict(M=int(ids.size), means2d=m2, conics=con, depths=dep, radii=rad, ids=ids,
+               ranges=ranges, alphas=alphas, last_ids=last)
+    if margin:
+        aux["margin"] = res[3]
+    return img, aux
 
 
 def sh_fwd(means3d, campos, coeffs, degree, *, radii=None, clamp=True, want_basis=False):

@@ -28,6 +28,17 @@ try:
             assert torch.equal(cur.wait(), ref), f"pipelined frame {k - 1} differs"
         cur = nxt
     assert torch.equal(cur.wait(), ref)
+    # inputs the frame has to marshal (float64 / strided / fp16): their copies are made on the current stream
+    # and read on a lane stream -- the ordering the pipelined path must get right
+    g2 = (g[0].double(), torch.stack([g[1], g[1]], 1)[:, 0], g[2].double(), g[3], g[4].half())
+    ref2 = ms.render_gaussians(*g2, cam, background_color=bg)
+    cur = None
+    for k in range(6):
+        nxt = render_gaussians_sharded(*g2, cam, background_color=bg, async_op=True)
+        if cur is not None:
+            assert torch.equal(cur.wait(), ref2), f"pipelined marshalled frame {k - 1} differs"
+        cur = nxt
+    assert torch.equal(cur.wait(), ref2)
     print(f"rank {rank}/{world}: sharded frames (blocking + pipelined) equal the single-GPU frame", flush=True)
 except Exception as e:
     print(f"rank {rank}: {type(e).__name__}: {e}", flush=True)

@@ -1,0 +1,186 @@
+"""GPU: the BASELINE configs at FULL size against the C oracle (configs 3, 4, 5; config 2 lives in
+test_hip_parity.py), through the calls a user makes.
+
+Per config:
+  * the frame of `render_gaussians(backend="hip")` -- the fused path: tight binning, lazily sorted lists,
+    split frames / coarse bins by the binning rule, sync-free -- equals the per-stage path (HIP
+    project -> bin -> rasterise: gsplat-exact, fully sorted lists) BIT FOR BIT, run to run;
+  * HIP binning of the oracle's projected inputs equals the oracle's lists bit for bit; HIP rasteriser on
+    those lists against the oracle's rasteriser under the strict bar of helpers.check_image_strict
+    (<= 1e-4 abs per pixel fp32 except where a branch of the walk sits within 1e-5 of its threshold;
+    zero unexplained pixels), `last_ids` equal wherever no branch is close;
+  * the fused frame end to end (its own projection) against oracle.render_fwd under the same rule with the
+    margin widened to 1e-4 (the two projections differ by an ulp in exp(scale): conics move by 1e-7
+    relative, which can only matter where a branch is within that of its threshold);
+  * config 5 additionally as the 8 tile-row bands of the multi-GPU decomposition
+    (render_gaussians_sharded(rehearse=(r, 8))): assembled bands == the single-GPU frame bit for bit;
+  * config 3 backward: finite, repeatable within atomic noise, fused == per-stage autograd; a 20k-Gaussian
+    crop against float64 autograd of the restatement (oracle/torch_oracle.py).
+
+Reference bar: tests/test_rasterization.py:94-146 (atol = rtol = 1e-4 mojo vs gsplat).
+"""
+import numpy as np
+import pytest
+import torch
+
+import mojosplat_amd as ms
+import oracle
+from helpers import check_image_strict, np_
+from mojosplat_amd import _fused
+from mojosplat_amd.binning import bin_gaussians_to_tiles_hip
+from mojosplat_amd.distributed import band_plan, render_gaussians_sharded
+from mojosplat_amd.rasterization import rasterize_gaussians_hip
+from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: (N, W, H, ell, fp16 colours)
+    "cfg3": (1_000_000, 1920, 1080, -4.0, False),
+    "cfg4": (6_000_000, 1600, 1063, -4.0, True),
+    "cfg5": (5_000_000, 3840, 2160, -4.0, False),
+}
+
+
+def _scene(name, device):
+    N, W, H, ell, fp16 = CONFIGS[name]
+    sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=device)
+    if fp16:
+        sc["features"] = sc["features"].half()
+    return sc, cam, (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_forward_full_size_vs_oracle(device, name):
+    N, W, H, ell, fp16 = CONFIGS[name]
+    sc, cam, g = _scene(name, device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    bgn = np.array(BACKGROUND_V1, np.float32)
+    th, tw = -(-H // 16), -(-W // 16)
+
+    # ---- the user's call (fused path, rule-chosen grid), three frames: first frame split, then the rule's
+    _fused._state.clear()
+    ms.render._bin_mode.clear()
+    frames = [ms.render_gaussians(*g, cam, background_color=bg, backend="hip") for _ in range(3)]
+    chosen = next(iter(ms.render._bin_mode.values()))
+    # ---- per-stage HIP path
+    m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+    ids, ranges = bin_gaussians_to_tiles_hip(m2, rad, dep, 16, tw, th)
+    st = rasterize_gaussians_hip(m2, con, g[4], g[3], bg, ranges, ids, cam)
+    for k, f in enumerate(frames):
+        assert torch.equal(f, st), f"{name}: fused frame {k} differs from the per-stage path"
+    for b in (16, 32, 64):     # every grid, explicitly: the same pixels
+        assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, bin_size=b), st), (name, b)
+    # every tile's list sorted by (depth bits, id)
+    cnt = (ranges[..., 1] - ranges[..., 0]).flatten().long()
+    key = (dep.view(torch.int32).to(torch.int64)[ids.long()] << 32) | ids.long()
+    tile_of = torch.repeat_interleave(torch.arange(th * tw, device=device), cnt)
+    assert bool(((tile_of[1:] > tile_of[:-1]) | ((tile_of[1:] == tile_of[:-1]) & (key[1:] > key[:-1]))).all())
+    M_hip = int(ids.numel())
+    del key, tile_of, cnt, ids, ranges, frames
+
+    # ---- oracle, full size
+    cpu = {k: np_(v.float()) for k, v in sc.items()}
+    ref, aux = oracle.render_fwd(cpu["means3d"], cpu["scales"], cpu["quats"], cpu["opacities"], cpu["features"],
+                                 np_(cam.view_matrix), cam.fx, cam.fy, cam.cx, cam.cy, W, H, background=bgn,
+                                 margin=True)
+    f64 = oracle.rasterize_fwd(aux["means2d"], aux["conics"], cpu["features"], cpu["opacities"], bgn, aux["ranges"],
+                               aux["ids"], H, W, 16, f64=True)
+    print(f"{name}: N={N} M_oracle={aux['M']} M_hip={M_hip} bin rule chose {chosen} px")
+    assert abs(M_hip - aux["M"]) <= max(50, aux["M"] // 100_000)   # a handful of +-1 radius flips (expf/logf ulps)
+
+    # ---- stage-wise: HIP binning + rasteriser on the ORACLE's projected inputs
+    to = lambda a: torch.from_numpy(a).to(device)
+    oids, oranges = bin_gaussians_to_tiles_hip(to(aux["means2d"]), to(aux["radii"]), to(aux["depths"]), 16, tw, th)
+    assert np.array_equal(np_(oids), aux["ids"]) and np.array_equal(np_(oranges), aux["ranges"])
+    img, alphas, last = rasterize_gaussians_hip(to(aux["means2d"]), to(aux["conics"]), g[4], g[3], bg, oranges, oids,
+                                                cam, return_aux=True)
+    check_image_strict(img, ref, aux["margin"], tag=f"{name} rasteriser on oracle inputs", eps=1e-5, f64=f64)
+    calm = aux["margin"] >= 1e-5
+    assert np.array_equal(np_(last)[calm], aux["last_ids"][calm])
+    assert np.abs(np_(alphas) - aux["alphas"])[calm].max() <= 1e-5
+    del img, alphas, last, oids, oranges
+
+    # ---- end to end: the fused frame (GPU projection) against the oracle's frame
+    check_image_strict(st, ref, aux["margin"], tag=f"{name} fused frame end to end", eps=1e-4)
+
+
+def test_config5_as_eight_bands_equals_the_single_gpu_frame(device):
+    """BASELINE config 5 is the 8-GPU config: each rank's band through the sharded entry point (rehearse =
+    act as that rank without a process group) lands in its slab; the assembled frame is the single-GPU one."""
+    sc, cam, g = _scene("cfg5", device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    H, W = cam.H, cam.W
+    full = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    th = -(-H // 16)
+    for world in (8, 3):
+        rows, bands = band_plan(th, world)
+        out = torch.zeros_like(full)
+        for r, (r0, r1) in enumerate(bands):
+            img = render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world))
+            y0, y1 = min(r0 * 16, H), min(r1 * 16, H)
+            out[y0:y1] = img[y0:y1]
+        assert torch.equal(out, full), world
+
+
+def test_config3_backward_full_size(device):
+    """Config 3 forward + backward at full size: gradients for means / scales / quats / opacities / colours
+    finite, non-zero, repeatable within the order of the float atomics, and equal to the per-stage
+    autograd functions (the fused differentiable frame runs tight binning + sync-free)."""
+    from mojosplat_amd.autograd import render_gaussians_trainable
+    sc, cam, g = _scene("cfg3", device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    v_img = torch.rand(cam.H, cam.W, 3, generator=torch.Generator().manual_seed(43)).to(device)
+    res = []
+    for stagewise in (False, False, True):
+        leaves = [sc[k].clone().requires_grad_(True) for k in names]
+        img = render_gaussians_trainable(*leaves, cam, background_color=bg, stagewise=stagewise)
+        (img * v_img).sum().backward()
+        res.append((img.detach(), [l.grad for l in leaves]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])
+    assert torch.equal(res[0][0], ms.render_gaussians(*g, cam, background_color=bg, backend="hip"))
+    for name, a, b, c in zip(names, res[0][1], res[1][1], res[2][1]):
+        assert torch.isfinite(a).all() and a.abs().sum() > 0, name
+        scale = float(c.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-6, f"{name}: not repeatable"
+        assert float((a - c).abs().max()) <= 1e-4 * scale + 1e-6, f"{name}: fused != per-stage"
+
+
+def test_config3_crop_backward_vs_float64_autograd(device):
+    """A 20k-Gaussian crop of config 3's scene (the Gaussians nearest the image centre, on a 320x192 window of
+    the same camera): HIP gradients against float64 autograd of the restatement, 5e-3 of each tensor's max."""
+    from mojosplat_amd.autograd import project_gaussians_autograd, render_gaussians_trainable
+    from mojosplat_amd.utils import Camera
+    from oracle import torch_oracle
+    sc, cam0, _ = _scene("cfg3", device)
+    W, H = 320, 192
+    cam = Camera(R=cam0.R, T=cam0.T, H=H, W=W, fx=cam0.fx, fy=cam0.fy, cx=W / 2.0, cy=H / 2.0, near=cam0.near,
+                 far=cam0.far)
+    with torch.no_grad():
+        m2, _, _, rad = ms.project_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], cam, backend="hip")
+        vis = (rad > 0).all(1)
+        d2 = ((m2 - torch.tensor([W / 2.0, H / 2.0], device=device)) ** 2).sum(1)
+        d2[~vis] = float("inf")
+        keep = torch.argsort(d2)[:20_000]
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    leaves = [sc[k][keep].clone().requires_grad_(True) for k in names]
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    v_img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(43)).to(device)
+    img = render_gaussians_trainable(*leaves, cam, background_color=bg)
+    (img * v_img).sum().backward()
+
+    with torch.no_grad():
+        m2h, conh, deph, radh = project_gaussians_autograd(*[l.detach() for l in leaves[:4]], cam)
+    ids, ranges = bin_gaussians_to_tiles_hip(m2h, radh, deph, 16, W // 16, H // 16)
+    rl = [l.detach().double().cpu().requires_grad_(True) for l in leaves]
+    rm2, rcon, _ = torch_oracle.project(rl[0], rl[1], rl[2], cam.view_matrix.double().cpu(), cam.fx, cam.fy, cam.cx,
+                                        cam.cy, W, H)
+    rimg, _ = torch_oracle.rasterize(rm2, rcon, rl[4], rl[3], bg.double().cpu(), ranges.cpu(), ids.cpu(), H, W, 16)
+    d = (img.detach().double().cpu() - rimg.detach()).abs()
+    assert float((d > 1e-4).float().mean()) <= 1e-4 and float(d.max()) <= 1e-2   # branch flips only
+    (rimg * v_img.double().cpu()).sum().backward()
+    for name, a, b in zip(names, leaves, rl):
+        got, ref = a.grad.double().cpu(), b.grad
+        err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+        assert err <= 5e-3 * scale + 1e-6, f"{name}: max err {err:.3g} vs scale {scale:.3g}"

@@ -151,13 +151,18 @@ def test_multi_view_batch_equals_single_views(device):
 
 @pytest.fixture
 def default_grid_only():
-    """render_gaussians without its race between binning granularities: every frame on the default grid."""
+    """render_gaussians without its binning-granularity rule: every frame on the default grid."""
+    import os
     from mojosplat_amd import render as R
-    old, R._BIN_MODES = R._BIN_MODES, (16,)
-    R._BIN_CHOICE.clear()
+    old = os.environ.get("MOJOSPLAT_BIN_PX")
+    os.environ["MOJOSPLAT_BIN_PX"] = "16"
+    R._bin_mode.clear()
     yield
-    R._BIN_MODES = old
-    R._BIN_CHOICE.clear()
+    if old is None:
+        os.environ.pop("MOJOSPLAT_BIN_PX", None)
+    else:
+        os.environ["MOJOSPLAT_BIN_PX"] = old
+    R._bin_mode.clear()
 
 
 def _stack_scene(n, z_lo, z_hi, opacity, device, seed=0):
@@ -253,29 +258,26 @@ def test_clean_up_pass_with_fp16_colours(device, default_grid_only, n, z_hi, opa
     _fused._state.clear()
 
 
-def test_binning_race_settles_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
+def test_binning_rule_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
     """A pile of faint Gaussians: the lazily sorted split frame fails its fronts and the lane falls back to
-    full sorts on 16-px tiles, which count other things than 32-px bins do.  The race between the binning
-    grids must run once all the same (its drift detector compares like with like, and a lane keeps what it
-    learnt about a grid while the race visits the others), every frame exact."""
+    full sorts, while render_gaussians' binning rule (big footprints -> plain coarse bins) moves the grid
+    after the first frame.  Every frame on the way is exact, and the rule settles (same mode from the third
+    frame on)."""
     from mojosplat_amd import render as R
     sc, cam = _stack_scene(4000, 4.0, 6.0, 0.005, device)
     bg = torch.tensor(BACKGROUND_V1, device=device)
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     ref = stagewise(sc, cam, bg, 16)
     _fused._state.clear()
-    R._BIN_CHOICE.clear()
-    races = []
-    start = R._BinTuner._start_race
+    R._bin_mode.clear()
     try:
-        R._BinTuner._start_race = lambda self: (races.append(1), start(self))[1]
-        for _ in range(60):
+        modes = []
+        for _ in range(24):
             assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, backend="hip"), ref)
-        (tuner,) = R._BIN_CHOICE.values()
-        assert len(races) == 1 and not tuner.queue, len(races)
+            modes.append(next(iter(R._bin_mode.values())))
+        assert len(set(modes[2:])) == 1, modes
     finally:
-        R._BinTuner._start_race = start
-        R._BIN_CHOICE.clear()
+        R._bin_mode.clear()
         _fused._state.clear()
 
 
@@ -401,19 +403,25 @@ def test_frame_does_not_depend_on_the_binning_granularity(device):
         _fused._state.clear()
         for _ in range(2):
             assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, tile_size=ts, backend="hip"), ref), ts
-    # the automatic choice: a race between the modes over the first frames, same pixels throughout
+    # explicit bin sizes, and the automatic choice (a rule on the previous frame's record): same pixels
+    for b in (16, 32, 64):
+        _fused._state.clear()
+        for _ in range(2):
+            assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, bin_size=b, backend="hip"), ref), b
+    with pytest.raises(ValueError, match="bin_size"):
+        ms.render_gaussians(*g, cam, background_color=bg, bin_size=48, backend="hip")
     _fused._state.clear()
-    R._BIN_CHOICE.clear()
+    R._bin_mode.clear()
     try:
         seen = set()
-        for _ in range(3 * (1 + R._TIMED_FRAMES) + 1):
-            tuner = R._tuner(g[0], cam, 16)
-            seen.add(tuner.next()[0])
+        for _ in range(6):
             assert torch.equal(ms.render_gaussians(*g, cam, background_color=bg, backend="hip"), ref)
-        (tuner,) = R._BIN_CHOICE.values()
-        assert seen >= {16, 32} and not tuner.queue and tuner.choice in seen
+            seen.add(next(iter(R._bin_mode.values())))
+        assert len(R._bin_mode) == 1 and seen <= {16, 32, 64}
+        best, times = R.tune_binning(*g, cam, background_color=bg, frames=2)   # the opt-in measurement
+        assert best in (16, 32, 64) and set(times) == {16, 32, 64} and all(t > 0 for t in times.values())
     finally:
-        R._BIN_CHOICE.clear()
+        R._bin_mode.clear()
         _fused._state.clear()
 
 

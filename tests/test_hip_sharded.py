@@ -31,3 +31,22 @@ def test_sharded_hip_path_with_a_process_group(world):
     assert r.returncode == 0, out[-3000:]
     for rank in range(world):
         assert f"rank {rank}/{world}: sharded frames (blocking + pipelined) equal the single-GPU frame" in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no launcher, no WORLD_SIZE): bench.py starts
+    the ranks itself as a child process, relays rank 0's JSON line and the return code.  On this one-GPU box
+    the two ranks share the device over gloo (MOJOSPLAT_BENCH_REHEARSE=1; RCCL refuses two ranks per device)."""
+    import json
+    env = dict(os.environ, MOJOSPLAT_BENCH_REHEARSE="1", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--workload", "cfg2", "--no-extras"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl"]["world"] == 2 and out["rccl"]["backend"] == "gloo"
+    assert out["verified"] is True and out["max_abs_vs_stagewise"] == 0.0 and out["value"] > 0
+    assert "REHEARSAL" in out["data"]

@@ -194,46 +194,31 @@ def test_c_abi_argument_validation_returns_status_codes():
     assert L.ms_render_workspace_bytes(N, 1, 1) >= L.ms_isect_workspace_bytes(N, 1, 1)
 
 
-def test_bin_tuner_races_the_modes_and_keeps_the_fastest():
-    """render.py's binning-granularity race: one warm-up + a few timed frames per mode, 64 px skipped when
-    32 px already lost clearly, re-run every _REPROBE_EVERY frames."""
+def test_bin_rule_on_the_baseline_configs():
+    """render.py's binning-granularity rule: footprint diameter and density estimated from a frame's
+    size record (pairs M on the grid it ran on, Gaussians on the grid) pick split / 32 / 64 px.  The
+    records below are the measured ones of profiles/r01_bin_modes.txt (M per mode; on-grid counts from
+    the scenes), with the mode that was fastest on the GPU."""
     from mojosplat_amd import render as R
-
-    def race(t, cost):
-        order = []
-        while t.queue:
-            mode, timed = t.next()
-            order.append((mode, timed))
-            t.done(mode, cost[mode] if timed else None)
-        return order
-
-    t = R._BinTuner()
-    order = race(t, {16: 1.0, 32: 0.8, 64: 0.9})
-    per_mode = 1 + R._TIMED_FRAMES
-    assert order == [(m, k > 0) for m in (16, 32, 64) for k in range(per_mode)]
-    assert t.choice == 32 and t.next() == (32, False)
-    t = R._BinTuner()
-    order = race(t, {16: 1.0, 32: 1.5, 64: 0.1})       # 64 is never tried
-    assert [m for m, _ in order] == [16] * per_mode + [32] * per_mode and t.choice == 16
-    # a frame whose intersection count has drifted from the race's restarts it
-    t2 = R._BinTuner()
-    while t2.queue:
-        mode, timed = t2.next()
-        t2.done(mode, {16: 1.0, 32: 2.0}[mode] if timed else None, (1000, 8))
-    assert t2.choice == 16
-    assert not t2.done(*t2.next()[:1], None, (1000, 8)) and not t2.done(*t2.next()[:1], None, (1100, 8))
-    assert not t2.queue
-    # another kind of frame (the lane fell back to full sorts on 16-px tiles) counts something else: no drift
-    assert not t2.done(*t2.next()[:1], None, (1700, 0)) and not t2.queue
-    # ... but not within _MIN_SETTLED frames of the last race (two scenes taking turns behind one key)
-    assert not t2.done(*t2.next()[:1], None, (2000, 8)) and not t2.queue
-    for _ in range(R._MIN_SETTLED):
-        assert not t2.done(*t2.next()[:1], None, (2000, 8))
-    assert t2.done(*t2.next()[:1], None, (3000, 8))
-    assert t2.queue and t2.next() == (16, False)
-    # a stale done() (another mode than announced) is ignored; the race comes round again
-    t.done(64, 0.0)
-    assert t.choice == 16
-    for _ in range(R._REPROBE_EVERY - 1):
-        assert t.next() == (16, False)
-    assert t.next() == (16, False) and t.queue     # the first frame of the next race: warm-up at 16
+    W, H = 1920, 1080
+    cases = {   # name: (on_grid, {mode: M}, W, H, fastest)
+        "cfg2": (95_000, {16: 195_694, 32: 195_858, 64: 140_298}, W, H, 16),
+        "cfg3": (950_000, {16: 1_966_222, 32: 1_967_590, 64: 1_406_830}, W, H, 16),
+        "cfg2-heavy": (95_000, {16: 472_816, 32: 473_006, 64: 245_133}, W, H, 32),
+        "cfg3-heavy": (950_000, {16: 4_763_542, 32: 4_765_457, 64: 2_463_575}, W, H, 64),
+        "cfg5": (4_700_000, {16: 17_106_998, 32: 17_119_671, 64: 9_899_012}, 3840, 2160, 64),
+    }
+    for name, (n, ms_, w, h, best) in cases.items():
+        for mode, m in ms_.items():       # whatever grid the previous frame ran on, the verdict is the same
+            assert R.bin_rule(mode, m, n, w, h) == best, (name, mode)
+    # config 4 (small footprints, 2700 entries per tile): 32 px from a split frame's record; 0.64 vs 0.66 ms
+    # at 64 px, so a record taken at 64 px may keep 64
+    assert R.bin_rule(16, 10_933_155, 5_700_000, 1600, 1063) == 32
+    assert R.bin_rule(64, 8_128_726, 5_700_000, 1600, 1063) in (32, 64)
+    # dead band: a scene sitting on a threshold keeps the mode it has
+    n, T = 100_000, 120 * 68
+    p_at = lambda d, g: (d / g + 1.0) ** 2
+    for mode, g in ((16, 32), (32, 32)):
+        assert R.bin_rule(mode, int(n * p_at(R._D_SPLIT * 1.02, g)), n, W, H) == mode
+        assert R.bin_rule(mode, int(n * p_at(R._D_SPLIT * 0.98, g)), n, W, H) == mode
+    assert R.bin_rule(16, 0, 0, W, H) == 16 and R.bin_rule(64, 0, 5, W, H) == 64    # empty frames decide nothing
