@@ -126,8 +126,10 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     H, W = camera.H, camera.W
     th = -(-H // tile_size)
     rows, bands = band_plan(th, world)
+    # the background takes the colours' dtype first, as in render_gaussians (reference render.py:55): with
+    # fp16 colours 0.1 is 0.09998 on every path
     bg = torch.zeros(C, device=dev, dtype=torch.float32) if background_color is None else \
-        torch.as_tensor(background_color, dtype=torch.float32, device=dev)
+        torch.as_tensor(background_color, device=dev).to(features.dtype).to(torch.float32)
     if bg.shape[0] != C:
         raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color channels ({C})")
 

@@ -57,7 +57,9 @@ _STAGE_HOOK = None
 _BIN_MODES = (16, 32, 64)
 _D_SPLIT, _E_SPLIT_DENSE, _E_COARSE = 24.0, 2000.0, 600.0
 _DEAD_BAND = 0.10
+_MIN_SETTLED = 64
 _bin_mode = {}            # (device, N to ~9 %, W, H) -> bin px of the next frame
+_bin_left = {}            # same key -> (the grid last switched away from, frames since)
 _bin_lock = threading.Lock()
 
 
@@ -73,7 +75,13 @@ def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int) -> int:
     if m <= 0 or on_grid <= 0:
         return mode
     g = 32 if mode == 16 else mode
-    d = g * (math.sqrt(max(m / on_grid, 1.0)) - 1.0)
+    p = max(m / on_grid, 1.0)
+    bins = math.ceil(W / g) * math.ceil(H / g)
+    if p >= 0.8 * bins:
+        # footprints as large as the image (every Gaussian in nearly every bin): the estimate below is
+        # clamped by the grid and says nothing; such a scene wants the coarsest bins
+        return 64
+    d = g * (math.sqrt(p) - 1.0)
     e = on_grid * (d / 16.0 + 1.0) ** 2 / (math.ceil(W / 16) * math.ceil(H / 16))
     lo, hi = _rule(d, e, 1.0 - _DEAD_BAND), _rule(d, e, 1.0 + _DEAD_BAND)
     return lo if lo == hi else mode     # inside a dead band: stay
@@ -186,6 +194,13 @@ def render_gaussians(
                 with _bin_lock:
                     if len(_bin_mode) >= 256 and key not in _bin_mode:
                         _bin_mode.pop(next(iter(_bin_mode)))
+                        _bin_left.pop(next(iter(_bin_left)), None)
+                    # never straight back to the grid just left (estimates taken on different grids can
+                    # disagree at the margins: no frame-by-frame flip-flop); after _MIN_SETTLED frames it may
+                    left, age = _bin_left.get(key, (None, 0))
+                    if nxt != mode and nxt == left and age < _MIN_SETTLED:
+                        nxt = mode
+                    _bin_left[key] = (mode, 0) if nxt != mode else (left, age + 1)
                     _bin_mode[key] = nxt
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are

@@ -10,7 +10,7 @@ Per config:
     (<= 1e-4 abs per pixel fp32 except where a branch of the walk sits within 1e-5 of its threshold;
     zero unexplained pixels), `last_ids` equal wherever no branch is close;
   * the fused frame end to end (its own projection) against oracle.render_fwd under the same rule with the
-    margin widened to 1e-4 (the two projections differ by an ulp in exp(scale): conics move by 1e-7
+    margin widened to 2e-5 (the two projections differ by an ulp in exp(scale): conics move by 1e-7
     relative, which can only matter where a branch is within that of its threshold);
   * config 5 additionally as the 8 tile-row bands of the multi-GPU decomposition
     (render_gaussians_sharded(rehearse=(r, 8))): assembled bands == the single-GPU frame bit for bit;
@@ -54,13 +54,15 @@ def _scene(name, device):
 def test_config_forward_full_size_vs_oracle(device, name):
     N, W, H, ell, fp16 = CONFIGS[name]
     sc, cam, g = _scene(name, device)
-    bg = torch.tensor(BACKGROUND_V1, device=device)
-    bgn = np.array(BACKGROUND_V1, np.float32)
+    # render_gaussians casts the background to the colours' dtype (reference render.py:55): with fp16
+    # colours 0.1 becomes 0.09998; every path below gets that same value
+    bg = torch.tensor(BACKGROUND_V1, device=device).to(sc["features"].dtype)
+    bgn = np_(bg.float())
     th, tw = -(-H // 16), -(-W // 16)
 
     # ---- the user's call (fused path, rule-chosen grid), three frames: first frame split, then the rule's
     _fused._state.clear()
-    ms.render._bin_mode.clear()
+    ms.render._bin_mode.clear(); ms.render._bin_left.clear()
     frames = [ms.render_gaussians(*g, cam, background_color=bg, backend="hip") for _ in range(3)]
     chosen = next(iter(ms.render._bin_mode.values()))
     # ---- per-stage HIP path
@@ -102,7 +104,7 @@ def test_config_forward_full_size_vs_oracle(device, name):
     del img, alphas, last, oids, oranges
 
     # ---- end to end: the fused frame (GPU projection) against the oracle's frame
-    check_image_strict(st, ref, aux["margin"], tag=f"{name} fused frame end to end", eps=1e-4)
+    check_image_strict(st, ref, aux["margin"], tag=f"{name} fused frame end to end", eps=2e-5)
 
 
 def test_config5_as_eight_bands_equals_the_single_gpu_frame(device):

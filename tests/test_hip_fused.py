@@ -156,13 +156,13 @@ def default_grid_only():
     from mojosplat_amd import render as R
     old = os.environ.get("MOJOSPLAT_BIN_PX")
     os.environ["MOJOSPLAT_BIN_PX"] = "16"
-    R._bin_mode.clear()
+    R._bin_mode.clear(); R._bin_left.clear()
     yield
     if old is None:
         os.environ.pop("MOJOSPLAT_BIN_PX", None)
     else:
         os.environ["MOJOSPLAT_BIN_PX"] = old
-    R._bin_mode.clear()
+    R._bin_mode.clear(); R._bin_left.clear()
 
 
 def _stack_scene(n, z_lo, z_hi, opacity, device, seed=0):
@@ -269,7 +269,7 @@ def test_binning_rule_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     ref = stagewise(sc, cam, bg, 16)
     _fused._state.clear()
-    R._bin_mode.clear()
+    R._bin_mode.clear(); R._bin_left.clear()
     try:
         modes = []
         for _ in range(24):
@@ -277,7 +277,7 @@ def test_binning_rule_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
             modes.append(next(iter(R._bin_mode.values())))
         assert len(set(modes[2:])) == 1, modes
     finally:
-        R._bin_mode.clear()
+        R._bin_mode.clear(); R._bin_left.clear()
         _fused._state.clear()
 
 
@@ -411,7 +411,7 @@ def test_frame_does_not_depend_on_the_binning_granularity(device):
     with pytest.raises(ValueError, match="bin_size"):
         ms.render_gaussians(*g, cam, background_color=bg, bin_size=48, backend="hip")
     _fused._state.clear()
-    R._bin_mode.clear()
+    R._bin_mode.clear(); R._bin_left.clear()
     try:
         seen = set()
         for _ in range(6):
@@ -421,7 +421,7 @@ def test_frame_does_not_depend_on_the_binning_granularity(device):
         best, times = R.tune_binning(*g, cam, background_color=bg, frames=2)   # the opt-in measurement
         assert best in (16, 32, 64) and set(times) == {16, 32, 64} and all(t > 0 for t in times.values())
     finally:
-        R._bin_mode.clear()
+        R._bin_mode.clear(); R._bin_left.clear()
         _fused._state.clear()
 
 
