@@ -13,7 +13,9 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmojosplat_hip.so")
+# MOJOSPLAT_HIP_LIB: another build of the same library (the -DMS_DIAG one of scripts/raster_waves.py)
+_LIB_PATH = os.environ.get("MOJOSPLAT_HIP_LIB") or \
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmojosplat_hip.so")
 _lib = None
 
 ABI_VERSION = 1

@@ -28,6 +28,7 @@
 //   <PACK> / <SPLIT>  kernel variants of split frames: 32-px bins whose keys carry the 4 block bits of
 //                     their entry and whose sorted lists leave the sort kernels as four 16x16-block
 //                     lists (emit_block_lists)
+#include <hip/hip_fp16.h>
 #include <string.h>
 
 #include <mutex>
@@ -285,7 +286,8 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     ms::ProjParams P, Grid g, int64_t chunk, float *__restrict__ means2d, float *__restrict__ conics,
     float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist,
-    uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks) {
+    uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks,
+    const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
@@ -306,6 +308,23 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
             conics[3 * i + 2] = o.c2;
             depths[i] = o.d;
             reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
+            if (rec && o.r0 > 0 && o.r1 > 0) {
+                // the rasteriser's staged record, ready made (ms::RasterRecord, ms_common.hpp): three 16-byte
+                // words per visible Gaussian instead of seven scattered 4-12-byte gathers + arithmetic per
+                // (tile, Gaussian) pair.  Same expressions as the rasteriser's own staging: same bits.
+                float col[3];
+                if (color_f16) {
+                    const __half *c = reinterpret_cast<const __half *>(colors) + 3 * i;
+                    col[0] = __half2float(c[0]); col[1] = __half2float(c[1]); col[2] = __half2float(c[2]);
+                } else {
+                    const float *c = reinterpret_cast<const float *>(colors) + 3 * i;
+                    col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
+                }
+                const ms::RasterRecord r = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], col[0], col[1], col[2]);
+                rec[3 * i] = r.a;
+                rec[3 * i + 1] = r.b;
+                rec[3 * i + 2] = r.c;
+            }
             if (o.r0 > 0 && o.r1 > 0) {
                 on_grid = bin_box<PACK>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
@@ -1273,7 +1292,23 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
                                       int32_t *radii, void *workspace, size_t workspace_bytes,
                                       int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
                                       void *stream_) {
+    return ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy, cx, cy, W, H,
+                                   eps2d, near_plane, far_plane, radius_clip, tile_size, row_begin, row_end, tight,
+                                   means2d, conics, depths, radii, workspace, workspace_bytes, tile_ranges, isect_info,
+                                   isect_info_mirror, nullptr, 0, nullptr, stream_);
+}
+
+int ms::project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                            const float *quats, const float *opacities, const float *viewmat,
+                            float fx, float fy, float cx, float cy, int W, int H, float eps2d,
+                            float near_plane, float far_plane, float radius_clip, int tile_size,
+                            int row_begin, int row_end, int tight, float *means2d, float *conics,
+                            float *depths,
+                            int32_t *radii, void *workspace, size_t workspace_bytes,
+                            int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
+                            const void *colors3, int color_dtype, void *raster_records, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (!opacities || !colors3) raster_records = nullptr;
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && fx != 0.f && fy != 0.f, MS_ERR_INVALID_ARG,
                "project_isect_count: bad sizes / camera");
     const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
@@ -1310,7 +1345,8 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
-                           quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks);
+                           quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks,
+                           colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records);
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,

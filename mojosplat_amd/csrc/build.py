@@ -29,16 +29,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """diag=True builds libmojosplat_hip_diag.so with -DMS_DIAG (per-wave stamps in the rasteriser;
+    scripts/raster_waves.py) next to the product library -- never loaded unless MOJOSPLAT_HIP_LIB names it."""
+    lib = LIB.replace(".so", "_diag.so") if diag else LIB
+    if not diag and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in _sources():
-        obj = os.path.splitext(src)[0] + ".o"
+        obj = os.path.splitext(src)[0] + (".diag.o" if diag else ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"] + (["-DMS_DIAG"] if diag else [])
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
             print(" ".join(cmd))
@@ -47,11 +50,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError(f"hipcc failed for: {failed}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib + ".tmp"] + objs
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, diag="--diag" in sys.argv))

@@ -35,6 +35,46 @@ constexpr float kAlphaThreshold = 1.0f / 255.0f;
 constexpr float kMaxAlpha = 0.999f;
 constexpr float kTransmittanceStop = 1e-4f;
 
+// The rasteriser's staged record of one Gaussian (3 channels), as the fused frame's projection kernel
+// writes it once per Gaussian and as the rasteriser's own staging computes it from the per-stage arrays:
+//   a = (mean.x, mean.y, a', b')   a' = -log2(e)/2 * conic.a, b' = -log2(e) * conic.b
+//   b = (c', log2(opacity), r, g)  c' = -log2(e)/2 * conic.c
+//   c = (b, s, n_c, n_a)           s = log2(255 o) with slack (+inf: no bound, evaluate everywhere and take the
+//                                  generic blend loop; -inf: opacity < 1/255, reaches nothing),
+//                                  n_c = -conic.b / conic.c, n_a = -conic.b / conic.a
+// log2(alpha)(d) = a' dx^2 + b' dx dy + c' dy^2 + log2(o); a quad can blend the Gaussian iff the minimum of
+// -(a' dx^2 + b' dx dy + c' dy^2) over its pixel-centre rectangle is <= s.
+struct RasterRecord {
+    float4 a, b, c;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ RasterRecord make_raster_record(float mx, float my, float ca, float cb, float cc,
+                                                           float op, float r, float g, float b) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    RasterRecord o;
+    o.a = make_float4(mx, my, -0.5f * kLog2e * ca, -kLog2e * cb);
+    o.b = make_float4(-0.5f * kLog2e * cc, __log2f(op), r, g);
+    const float det = ca * cc - cb * cb;
+    const bool bounded = det > 0.f && ca > 0.f && cc > 0.f && op <= kMaxAlpha;
+    // (approximate reciprocals / log: their 1e-7 relative error is far inside the slack)
+    // opacity below 1/255 can never blend: -inf, no quad is reached
+    const float s = !(op >= kAlphaThreshold) ? -__builtin_huge_valf()
+                    : bounded ? (__log2f(op * 255.0f) * 1.0001f + 1.5e-4f) : __builtin_huge_valf();
+    o.c = make_float4(b, s, bounded ? -cb * __builtin_amdgcn_rcpf(cc) : 0.f, bounded ? -cb * __builtin_amdgcn_rcpf(ca) : 0.f);
+    return o;
+}
+#endif
+
+// binning.hip: ms_project_isect_count that also writes the rasteriser's records (raster_records: N x 48 B,
+// or null; colors3: the frame's colours, 3 channels, f32 or f16)
+int project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                        const float *quats, const float *opacities, const float *viewmat, float fx, float fy,
+                        float cx, float cy, int W, int H, float eps2d, float near_plane, float far_plane,
+                        float radius_clip, int tile_size, int row_begin, int row_end, int tight, float *means2d,
+                        float *conics, float *depths, int32_t *radii, void *workspace, size_t workspace_bytes,
+                        int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
+                        const void *colors3, int color_dtype, void *raster_records, void *stream);
+
 // Lazy sorting (binning.hip): tiles longer than front_threshold have only front_count[tile] sorted
 // entries; the rasteriser appends a tile to redo_list when pixels are still alive at the end of it.
 struct LazyLists {
@@ -52,12 +92,15 @@ struct LazyLists {
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
 
 // rasterize.hip: ms_rasterize_to_pixels_3dgs_fwd with a separate density hint (ms_render_fwd's
-// sync-free frames pass the buffer capacity as M and the previous frame's M as the hint)
+// sync-free frames pass the buffer capacity as M and the previous frame's M as the hint).
+// records: N ready-made RasterRecords (3 channels) or null; order: blockIdx -> 16x16 block of the band
+// (heaviest first) or null
 int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means2d, const float *conics,
                   const void *colors, int color_dtype, int CDIM, const float *opacities, const float *backgrounds,
                   int W, int H, int tile_size, int tile_row_begin, int tile_row_end, const int32_t *tile_ranges,
                   const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
-                  const LazyLists *lazy, void *after_raster_event, void *stream);
+                  const LazyLists *lazy, const void *records, const int32_t *order, void *after_raster_event,
+                  void *stream);
 
 // Block lists of a split frame (ms_render_fwd): what the sort kernels of 32-px bins write instead of
 // flatten_ids.  Bin `b` with list [start, start + n) owns block_ids[4 start, 4 (start + n)): its block q
@@ -80,7 +123,8 @@ int rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const floa
                         const void *colors, int color_dtype, int CDIM, const float *opacities,
                         const float *backgrounds, int W, int H, int block_row_begin, int block_row_end,
                         const int32_t *bin_ranges, const BlockLists *lists, float *render_colors,
-                        const LazyLists *lazy, void *after_raster_event, void *stream);
+                        const LazyLists *lazy, const void *records, const int32_t *order, void *after_raster_event,
+                        void *stream);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

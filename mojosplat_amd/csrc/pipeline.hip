@@ -14,7 +14,7 @@ namespace {
 
 struct WsLayout {
     size_t off_isect, isect_bytes, off_means2d, off_conics, off_depths, off_radii, off_ranges, off_info, off_bin_ranges,
-        off_bin_more, total;
+        off_bin_more, off_records, total;
 };
 
 WsLayout ws_layout(int64_t N, int tw, int th) {
@@ -30,6 +30,7 @@ WsLayout ws_layout(int64_t N, int tw, int th) {
     L.off_info = o;    o += 256;
     L.off_bin_ranges = o; o += ms::align_up(T * 8, 256);   // split frames: ranges / flags of the 32-px bins
     L.off_bin_more = o;   o += ms::align_up(T * 4, 256);
+    L.off_records = o;    o += ms::align_up(n * sizeof(ms::RasterRecord), 256);   // the rasteriser's ready-made records
     L.total = o;
     return L;
 }
@@ -142,6 +143,9 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
     ms::LazyLists lazy_lists;
     if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, split ? bw : tw, split ? bh : th, &lazy_lists);
+    // the rasteriser's ready-made records (3-channel forward frames): written by the projection kernel
+    const bool use_records = CDIM == 3 && opacities && colors && !render_alphas && !last_ids;
+    void *records = use_records ? (void *)(ws + L.off_records) : nullptr;
     bool speculated = false;
     if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);
@@ -155,12 +159,13 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             (void)hipGetLastError();
             mirror = nullptr;
         }
-        if (int rc = ms_project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
-                                            cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,
-                                            split ? 32 : tile_size, split ? b0 : r0, split ? b1 : r1,
-                                            /*tight | ranges for the band only (| block masks)=*/split ? bin_flags : 1 | 2,
-                                            means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
-                                            split ? bin_ranges : ranges, info, (int64_t *)mirror, stream))
+        if (int rc = ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
+                                             cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,
+                                             split ? 32 : tile_size, split ? b0 : r0, split ? b1 : r1,
+                                             /*tight | ranges for the band only (| block masks)=*/split ? bin_flags : 1 | 2,
+                                             means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
+                                             split ? bin_ranges : ranges, info, (int64_t *)mirror,
+                                             use_records ? colors : nullptr, color_dtype, records, stream))
             return rc;
         mark(1);
         host_info[7] = no_split ? 16 : 0;
@@ -189,7 +194,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                 // (a 16-px grid holds ~1.7x the entries of the 32-px bins it was cut from)
                 if (int rc = ms::rasterize_fwd_split(N, c, prev[0] > 0 ? prev[0] * 17 / 10 : c, means2d, conics, colors,
                                                      color_dtype, CDIM, opacities, backgrounds, W, H, r0, r1,
-                                                     bin_ranges, &lists, render_colors, &lazy_lists,
+                                                     bin_ranges, &lists, render_colors, &lazy_lists, records, nullptr,
                                                      stage_events ? stage_events[3] : nullptr, stream))
                     return rc;
                 host_info[7] = 1 | 8;
@@ -204,7 +209,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
                                            render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr,
-                                           stage_events ? stage_events[3] : nullptr, stream))
+                                           records, nullptr, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0);
             }
@@ -270,6 +275,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
         lazy_lists.keys = keys;
         return ms::rasterize_fwd_split(N, c, M * 17 / 10, means2d, conics, colors, color_dtype, CDIM, opacities,
                                        backgrounds, W, H, r0, r1, bin_ranges, &lists, render_colors, &lazy_lists,
+                                       records, nullptr,
                                        (!speculated && stage_events) ? stage_events[3] : nullptr, stream);
     }
     if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
@@ -280,7 +286,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     lazy_lists.keys = keys;
     if (int rc = ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                                    tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
-                                   lazy ? &lazy_lists : nullptr,
+                                   lazy ? &lazy_lists : nullptr, records, nullptr,
                                    (!speculated && stage_events) ? stage_events[3] : nullptr, stream))
         return rc;
     return MS_OK;

@@ -57,11 +57,23 @@ struct RasterArgs {
     float *render_alphas;
     int32_t *last_ids;
     int W, H, ts, tw, nsx, nsub, cdim, tile0, nblocks, max_isects, n_gauss, parts;
+    const int32_t *order;  // blockIdx -> block (heaviest first), or null: xcd_remap
+    const float4 *records; // ready-made ms::RasterRecord per Gaussian (3 channels), or null: stage from the arrays
     ms::LazyLists lazy;   // front_count == nullptr: every list is fully sorted
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kBatch = 64;
+
+#ifdef MS_DIAG
+// Diagnostic build only (scripts/diag_build.py; never the shipped library): per-wave stamps of the
+// rasteriser -- start / end shader clock, evaluations, batches -- into a buffer of their own that no
+// other code reads (MI355X_MICROARCH.md, DVFS give-back (6): stamps never feed an output).
+__device__ unsigned long long *g_diag_stamps = nullptr;
+#define MS_DIAG_ONLY(...) __VA_ARGS__
+#else
+#define MS_DIAG_ONLY(...)
+#endif
 
 __device__ __forceinline__ float load_color(const float *p) { return *p; }
 __device__ __forceinline__ float load_color(const __half *p) { return __half2float(*p); }
@@ -78,23 +90,40 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
-// CP = compile-time channel capacity (>= runtime cdim).
+// CP = compile-time channel capacity (>= runtime cdim).  NQ = quads per wave: a 16x16 block belongs to ONE
+// workgroup of 4 / NQ waves (NQ = 4: one wave, 4 pixels per lane; 2: two waves, upper / lower 16x8 strip;
+// 1: four waves, one 8x8 quad and ONE pixel per lane each).  The waves of a workgroup are fully independent
+// (private LDS slice, no workgroup barrier anywhere): they share a workgroup so that they share a CU, i.e.
+// the L1 / L2 lines of the list they all stage.
+// PACKED: the frame's projection kernel has left one ready-made 48-byte record per Gaussian
+// (ms::RasterRecord): staging is three 16-byte gathers, the quad tests and three 16-byte LDS stores.
 // The staging lanes vote: B[q] = ballot(entry reaches quad q) -- a wave-uniform 64-bit mask per
 // quad.  Each quad then walks ITS set bits in order (front-to-back per pixel is preserved: the
-// four quads are disjoint pixel sets), so culled (quad, entry) pairs cost nothing, there is one
+// quads are disjoint pixel sets), so culled (quad, entry) pairs cost nothing, there is one
 // scalar branch per evaluation (the loop), and blend/stop are selects.  A finished pixel
 // raises its own alpha threshold to +inf, which folds the "still live" test into the
 // alpha >= 1/255 compare.
-// Waves are fully independent (one 16x16 block each, private LDS slice); WPB of them share a
-// workgroup only to fill the CU's wave slots -- there is no workgroup barrier anywhere.
+//
+// Round 2 (profiles/r02_raster_waves.md, per-wave stamps of scripts/raster_waves.py on config 3): with ~7
+// waves resident per SIMD the round-1 kernel issued VALU at the SIMD's rate (58-65 cycles per 64-pixel
+// evaluation and SIMD), but a wave ALONE needed ~400 cycles per evaluation (bit scan -> LDS round trip ->
+// 7 dependent FMAs -> exp -> compares -> select, strictly serial), its heaviest waves ran 500 evaluations =
+// 80 % of the kernel's duration and the last wave started at 60 % of it: mean residency 64 %.  Hence
+//   * the walk is software pipelined over two register sets that take turns (loop unrolled by two, no
+//     copies): the LDS reads of the next set bit fly while the current record is evaluated;
+//   * with ready-made records staging is cheap enough to give every quad its own wave (NQ = 1): the longest
+//     wave's work halves and twice as many, shorter waves fill the tail;
+//   * blocks are launched heaviest first (A.order, built by the binning stage) instead of in image order.
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int CP, typename ColorT, bool AUX, int WPB, int NQ>
-__global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(RasterArgs A) {
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
+__global__ __launch_bounds__(64 * (4 / NQ), (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(RasterArgs A) {
+    static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
+    constexpr int WPB = 4 / NQ;
     constexpr int CS = (CP == 3) ? 4 : CP;       // CP == 3: r,g ride in s_b; b alone at a 16-B stride (same LDS index as s_a/s_b)
     // one LDS block per wave, the three arrays at fixed offsets of it: with CS == 4 an entry's three
     // records sit at the SAME index * 16 B, so the blend loop forms one LDS address per evaluation
@@ -109,14 +138,11 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
     float4 *s_a = s_stage[wib].a, *s_b = s_stage[wib].b;
     float *s_col = s_stage[wib].col;
 
-    const int vbid = blockIdx.x * WPB + wib;
-    if (vbid >= A.nblocks) return;
-    // NQ quads per wave: 4 = one wave per 16x16 block; 2 = two waves per block (upper / lower 16x8
-    // strip), twice the waves so that the wave slots refill as light tiles finish
-    constexpr int kParts = 4 / NQ;
-    const int item0 = xcd_remap(vbid, A.nblocks);
-    const int item = item0 / kParts;
-    const int qbase = NQ == 4 ? 0 : __builtin_amdgcn_readfirstlane((item0 - item * kParts) * NQ);
+    MS_DIAG_ONLY(const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime(), diag_c0 = __builtin_amdgcn_s_memtime(); unsigned diag_evals = 0, diag_batches = 0;)
+    // blockIdx -> 16x16 block: heaviest first when the binning stage has left an order, else image order
+    // interleaved over the XCDs
+    const int item = A.order ? A.order[blockIdx.x] : xcd_remap(blockIdx.x, A.nblocks);
+    const int qbase = NQ == 4 ? 0 : wib * NQ;
     const int bt = item / A.nsub, sub = item - bt * A.nsub;
     const int tile = A.tile0 + bt;
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
@@ -151,7 +177,9 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
     const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
     const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
 
-    float r_mx = 0.f, r_my = 0.f, r_ca = 0.f, r_cb = 0.f, r_cc = 0.f, r_op = 0.f;
+    // what the staging lane holds of its entry: the record's three words (PACKED), or the per-stage fields
+    float4 r_a = make_float4(0.f, 0.f, 0.f, 0.f), r_b = r_a, r_c = r_a;
+    float r_ca = 0.f, r_cb = 0.f, r_cc = 0.f, r_op = 0.f;
     float r_col[CP];
     int r_g = 0;
     auto fetch_id = [&](int b0) {
@@ -164,12 +192,17 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
             // ids outside [0, N) can only come from a sync-free frame that overflowed its buffer (the
             // frame is then redone); clamp so that even that frame never reads out of bounds
             const int g = min(max(r_g, 0), A.n_gauss - 1);
-            const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
-            r_mx = m.x; r_my = m.y;
-            r_ca = A.conics[3 * g]; r_cb = A.conics[3 * g + 1]; r_cc = A.conics[3 * g + 2];
-            r_op = A.opacities[g];
+            if constexpr (PACKED) {
+                const float4 *rec = A.records + 3 * (size_t)g;
+                r_a = rec[0]; r_b = rec[1]; r_c = rec[2];
+            } else {
+                const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
+                r_a.x = m.x; r_a.y = m.y;
+                r_ca = A.conics[3 * g]; r_cb = A.conics[3 * g + 1]; r_cc = A.conics[3 * g + 2];
+                r_op = A.opacities[g];
 #pragma unroll
-            for (int k = 0; k < CP; ++k) r_col[k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
+                for (int k = 0; k < CP; ++k) r_col[k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
+            }
         }
     };
 
@@ -180,44 +213,44 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
     }
     for (int b0 = start; b0 < end; b0 += kBatch) {
         // --- stage this batch: record -> LDS, reach of the alpha >= 1/255 ellipse -> quad votes
+        // A quad can blend this Gaussian iff min over the quad's pixel-centre rectangle of
+        // sigma(p - mean) <= ln(255 o).  sigma is a convex quadratic, so the minimum over a box
+        // is 0 if the mean is inside, else it sits on the face(s) nearest the mean: one 1-D
+        // clamped minimisation per such face (exact; tighter than the ellipse's bounding box
+        // for elongated / rotated Gaussians).  Slack keeps the test conservative w.r.t. the
+        // per-pixel alpha >= 1/255 decision.  (In log2 units on the record's a', b', c'.)
         int mask = 0;
         bool npd = false;
-        if (b0 + lane < end && r_op >= ms::kAlphaThreshold) {
-            const float det = r_ca * r_cc - r_cb * r_cb;
-            if (det > 0.f && r_ca > 0.f && r_cc > 0.f) {
-                // A quad can blend this Gaussian iff min over the quad's pixel-centre rectangle of
-                // sigma(p - mean) <= ln(255 o).  sigma is a convex quadratic, so the minimum over a box
-                // is 0 if the mean is inside, else it sits on the face(s) nearest the mean: one 1-D
-                // clamped minimisation per such face (exact; tighter than the ellipse's bounding box
-                // for elongated / rotated Gaussians).  Slack keeps the test conservative w.r.t. the
-                // per-pixel alpha >= 1/255 decision.
-                const float smax = __logf(r_op * 255.0f) * 1.0001f + 1e-4f;
-                // (approximate reciprocals: their 1e-7 relative error is far inside the test's slack)
-                const float nb_c = -r_cb * __builtin_amdgcn_rcpf(r_cc), nb_a = -r_cb * __builtin_amdgcn_rcpf(r_ca);
+        if (b0 + lane < end) {
+            if constexpr (!PACKED) {
+                const ms::RasterRecord rr = ms::make_raster_record(r_a.x, r_a.y, r_ca, r_cb, r_cc, r_op, 0.f, 0.f, 0.f);
+                r_a = rr.a; r_b = rr.b; r_c = rr.c;
+            }
+            const float smax = r_c.y, nb_c = r_c.z, nb_a = r_c.w;
+            if (smax == kInf) {
+                mask = 0xf;   // not positive definite, or the 0.999 clamp can bind: no bound, generic loop
+                npd = true;
+            } else if (smax > -kInf) {
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) {
                     const int q = qbase + qi;
-                    const float xl = fbx + (float)((q & 1) * 8) - r_mx, xh = xl + 7.0f;   // rectangle - mean
-                    const float yl = fby + (float)((q >> 1) * 8) - r_my, yh = yl + 7.0f;
+                    const float xl = fbx + (float)((q & 1) * 8) - r_a.x, xh = xl + 7.0f;   // rectangle - mean
+                    const float yl = fby + (float)((q >> 1) * 8) - r_a.y, yh = yl + 7.0f;
                     const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
                     float best = (in_x && in_y) ? 0.f : 3.0e38f;
                     if (!in_x) {
                         const float dx = xl > 0.f ? xl : xh;
                         const float dy = fminf(fmaxf(nb_c * dx, yl), yh);
-                        best = 0.5f * (r_ca * dx * dx + r_cc * dy * dy) + r_cb * dx * dy;
+                        best = -(r_a.z * dx * dx + r_b.x * dy * dy + r_a.w * dx * dy);
                     }
                     if (!in_y) {
                         const float dy = yl > 0.f ? yl : yh;
                         const float dx = fminf(fmaxf(nb_a * dy, xl), xh);
-                        best = fminf(best, 0.5f * (r_ca * dx * dx + r_cc * dy * dy) + r_cb * dx * dy);
+                        best = fminf(best, -(r_a.z * dx * dx + r_b.x * dy * dy + r_a.w * dx * dy));
                     }
                     mask |= (best <= smax) ? (1 << qi) : 0;
                 }
-            } else {
-                mask = 0xf;  // not positive definite: no bound, evaluate everywhere
-                npd = true;
             }
-            npd = npd || r_op > ms::kMaxAlpha;  // the 0.999 clamp can bind: generic loop as well
         }
         unsigned long long B[NQ];
 #pragma unroll
@@ -225,12 +258,15 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
 
         wave_lds_sync();  // LDS reads of the previous batch are complete
         if (mask) {
-            s_a[lane] = make_float4(r_mx, r_my, -0.5f * kLog2e * r_ca, -kLog2e * r_cb);
-            if constexpr (CP == 3) {
-                s_b[lane] = make_float4(-0.5f * kLog2e * r_cc, __log2f(r_op), r_col[0], r_col[1]);
+            s_a[lane] = r_a;
+            if constexpr (PACKED) {
+                s_b[lane] = r_b;
+                reinterpret_cast<float4 *>(s_col)[lane] = r_c;   // CS == 4: the blue channel at index * 16 B
+            } else if constexpr (CP == 3) {
+                s_b[lane] = make_float4(r_b.x, r_b.y, r_col[0], r_col[1]);
                 s_col[lane * CS] = r_col[2];
             } else {
-                s_b[lane] = make_float4(-0.5f * kLog2e * r_cc, __log2f(r_op), 0.f, 0.f);
+                s_b[lane] = r_b;
 #pragma unroll
                 for (int k = 0; k < CP; ++k) s_col[lane * CS + k] = r_col[k];
             }
@@ -240,6 +276,7 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
             gather(b0 + kBatch);
             fetch_id(b0 + 2 * kBatch);
         }
+        MS_DIAG_ONLY(++diag_batches;)
 
         // sigma < 0 (skipped by the reference, rasterization.mojo:144) cannot happen for a positive
         // definite conic, and alpha = o exp(-sigma) <= o cannot exceed 0.999 unless o does: only a
@@ -248,24 +285,31 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
         bool any_live = false;
         auto blend_batch = [&](auto check) __attribute__((always_inline)) {
             constexpr bool CHECK = decltype(check)::value;
+            constexpr int RC = CP == 3 ? 1 : CP;   // CP == 3: r, g ride in the second word
+            struct Rec { float4 a, b; float c[RC]; int t; };
+            auto load = [&](Rec &r, int t) __attribute__((always_inline)) {
+                r.t = t;
+                r.a = s_a[t]; r.b = s_b[t];
+                if constexpr (CP == 3) r.c[0] = s_col[t * CS];
+                else {
+#pragma unroll
+                    for (int k = 0; k < CP; ++k) r.c[k] = s_col[t * CS + k];
+                }
+            };
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 const int q = qbase + qi;
                 if (!__any(thr[qi] < kInf)) continue;  // every pixel of this quad is finished (or outside)
                 const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
-                unsigned long long m = B[qi];
-                while (m) {
-                    const int t = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const float4 ra = s_a[t];
-                    const float4 rb = s_b[t];
-                    const float dx = ra.x - px, dy = ra.y - py;
+                auto eval = [&](const Rec &r) __attribute__((always_inline)) {
+                    MS_DIAG_ONLY(++diag_evals;)
+                    const float dx = r.a.x - px, dy = r.a.y - py;
                     // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
-                    const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
+                    const float la = fmaf(dx, fmaf(r.a.z, dx, r.a.w * dy), fmaf(r.b.x * dy, dy, r.b.y));
                     float alpha = __builtin_amdgcn_exp2f(la);
                     if constexpr (CHECK) alpha = fminf(ms::kMaxAlpha, alpha);
                     bool hit = alpha >= thr[qi];                                  // alpha >= 1/255, pixel live
-                    if constexpr (CHECK) hit = hit && la <= rb.y;               // sigma >= 0
+                    if constexpr (CHECK) hit = hit && la <= r.b.y;                // sigma >= 0
                     const float next_T = fmaf(-alpha, T[qi], T[qi]);            // T (1 - alpha)
                     const bool add = hit && next_T > ms::kTransmittanceStop;
                     // one select (v_cmp / v_cndmask issue at half the FMA rate on gfx950, v_exp at a
@@ -273,19 +317,43 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
                     const float a_eff = add ? alpha : 0.f;
                     const float vis = a_eff * T[qi];
                     if constexpr (CP == 3) {
-                        pix[qi][0] += rb.z * vis;
-                        pix[qi][1] += rb.w * vis;
-                        pix[qi][2] += s_col[t * CS] * vis;
+                        pix[qi][0] += r.b.z * vis;
+                        pix[qi][1] += r.b.w * vis;
+                        pix[qi][2] += r.c[0] * vis;
                     } else {
 #pragma unroll
-                        for (int k = 0; k < CP; ++k) pix[qi][k] += s_col[t * CS + k] * vis;
+                        for (int k = 0; k < CP; ++k) pix[qi][k] += r.c[k] * vis;
                     }
-                    if constexpr (AUX) last[qi] = add ? b0 + t : last[qi];
+                    if constexpr (AUX) last[qi] = add ? b0 + r.t : last[qi];
                     T[qi] = fmaf(-a_eff, T[qi], T[qi]);                         // next_T where blended, T elsewhere
                     // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path.
                     if (__ballot(hit && !add)) {
                         asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
                         thr[qi] = (hit && !add) ? kInf : thr[qi];
+                    }
+                };
+                unsigned long long m = B[qi];
+                if (m) {
+                    // two register sets take turns: the LDS reads of the NEXT set bit are in flight while
+                    // the current record is evaluated (the loop is unrolled by two, so nothing is copied)
+                    Rec r0, r1;
+                    load(r0, __ffsll((long long)m) - 1);
+                    m &= m - 1;
+                    for (;;) {
+                        bool more = m != 0;
+                        if (more) {
+                            load(r1, __ffsll((long long)m) - 1);
+                            m &= m - 1;
+                        }
+                        eval(r0);
+                        if (!more) break;
+                        more = m != 0;
+                        if (more) {
+                            load(r0, __ffsll((long long)m) - 1);
+                            m &= m - 1;
+                        }
+                        eval(r1);
+                        if (!more) break;
                     }
                 }
                 any_live = any_live || __any(thr[qi] < kInf);
@@ -296,6 +364,16 @@ __global__ __launch_bounds__(64 * WPB, (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(R
         if (!any_live) break;
     }
 
+#ifdef MS_DIAG
+    if (g_diag_stamps && lane == 0) {
+        unsigned long long *d = g_diag_stamps + 8 * ((size_t)blockIdx.x * WPB + wib);
+        d[0] = diag_t0;                               // 100 MHz, chip-wide
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[4] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this wave's life
+        d[2] = ((unsigned long long)diag_batches << 32) | diag_evals;
+        d[3] = ((unsigned long long)(end_all - start) << 32) | (unsigned)(__builtin_amdgcn_s_getreg((4 << 11) | 20) & 0xf) << 24 | (unsigned)(tile & 0xffffff);
+    }
+#endif
     int redo_tile = end < end_all ? tile : -1;  // wave-uniform; only heavy tiles of a lazily sorted frame
     if (A.lazy.bin_more) {   // split frame: this block's list was cut from the front of its 32-px bin
         const int bin = (tile_y >> 1) * A.lazy.bin_w + (tile_x >> 1);
@@ -550,15 +628,40 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     }
 }
 
+// MOJOSPLAT_RASTER_PARTS=1|2|4 forces the waves per 16x16 block (measurements); 0 / unset: the rule below
+static int raster_parts_override() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_RASTER_PARTS");
+        const int n = e ? atoi(e) : 0;
+        return (n == 1 || n == 2 || n == 4) ? n : 0;
+    }();
+    return v;
+}
+
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
-    const dim3 grid((unsigned)A.nblocks), block(64);
     const bool aux = A.render_alphas || A.last_ids;
-#define MS_LAUNCH_RASTER(AUXV, NQV) \
-    hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, 1, NQV>), grid, block, 0, stream, A)
-    if (A.parts == 2) { if (aux) MS_LAUNCH_RASTER(true, 2); else MS_LAUNCH_RASTER(false, 2); }
-    else if (A.parts == 4) { if (aux) MS_LAUNCH_RASTER(true, 1); else MS_LAUNCH_RASTER(false, 1); }
-    else { if (aux) MS_LAUNCH_RASTER(true, 4); else MS_LAUNCH_RASTER(false, 4); }
+    const dim3 grid((unsigned)A.nblocks);
+#define MS_LAUNCH_RASTER(AUXV, NQV, PK) \
+    hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, NQV, PK>), grid, dim3(64 * (4 / NQV)), 0, stream, A)
+#define MS_LAUNCH_RASTER_NQ(AUXV, PK)                              \
+    do {                                                           \
+        if (A.parts == 2) MS_LAUNCH_RASTER(AUXV, 2, PK);           \
+        else if (A.parts == 4) MS_LAUNCH_RASTER(AUXV, 1, PK);      \
+        else MS_LAUNCH_RASTER(AUXV, 4, PK);                        \
+    } while (0)
+    bool done = false;
+    if constexpr (CP == 3) {
+        if (A.records && !aux) {
+            MS_LAUNCH_RASTER_NQ(false, true);
+            done = true;
+        }
+    }
+    if (!done) {
+        if (aux) MS_LAUNCH_RASTER_NQ(true, false);
+        else MS_LAUNCH_RASTER_NQ(false, false);
+    }
+#undef MS_LAUNCH_RASTER_NQ
 #undef MS_LAUNCH_RASTER
     // in-situ timing of THIS kernel: the caller's event goes between it and the clean-up launch
     if (after_raster_event) (void)hipEventRecord((hipEvent_t)after_raster_event, stream);
@@ -588,6 +691,23 @@ void launch_redo(const RasterArgs &A, hipStream_t stream) {
 
 }  // namespace
 
+namespace {
+// Waves per 16x16 block.  One wave per block leaves a one-round launch (<= 8192 wave slots on
+// the chip) with a long tail: light tiles retire, their slots stay empty and the heavy tiles
+// finish at a fraction of the SIMD's issue rate.  Splitting blocks over 2 or 4 waves (each
+// stages the whole list but blends only its quads) refills the slots; the duplicated staging
+// only pays while staging is cheap against blending: with ready-made records (three 16-byte gathers
+// per entry, no arithmetic) every quad gets its own wave; staging from the per-stage arrays (seven
+// gathers + the folding arithmetic) 4 waves up to 150 entries per block, 2 up to 1 500, else 1.
+int choose_parts(int64_t blocks, int64_t density_hint, bool records) {
+    if (const int forced = raster_parts_override()) return forced;
+    if (records) return 4;
+    if (blocks >= 16384) return 1;   // many-round launches gain nothing
+    const int64_t per_block = density_hint / blocks;
+    return per_block > 1500 ? 1 : per_block > 150 ? 2 : 4;
+}
+}  // namespace
+
 // density_hint: intersections the band is expected to hold (the exact M when the caller knows it, the
 // previous frame's M on a sync-free frame) -- only steers how many waves share a 16x16 block.
 int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means2d, const float *conics,
@@ -595,7 +715,8 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
                       const float *backgrounds, int W, int H, int tile_size, int tile_row_begin,
                       int tile_row_end, const int32_t *tile_ranges, const int32_t *flatten_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
-                      const ms::LazyLists *lazy, void *after_raster_event, void *stream) {
+                      const ms::LazyLists *lazy, const void *records, const int32_t *order, void *after_raster_event,
+                      void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_fwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_fwd: CDIM %d not in 1..32", CDIM);
@@ -609,6 +730,8 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.means2d = means2d; A.conics = conics; A.colors = colors; A.opacities = opacities;
     A.backgrounds = backgrounds; A.tile_ranges = tile_ranges; A.flatten_ids = flatten_ids;
     A.render_colors = render_colors; A.render_alphas = render_alphas; A.last_ids = last_ids;
+    A.order = order;
+    A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     if (lazy) A.lazy = *lazy;
     else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0x7fffffff};
     A.W = W; A.H = H; A.ts = tile_size;
@@ -628,25 +751,21 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     }
     const int64_t blocks = (int64_t)band_tiles * A.nsub;
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
-    // Waves per 16x16 block.  One wave per block leaves a one-round launch (<= 8192 wave slots on
-    // the chip) with a long tail: light tiles retire, their slots stay empty and the heavy tiles
-    // finish at a fraction of the SIMD's issue rate.  Splitting blocks over 2 or 4 waves (each
-    // stages the whole list but blends only its quads) refills the slots; the duplicated staging
-    // only pays while lists are short.  Measured at 1080p: 50 entries/tile -> 4 waves (183 -> 138 us
-    // per frame), 500 -> 2 (raster 165 -> 145 us), 3 000 -> 1 (2 costs +7 %); many-round launches
-    // (4K: 32 400 blocks) gain nothing.
-    A.parts = 1;
-    if (blocks < 16384) {
-        const int64_t per_block = density_hint / blocks;
-        A.parts = per_block > 1500 ? 1 : per_block > 150 ? 2 : 4;
-    }
-    A.nblocks = (int)blocks * A.parts;
+    A.parts = choose_parts(blocks, density_hint, A.records != nullptr);
+    A.nblocks = (int)blocks;
     A.max_isects = (int)M;
     MS_REQUIRE(N > 0 || M == 0, MS_ERR_INVALID_ARG, "rasterize_fwd: M > 0 with N == 0");
     A.n_gauss = (int)(N < 0x7fffffffll ? (N > 0 ? N : 1) : 0x7fffffffll);
     if (color_dtype == MS_COLOR_F16) return launch_fwd<__half>(A, (hipStream_t)stream, after_raster_event);
     return launch_fwd<float>(A, (hipStream_t)stream, after_raster_event);
 }
+
+#ifdef MS_DIAG
+extern "C" int ms_diag_set_stamps(void *device_buffer) {
+    MS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_stamps), &device_buffer, sizeof(void *)));
+    return MS_OK;
+}
+#endif
 
 extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float *means2d,
                                                const float *conics, const void *colors,
@@ -659,14 +778,15 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
                                                void *stream) {
     return ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                              tile_size, tile_row_begin, tile_row_end, tile_ranges, flatten_ids, render_colors,
-                             render_alphas, last_ids, nullptr, nullptr, stream);
+                             render_alphas, last_ids, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const float *means2d, const float *conics,
                             const void *colors, int color_dtype, int CDIM, const float *opacities,
                             const float *backgrounds, int W, int H, int block_row_begin, int block_row_end,
                             const int32_t *bin_ranges, const ms::BlockLists *lists, float *render_colors,
-                            const ms::LazyLists *lazy, void *after_raster_event, void *stream_) {
+                            const ms::LazyLists *lazy, const void *records, const int32_t *order,
+                            void *after_raster_event, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MS_REQUIRE(N > 0 && cap > 0 && cap <= 0x1fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd_split: bad N/cap");
     MS_REQUIRE(W > 0 && H > 0 && CDIM >= 1 && CDIM <= 4, MS_ERR_INVALID_ARG, "rasterize_fwd_split: bad sizes");
@@ -688,6 +808,8 @@ int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const 
     A.means2d = means2d; A.conics = conics; A.colors = colors; A.opacities = opacities;
     A.backgrounds = backgrounds; A.tile_ranges = lists->block_ranges; A.flatten_ids = lists->block_ids;
     A.render_colors = render_colors; A.render_alphas = nullptr; A.last_ids = nullptr;
+    A.order = order;
+    A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     A.lazy = *lazy;
     A.lazy.front_count = nullptr;   // block lists are walked to their end; the bin's flag says whether that was all
     A.lazy.bin_more = lists->bin_more;
@@ -696,12 +818,8 @@ int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const 
     A.W = W; A.H = H; A.ts = 16; A.tw = tw16; A.nsx = 1; A.nsub = 1; A.cdim = CDIM;
     A.tile0 = r0 * tw16;
     const int64_t blocks = (int64_t)(r1 - r0) * tw16;
-    A.parts = 1;
-    if (blocks < 16384) {   // as rasterize_fwd
-        const int64_t per_block = density_hint / blocks;
-        A.parts = per_block > 1500 ? 1 : per_block > 150 ? 2 : 4;
-    }
-    A.nblocks = (int)blocks * A.parts;
+    A.parts = choose_parts(blocks, density_hint, A.records != nullptr);
+    A.nblocks = (int)blocks;
     A.max_isects = (int)(4 * cap);
     A.n_gauss = (int)(N < 0x7fffffffll ? N : 0x7fffffffll);
     if (int rc = color_dtype == MS_COLOR_F16 ? launch_fwd<__half>(A, stream, after_raster_event)
