@@ -416,9 +416,20 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
                                                           int32_t *__restrict__ redo_flag,
                                                           int32_t *__restrict__ redo_count,
                                                           int band_only, int64_t *__restrict__ info,
-                                                          int64_t *__restrict__ info_mirror) {
+                                                          int64_t *__restrict__ info_mirror,
+                                                          int32_t *__restrict__ order) {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
+    // heaviest-first order of the band's tiles for the rasteriser's launch (order[0 .. band tiles)): counting
+    // sort over 128 buckets of the list length (4 per octave); ties in whatever order the atomics fall
+    __shared__ unsigned int s_bkt[128], s_base[128];
+    auto bucket_of = [](unsigned int c) -> int {
+        if (c == 0) return 0;
+        const int l = 31 - __clz((int)c);
+        const int frac = l >= 2 ? (int)((c >> (l - 2)) & 3u) : (int)((c << (2 - l)) & 3u);
+        return 1 + 4 * l + frac;
+    };
+    if (threadIdx.x < 128) s_bkt[threadIdx.x] = 0;
     const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
     // band_only: tile_ranges is written for the band's tiles alone (a caller whose later stages all
     // stay inside the band -- ms_render_fwd on a multi-GPU rank -- saves the walk over the rest)
@@ -427,6 +438,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
     const int per_wave = ((t_hi - t_lo + 15) / 16 + 63) & ~63;   // tiles per wave, a multiple of 64
     const int w0 = t_lo + w * per_wave, w1 = min(t_hi, w0 + per_wave);
     if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; }
+    // (s_bkt is zeroed above and first added to after the __syncthreads() between the two passes)
     auto count_of = [&](int t) -> unsigned int {
         return (t < w1 && t >= band0 && t < band1) ? tile_count[t - band0] : 0u;
     };
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
             if (c > (unsigned)kLargeCapDecl) xl_list[atomicAdd(&s_nxl, 1u)] = t;
             else if (c > (unsigned)kMediumCapDecl) large_list[atomicAdd(&s_nlarge, 1u)] = t;
             else if (c > (unsigned)kSmallCapDecl) medium_list[atomicAdd(&s_nmedium, 1u)] = t;
+            if (order && t >= band0 && t < band1) atomicAdd(&s_bkt[bucket_of(c)], 1u);
         }
         run += (unsigned long long)__shfl((int)incl, 63);  // step total (< 2^31 per 64 tiles by int32 M limit)
     };
@@ -488,6 +501,28 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
     for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (unsigned int)__shfl_xor((int)lmax, d));
     if (lane == 0) atomicMax(&s_max, lmax);
     __syncthreads();
+    if (order) {
+        if (w == 0) {   // s_base[b] = tiles in heavier buckets (descending order): suffix sums over 128 buckets
+            const unsigned int c0 = s_bkt[127 - 2 * lane], c1 = s_bkt[126 - 2 * lane];   // lane 0 owns the heaviest two
+            unsigned int incl = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned int o = (unsigned int)__shfl_up((int)incl, d);
+                if (lane >= d) incl += o;
+            }
+            const unsigned int excl = incl - (c0 + c1);
+            s_base[127 - 2 * lane] = excl;
+            s_base[126 - 2 * lane] = excl + c0;
+        }
+        __syncthreads();
+        auto place = [&](int t, unsigned int c) {
+            if (t < w1 && t >= band0 && t < band1) order[atomicAdd(&s_base[bucket_of(c)], 1u)] = t;
+        };
+#pragma unroll
+        for (int k = 0; k < kPre; ++k)
+            if (w0 + k * 64 < w1) place(w0 + k * 64 + lane, pre[k]);
+        for (int tb = w0 + kPre * 64; tb < w1; tb += 64) place(tb + lane, count_of(tb + lane));
+    }
     if (threadIdx.x == 0) {
         info[0] = (int64_t)grand;
         info[1] = (int64_t)s_max;
@@ -1134,7 +1169,7 @@ struct Plan {
     int T, T_local;
     size_t lds_bytes;
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
-        off_redo_list, off_redo_count, off_depth_wg, total;
+        off_redo_list, off_redo_count, off_depth_wg, off_order, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -1159,6 +1194,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_redo_list = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_redo_count = o; o += 256;
     p.off_depth_wg = o;   o += ms::align_up((size_t)kMaxG * 8, 256);   // per-workgroup depth-bit min / max (k_isect_scatter)
+    p.off_order = o;      o += ms::align_up((size_t)p.T * 4, 256);     // the band's tiles, heaviest first (rasteriser launch order)
     // (the only N-dependent block comes last: everything above -- the clean-up count among it, which a caller
     // reads back one frame later -- stays where it is when the scene grows or shrinks on a fixed grid)
     p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
@@ -1207,7 +1243,7 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
     }
     hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium, large, xl,
                        wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count),
-                       band_only, isect_info, info_mirror);
+                       band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order));
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -1229,6 +1265,13 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->packed = 0;
     out->row_lo = 0;
     out->row_hi = 0x7fffffff;
+}
+
+// The band's tiles, heaviest list first, as the count pass leaves them (order[0 .. band tiles), absolute tile ids).
+const int32_t *ms::isect_order_array(const void *workspace, int64_t N, int tile_w, int tile_h) {
+    Plan p;
+    make_plan(N, tile_w, tile_h, 0, tile_h, p);
+    return (const int32_t *)((const char *)workspace + p.off_order);
 }
 
 extern "C" size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h) {

@@ -32,16 +32,20 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
     """diag=True builds libmojosplat_hip_diag.so with -DMS_DIAG (per-wave stamps in the rasteriser;
     scripts/raster_waves.py) next to the product library -- never loaded unless MOJOSPLAT_HIP_LIB names it."""
+    # MS_VARIANT=name MS_EXTRA_FLAGS="-D..." builds libmojosplat_hip_<name>.so (kernel-tuning experiments)
+    variant, extra = os.environ.get("MS_VARIANT"), os.environ.get("MS_EXTRA_FLAGS", "").split()
     lib = LIB.replace(".so", "_diag.so") if diag else LIB
-    if not diag and not force and not _stale():
+    if variant:
+        lib = LIB.replace(".so", f"_{variant}.so")
+    if not diag and not variant and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in _sources():
-        obj = os.path.splitext(src)[0] + (".diag.o" if diag else ".o")
+        obj = os.path.splitext(src)[0] + (f".{variant}.o" if variant else ".diag.o" if diag else ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"] + (["-DMS_DIAG"] if diag else [])
+               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"] + (["-DMS_DIAG"] if diag else []) + extra
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
             print(" ".join(cmd))

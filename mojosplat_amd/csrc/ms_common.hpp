@@ -90,11 +90,12 @@ struct LazyLists {
     int row_lo, row_hi;     // split frames: the band in 16-px block rows (the clean-up leaves other rows alone)
 };
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
+const int32_t *isect_order_array(const void *workspace, int64_t N, int tile_w, int tile_h);
 
 // rasterize.hip: ms_rasterize_to_pixels_3dgs_fwd with a separate density hint (ms_render_fwd's
 // sync-free frames pass the buffer capacity as M and the previous frame's M as the hint).
-// records: N ready-made RasterRecords (3 channels) or null; order: blockIdx -> 16x16 block of the band
-// (heaviest first) or null
+// records: N ready-made RasterRecords (3 channels) or null; order: the band's tiles of the BINNING grid,
+// heaviest list first (isect_order_array; for a split frame these are its 32-px bins), or null
 int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means2d, const float *conics,
                   const void *colors, int color_dtype, int CDIM, const float *opacities, const float *backgrounds,
                   int W, int H, int tile_size, int tile_row_begin, int tile_row_end, const int32_t *tile_ranges,

@@ -46,6 +46,14 @@ static int ms_lazy_enabled() {
     return v;
 }
 
+static int ms_order_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_RASTER_ORDER");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+
 // MOJOSPLAT_SPLIT=0: bin on the rasteriser's own 16-px tiles instead of 32-px bins cut into block lists
 static int ms_split_enabled() {
     static const int v = [] {
@@ -146,6 +154,10 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     // the rasteriser's ready-made records (3-channel forward frames): written by the projection kernel
     const bool use_records = CDIM == 3 && opacities && colors && !render_alphas && !last_ids;
     void *records = use_records ? (void *)(ws + L.off_records) : nullptr;
+    // the rasteriser launches its blocks heaviest list first (the count pass leaves the order of the binning
+    // grid's tiles in the isect workspace); MOJOSPLAT_RASTER_ORDER=0: image order interleaved over the XCDs
+    const int32_t *order = ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, split ? bw : tw, split ? bh : th)
+                                              : nullptr;
     bool speculated = false;
     if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);
@@ -194,7 +206,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                 // (a 16-px grid holds ~1.7x the entries of the 32-px bins it was cut from)
                 if (int rc = ms::rasterize_fwd_split(N, c, prev[0] > 0 ? prev[0] * 17 / 10 : c, means2d, conics, colors,
                                                      color_dtype, CDIM, opacities, backgrounds, W, H, r0, r1,
-                                                     bin_ranges, &lists, render_colors, &lazy_lists, records, nullptr,
+                                                     bin_ranges, &lists, render_colors, &lazy_lists, records, order,
                                                      stage_events ? stage_events[3] : nullptr, stream))
                     return rc;
                 host_info[7] = 1 | 8;
@@ -209,7 +221,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
                                            render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr,
-                                           records, nullptr, stage_events ? stage_events[3] : nullptr, stream))
+                                           records, order, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0);
             }
@@ -275,7 +287,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
         lazy_lists.keys = keys;
         return ms::rasterize_fwd_split(N, c, M * 17 / 10, means2d, conics, colors, color_dtype, CDIM, opacities,
                                        backgrounds, W, H, r0, r1, bin_ranges, &lists, render_colors, &lazy_lists,
-                                       records, nullptr,
+                                       records, order,
                                        (!speculated && stage_events) ? stage_events[3] : nullptr, stream);
     }
     if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
@@ -286,7 +298,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     lazy_lists.keys = keys;
     if (int rc = ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                                    tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
-                                   lazy ? &lazy_lists : nullptr, records, nullptr,
+                                   lazy ? &lazy_lists : nullptr, records, order,
                                    (!speculated && stage_events) ? stage_events[3] : nullptr, stream))
         return rc;
     return MS_OK;

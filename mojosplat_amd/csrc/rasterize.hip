@@ -57,7 +57,8 @@ struct RasterArgs {
     float *render_alphas;
     int32_t *last_ids;
     int W, H, ts, tw, nsx, nsub, cdim, tile0, nblocks, max_isects, n_gauss, parts;
-    const int32_t *order;  // blockIdx -> block (heaviest first), or null: xcd_remap
+    const int32_t *order;  // the band's tiles (order_bins: the 32-px bins of a split frame), heaviest first; null: xcd_remap
+    int order_bins, row0, row1;
     const float4 *records; // ready-made ms::RasterRecord per Gaussian (3 channels), or null: stage from the arrays
     ms::LazyLists lazy;   // front_count == nullptr: every list is fully sorted
 };
@@ -120,31 +121,62 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
-__global__ __launch_bounds__(64 * (4 / NQ), (CP <= 4 ? 8 : 1)) void k_rasterize_fwd(RasterArgs A) {
+#ifndef MS_RASTER_GROUP
+#define MS_RASTER_GROUP 2
+#endif
+#ifndef MS_RASTER_MINW
+#define MS_RASTER_MINW 8
+#endif
+constexpr int kGroup = MS_RASTER_GROUP;   // records evaluated per trip of the blend loop
+
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool SOLO>
+__global__ __launch_bounds__(SOLO ? 64 : 64 * (4 / NQ), (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasterize_fwd(RasterArgs A) {
     static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
-    constexpr int WPB = 4 / NQ;
-    constexpr int CS = (CP == 3) ? 4 : CP;       // CP == 3: r,g ride in s_b; b alone at a 16-B stride (same LDS index as s_a/s_b)
-    // one LDS block per wave, the three arrays at fixed offsets of it: with CS == 4 an entry's three
-    // records sit at the SAME index * 16 B, so the blend loop forms one LDS address per evaluation
-    // (a v_mov of the scalar index) and reaches all three through the instruction's offset field
+    // SOLO: every wave is a workgroup of its own (wave slots refill one by one instead of four at a time); the
+    // 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16, ...: dealt round-robin over the 8 XCDs, they land
+    // on ONE XCD back to back and share its L2 for the list they all stage (speed only, never correctness)
+    constexpr int WPB = SOLO ? 1 : 4 / NQ;
+    constexpr int kParts = 4 / NQ;
+    constexpr int CS = (CP == 3) ? 4 : CP;       // CP == 3: r, g ride in the second word; blue heads a third 16-byte word
+    constexpr int kSlots = kBatch + kGroup;      // room for the neutral records that pad a list to a multiple of kGroup
+    // One LDS block per (wave, quad): the records of the entries that REACH the quad, compacted in list order.
+    // The three arrays sit at fixed offsets, so a record's words share one index * 16 B and the blend loop
+    // reaches kGroup consecutive records from ONE address register through the instructions' offset fields.
     struct Stage {
-        float4 a[kBatch];        // mean.x, mean.y, a', b'
-        float4 b[kBatch];        // c', log2(opacity), (r, g | -, -)
-        float col[kBatch * CS];
+        float4 a[kSlots];        // mean.x, mean.y, a', b'
+        float4 b[kSlots];        // c', log2(opacity), (r, g | index in batch, -)
+        float col[kSlots * CS];  // CP == 3: (blue, index in batch, -, -)
     };
-    __shared__ Stage s_stage[WPB];
+    __shared__ Stage s_stage[WPB][NQ];
     const int wib = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4 *s_a = s_stage[wib].a, *s_b = s_stage[wib].b;
-    float *s_col = s_stage[wib].col;
+    int wg = blockIdx.x, part = wib;   // workgroup index in units of blocks, and which of the block's waves this is
+    if constexpr (SOLO && kParts > 1) {
+        const int j = blockIdx.x >> 3;
+        part = j % kParts;
+        wg = ((j / kParts) << 3) | (blockIdx.x & 7);
+        if (wg >= A.nblocks) return;
+    }
 
     MS_DIAG_ONLY(const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime(), diag_c0 = __builtin_amdgcn_s_memtime(); unsigned diag_evals = 0, diag_batches = 0;)
     // blockIdx -> 16x16 block: heaviest first when the binning stage has left an order, else image order
     // interleaved over the XCDs
-    const int item = A.order ? A.order[blockIdx.x] : xcd_remap(blockIdx.x, A.nblocks);
-    const int qbase = NQ == 4 ? 0 : wib * NQ;
-    const int bt = item / A.nsub, sub = item - bt * A.nsub;
-    const int tile = A.tile0 + bt;
+    const int qbase = NQ == 4 ? 0 : part * NQ;
+    int tile, sub;
+    if (A.order && A.order_bins) {   // split frame: the order lists 32-px bins, four workgroups (blocks) per bin
+        const int e = A.order[wg >> 2], sb = wg & 3;
+        const int by16 = 2 * (e / A.lazy.bin_w) + (sb >> 1), bx16 = 2 * (e % A.lazy.bin_w) + (sb & 1);
+        if (bx16 >= A.tw || by16 < A.row0 || by16 >= A.row1) return;   // (uniform per workgroup; no barrier anywhere)
+        tile = by16 * A.tw + bx16;
+        sub = 0;
+    } else if (A.order) {
+        tile = A.order[wg / A.nsub];
+        sub = wg % A.nsub;
+    } else {
+        const int item = xcd_remap(wg, A.nblocks);
+        const int bt = item / A.nsub;
+        sub = item - bt * A.nsub;
+        tile = A.tile0 + bt;
+    }
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
     const int lane = threadIdx.x & 63;
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(64 * (4 / NQ), (CP <= 4 ? 8 : 1)) void k_rasterize_
         fetch_id(start + kBatch);
     }
     for (int b0 = start; b0 < end; b0 += kBatch) {
-        // --- stage this batch: record -> LDS, reach of the alpha >= 1/255 ellipse -> quad votes
+        // --- stage this batch: reach of the alpha >= 1/255 ellipse -> quad votes -> compacted records in LDS
         // A quad can blend this Gaussian iff min over the quad's pixel-centre rectangle of
         // sigma(p - mean) <= ln(255 o).  sigma is a convex quadratic, so the minimum over a box
         // is 0 if the mean is inside, else it sits on the face(s) nearest the mean: one 1-D
@@ -257,18 +289,36 @@ __global__ __launch_bounds__(64 * (4 / NQ), (CP <= 4 ? 8 : 1)) void k_rasterize_
         for (int qi = 0; qi < NQ; ++qi) B[qi] = __ballot((mask >> qi) & 1);
 
         wave_lds_sync();  // LDS reads of the previous batch are complete
-        if (mask) {
-            s_a[lane] = r_a;
-            if constexpr (PACKED) {
-                s_b[lane] = r_b;
-                reinterpret_cast<float4 *>(s_col)[lane] = r_c;   // CS == 4: the blue channel at index * 16 B
-            } else if constexpr (CP == 3) {
-                s_b[lane] = make_float4(r_b.x, r_b.y, r_col[0], r_col[1]);
-                s_col[lane * CS] = r_col[2];
-            } else {
-                s_b[lane] = r_b;
+        // every reached quad gets the record at its rank among the quad's entries (list order is kept); the
+        // index in the batch rides along for last_ids; kGroup neutral records (alpha = 0) close each list
+        if constexpr (!PACKED) {
+            if constexpr (CP == 3) { r_b.z = r_col[0]; r_b.w = r_col[1]; r_c.x = r_col[2]; }
+        }
+        if constexpr (CP == 3) r_c.y = __int_as_float(lane);
+        else r_b.z = __int_as_float(lane);
 #pragma unroll
-                for (int k = 0; k < CP; ++k) s_col[lane * CS + k] = r_col[k];
+        for (int qi = 0; qi < NQ; ++qi) {
+            Stage &S = s_stage[wib][qi];
+            const unsigned long long b = B[qi];
+            const int n = __popcll(b);
+            if ((mask >> qi) & 1) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                S.a[pos] = r_a;
+                S.b[pos] = r_b;
+                if constexpr (CP == 3) reinterpret_cast<float4 *>(S.col)[pos] = r_c;
+                else {
+#pragma unroll
+                    for (int k = 0; k < CP; ++k) S.col[pos * CS + k] = r_col[k];
+                }
+            }
+            if (lane < kGroup) {
+                S.a[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                S.b[n + lane] = make_float4(0.f, -kInf, 0.f, 0.f);   // log2(alpha) = -inf: alpha = 0, never a hit
+                if constexpr (CP == 3) reinterpret_cast<float4 *>(S.col)[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                else {
+#pragma unroll
+                    for (int k = 0; k < CP; ++k) S.col[(n + lane) * CS + k] = 0.f;
+                }
             }
         }
         wave_lds_sync();
@@ -285,75 +335,69 @@ __global__ __launch_bounds__(64 * (4 / NQ), (CP <= 4 ? 8 : 1)) void k_rasterize_
         bool any_live = false;
         auto blend_batch = [&](auto check) __attribute__((always_inline)) {
             constexpr bool CHECK = decltype(check)::value;
-            constexpr int RC = CP == 3 ? 1 : CP;   // CP == 3: r, g ride in the second word
-            struct Rec { float4 a, b; float c[RC]; int t; };
-            auto load = [&](Rec &r, int t) __attribute__((always_inline)) {
-                r.t = t;
-                r.a = s_a[t]; r.b = s_b[t];
-                if constexpr (CP == 3) r.c[0] = s_col[t * CS];
-                else {
-#pragma unroll
-                    for (int k = 0; k < CP; ++k) r.c[k] = s_col[t * CS + k];
-                }
-            };
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 const int q = qbase + qi;
                 if (!__any(thr[qi] < kInf)) continue;  // every pixel of this quad is finished (or outside)
                 const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
-                auto eval = [&](const Rec &r) __attribute__((always_inline)) {
-                    MS_DIAG_ONLY(++diag_evals;)
-                    const float dx = r.a.x - px, dy = r.a.y - py;
-                    // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
-                    const float la = fmaf(dx, fmaf(r.a.z, dx, r.a.w * dy), fmaf(r.b.x * dy, dy, r.b.y));
-                    float alpha = __builtin_amdgcn_exp2f(la);
-                    if constexpr (CHECK) alpha = fminf(ms::kMaxAlpha, alpha);
-                    bool hit = alpha >= thr[qi];                                  // alpha >= 1/255, pixel live
-                    if constexpr (CHECK) hit = hit && la <= r.b.y;                // sigma >= 0
-                    const float next_T = fmaf(-alpha, T[qi], T[qi]);            // T (1 - alpha)
-                    const bool add = hit && next_T > ms::kTransmittanceStop;
-                    // one select (v_cmp / v_cndmask issue at half the FMA rate on gfx950, v_exp at a
-                    // quarter): alpha -> 0 for lanes that do not blend, then everything else is FMAs
-                    const float a_eff = add ? alpha : 0.f;
-                    const float vis = a_eff * T[qi];
-                    if constexpr (CP == 3) {
-                        pix[qi][0] += r.b.z * vis;
-                        pix[qi][1] += r.b.w * vis;
-                        pix[qi][2] += r.c[0] * vis;
-                    } else {
+                const Stage &S = s_stage[wib][qi];
+                const int n = __popcll(B[qi]);
+                // kGroup records per trip: their LDS reads go out together, the kGroup log2(alpha) chains and
+                // exp2 are independent of each other (and of the T chain), then the blends run in list order
+                for (int k0 = 0; k0 < n; k0 += kGroup) {
+                    float4 ra[kGroup], rb[kGroup];
+                    float rc[kGroup][CP == 3 ? 1 : CP];
+                    int rt[kGroup];
 #pragma unroll
-                        for (int k = 0; k < CP; ++k) pix[qi][k] += r.c[k] * vis;
-                    }
-                    if constexpr (AUX) last[qi] = add ? b0 + r.t : last[qi];
-                    T[qi] = fmaf(-a_eff, T[qi], T[qi]);                         // next_T where blended, T elsewhere
-                    // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path.
-                    if (__ballot(hit && !add)) {
-                        asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
-                        thr[qi] = (hit && !add) ? kInf : thr[qi];
-                    }
-                };
-                unsigned long long m = B[qi];
-                if (m) {
-                    // two register sets take turns: the LDS reads of the NEXT set bit are in flight while
-                    // the current record is evaluated (the loop is unrolled by two, so nothing is copied)
-                    Rec r0, r1;
-                    load(r0, __ffsll((long long)m) - 1);
-                    m &= m - 1;
-                    for (;;) {
-                        bool more = m != 0;
-                        if (more) {
-                            load(r1, __ffsll((long long)m) - 1);
-                            m &= m - 1;
+                    for (int j = 0; j < kGroup; ++j) {
+                        ra[j] = S.a[k0 + j];
+                        rb[j] = S.b[k0 + j];
+                        if constexpr (CP == 3) {
+                            if constexpr (AUX) {
+                                const float2 c2 = reinterpret_cast<const float2 *>(S.col)[2 * (k0 + j)];
+                                rc[j][0] = c2.x; rt[j] = __float_as_int(c2.y);
+                            } else rc[j][0] = S.col[(k0 + j) * CS];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CP; ++c) rc[j][c] = S.col[(k0 + j) * CS + c];
+                            if constexpr (AUX) rt[j] = __float_as_int(rb[j].z);
                         }
-                        eval(r0);
-                        if (!more) break;
-                        more = m != 0;
-                        if (more) {
-                            load(r0, __ffsll((long long)m) - 1);
-                            m &= m - 1;
+                    }
+                    float la[kGroup], alpha[kGroup];
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) {
+                        const float dx = ra[j].x - px, dy = ra[j].y - py;
+                        // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
+                        la[j] = fmaf(dx, fmaf(ra[j].z, dx, ra[j].w * dy), fmaf(rb[j].x * dy, dy, rb[j].y));
+                        alpha[j] = __builtin_amdgcn_exp2f(la[j]);
+                        if constexpr (CHECK) alpha[j] = fminf(ms::kMaxAlpha, alpha[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) {
+                        MS_DIAG_ONLY(++diag_evals;)
+                        bool hit = alpha[j] >= thr[qi];                               // alpha >= 1/255, pixel live
+                        if constexpr (CHECK) hit = hit && la[j] <= rb[j].y;           // sigma >= 0
+                        const float next_T = fmaf(-alpha[j], T[qi], T[qi]);          // T (1 - alpha)
+                        const bool add = hit && next_T > ms::kTransmittanceStop;
+                        // one select (v_cmp / v_cndmask issue at half the FMA rate on gfx950, v_exp at a
+                        // quarter): alpha -> 0 for lanes that do not blend, then everything else is FMAs
+                        const float a_eff = add ? alpha[j] : 0.f;
+                        const float vis = a_eff * T[qi];
+                        if constexpr (CP == 3) {
+                            pix[qi][0] += rb[j].z * vis;
+                            pix[qi][1] += rb[j].w * vis;
+                            pix[qi][2] += rc[j][0] * vis;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CP; ++c) pix[qi][c] += rc[j][c] * vis;
                         }
-                        eval(r1);
-                        if (!more) break;
+                        if constexpr (AUX) last[qi] = add ? b0 + rt[j] : last[qi];
+                        T[qi] = fmaf(-a_eff, T[qi], T[qi]);                          // next_T where blended, T elsewhere
+                        // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path.
+                        if (__ballot(hit && !add)) {
+                            asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
+                            thr[qi] = (hit && !add) ? kInf : thr[qi];
+                        }
                     }
                 }
                 any_live = any_live || __any(thr[qi] < kInf);
@@ -366,7 +410,7 @@ __global__ __launch_bounds__(64 * (4 / NQ), (CP <= 4 ? 8 : 1)) void k_rasterize_
 
 #ifdef MS_DIAG
     if (g_diag_stamps && lane == 0) {
-        unsigned long long *d = g_diag_stamps + 8 * ((size_t)blockIdx.x * WPB + wib);
+        unsigned long long *d = g_diag_stamps + 8 * ((size_t)wg * kParts + part);
         d[0] = diag_t0;                               // 100 MHz, chip-wide
         d[1] = __builtin_amdgcn_s_memrealtime();
         d[4] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this wave's life
@@ -638,17 +682,28 @@ static int raster_parts_override() {
     return v;
 }
 
+// MOJOSPLAT_RASTER_SOLO=0: the waves of a block share a workgroup (one CU) instead of being workgroups of their own
+static bool raster_solo() {
+    static const bool v = [] {
+        const char *e = getenv("MOJOSPLAT_RASTER_SOLO");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return v;
+}
+
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
     const bool aux = A.render_alphas || A.last_ids;
-    const dim3 grid((unsigned)A.nblocks);
-#define MS_LAUNCH_RASTER(AUXV, NQV, PK) \
-    hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, NQV, PK>), grid, dim3(64 * (4 / NQV)), 0, stream, A)
-#define MS_LAUNCH_RASTER_NQ(AUXV, PK)                              \
-    do {                                                           \
-        if (A.parts == 2) MS_LAUNCH_RASTER(AUXV, 2, PK);           \
-        else if (A.parts == 4) MS_LAUNCH_RASTER(AUXV, 1, PK);      \
-        else MS_LAUNCH_RASTER(AUXV, 4, PK);                        \
+    const bool solo = raster_solo() && A.parts > 1;
+    // solo: parts single-wave workgroups per block, the block count rounded up to the 8 XCDs
+    const dim3 grid(solo ? (unsigned)(((A.nblocks + 7) / 8) * 8 * A.parts) : (unsigned)A.nblocks);
+#define MS_LAUNCH_RASTER(AUXV, NQV, PK, SOLOV) \
+    hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, NQV, PK, SOLOV>), grid, dim3(SOLOV ? 64 : 64 * (4 / NQV)), 0, stream, A)
+#define MS_LAUNCH_RASTER_NQ(AUXV, PK)                                             \
+    do {                                                                          \
+        if (A.parts == 2) { if (solo) MS_LAUNCH_RASTER(AUXV, 2, PK, true); else MS_LAUNCH_RASTER(AUXV, 2, PK, false); }      \
+        else if (A.parts == 4) { if (solo) MS_LAUNCH_RASTER(AUXV, 1, PK, true); else MS_LAUNCH_RASTER(AUXV, 1, PK, false); } \
+        else MS_LAUNCH_RASTER(AUXV, 4, PK, false);                                \
     } while (0)
     bool done = false;
     if constexpr (CP == 3) {
@@ -731,6 +786,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.backgrounds = backgrounds; A.tile_ranges = tile_ranges; A.flatten_ids = flatten_ids;
     A.render_colors = render_colors; A.render_alphas = render_alphas; A.last_ids = last_ids;
     A.order = order;
+    A.order_bins = 0; A.row0 = tile_row_begin; A.row1 = tile_row_end;
     A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     if (lazy) A.lazy = *lazy;
     else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0x7fffffff};
@@ -809,6 +865,7 @@ int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const 
     A.backgrounds = backgrounds; A.tile_ranges = lists->block_ranges; A.flatten_ids = lists->block_ids;
     A.render_colors = render_colors; A.render_alphas = nullptr; A.last_ids = nullptr;
     A.order = order;
+    A.order_bins = order ? 1 : 0; A.row0 = r0; A.row1 = r1;
     A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     A.lazy = *lazy;
     A.lazy.front_count = nullptr;   // block lists are walked to their end; the bin's flag says whether that was all
@@ -819,7 +876,8 @@ int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const 
     A.tile0 = r0 * tw16;
     const int64_t blocks = (int64_t)(r1 - r0) * tw16;
     A.parts = choose_parts(blocks, density_hint, A.records != nullptr);
-    A.nblocks = (int)blocks;
+    // with an order: four workgroups per 32-px bin of the band (those outside the image or the band leave at once)
+    A.nblocks = order ? 4 * ((r1 + 1) / 2 - r0 / 2) * bw : (int)blocks;
     A.max_isects = (int)(4 * cap);
     A.n_gauss = (int)(N < 0x7fffffffll ? N : 0x7fffffffll);
     if (int rc = color_dtype == MS_COLOR_F16 ? launch_fwd<__half>(A, stream, after_raster_event)

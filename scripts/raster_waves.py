@@ -36,7 +36,7 @@ def main():
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     for _ in range(5):
         ms.render_gaussians(*g, cam, background_color=bg)
-    nmax = 4 * (-(-W // 16)) * (-(-H // 16))
+    nmax = 4 * (-(-W // 16) + 2) * (-(-H // 16) + 2)
     buf = torch.zeros(nmax * 8, dtype=torch.int64, device=dev)
     _hip.check(L.ms_diag_set_stamps(ctypes.c_void_p(buf.data_ptr())), "diag")
     ms.render_gaussians(*g, cam, background_color=bg)
