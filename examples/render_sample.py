@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--out", default="output/render_example.png")
+    ap.add_argument("--raw", default=None, help="also save the float32 frame (H, W, 3) as .npy")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("backend='hip' needs a ROCm GPU")
@@ -49,6 +50,8 @@ def main():
     print(f"rendered {tuple(img.shape)} in {(time.perf_counter() - t0) * 1e3:.2f} ms (first call), "
           f"range [{img.min().item():.4f}, {img.max().item():.4f}]")
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    if args.raw:
+        np.save(args.raw, img.cpu().numpy())
     u8 = (img.clamp(0, 1).cpu().numpy() * 255).astype(np.uint8)
     print("saved", save_image(u8, args.out))
 

@@ -1265,6 +1265,7 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->packed = 0;
     out->row_lo = 0;
     out->row_hi = 0x7fffffff;
+    out->redo_grid = 64;
 }
 
 // The band's tiles, heaviest list first, as the count pass leaves them (order[0 .. band tiles), absolute tile ids).

@@ -88,6 +88,8 @@ struct LazyLists {
     int bin_w;
     int packed;             // key / list words are id << 4 | block bits
     int row_lo, row_hi;     // split frames: the band in 16-px block rows (the clean-up leaves other rows alone)
+    int redo_grid;          // workgroups of the clean-up launch: 1 while recent frames needed none (an empty
+                            // 64-workgroup launch costs 4.5 us, a one-workgroup one 2), 64 after a frame that did
 };
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
 const int32_t *isect_order_array(const void *workspace, int64_t N, int tile_w, int tile_h);

@@ -151,6 +151,9 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
     ms::LazyLists lazy_lists;
     if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, split ? bw : tw, split ? bh : th, &lazy_lists);
+    // (host_info[5] of the record left by the previous frame: the clean-up count it reported, or the buffer size
+    // an exact-path frame asked for -- either way "not a quiet run of frames")
+    if (lazy && (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN)) lazy_lists.redo_grid = host_info[5] > 0 ? 64 : 1;
     // the rasteriser's ready-made records (3-channel forward frames): written by the projection kernel
     const bool use_records = CDIM == 3 && opacities && colors && !render_alphas && !last_ids;
     void *records = use_records ? (void *)(ws + L.off_records) : nullptr;

@@ -682,6 +682,8 @@ static int raster_parts_override() {
     return v;
 }
 
+static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 64 ? A.lazy.redo_grid : 64); }
+
 // MOJOSPLAT_RASTER_SOLO=0: the waves of a block share a workgroup (one CU) instead of being workgroups of their own
 static bool raster_solo() {
     static const bool v = [] {
@@ -723,7 +725,7 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
     if constexpr (CP <= 4) {
         // lazily sorted frame: redo the (normally zero) tiles whose front did not saturate them
         if (A.lazy.front_count)
-            hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(64), dim3(256), 0, stream, A);
+            hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(redo_grid(A)), dim3(256), 0, stream, A);
     }
 }
 
@@ -740,8 +742,8 @@ int launch_fwd(const RasterArgs &A, hipStream_t stream, void *after_raster_event
 
 template <typename ColorT>
 void launch_redo(const RasterArgs &A, hipStream_t stream) {
-    if (A.cdim == 3) hipLaunchKernelGGL((k_tile_redo<3, ColorT>), dim3(64), dim3(256), 0, stream, A);
-    else hipLaunchKernelGGL((k_tile_redo<4, ColorT>), dim3(64), dim3(256), 0, stream, A);
+    if (A.cdim == 3) hipLaunchKernelGGL((k_tile_redo<3, ColorT>), dim3(redo_grid(A)), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL((k_tile_redo<4, ColorT>), dim3(redo_grid(A)), dim3(256), 0, stream, A);
 }
 
 }  // namespace
@@ -789,7 +791,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.order_bins = 0; A.row0 = tile_row_begin; A.row1 = tile_row_end;
     A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     if (lazy) A.lazy = *lazy;
-    else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0x7fffffff};
+    else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0x7fffffff, 64};
     A.W = W; A.H = H; A.ts = tile_size;
     A.tw = (W + tile_size - 1) / tile_size;
     const int th = (H + tile_size - 1) / tile_size;

@@ -147,6 +147,16 @@ def test_multi_view_batch_equals_single_views(device):
     for k, c in enumerate(cams):
         assert torch.equal(batch[k], ms.render_gaussians(*g, c, background_color=bg, backend="hip"))
     assert not torch.equal(batch[0], batch[4])
+    # ... and every view against the ORACLE's frame for that camera (the camera dimension the
+    # reference's kernels carry, kernels/projection.mojo:32-37), under the suite's strict bar
+    import oracle
+    from helpers import check_image_strict, np_
+    cpu = {k: np_(v) for k, v in sc.items()}
+    for k, c in enumerate(cams):
+        ref, aux = oracle.render_fwd(cpu["means3d"], cpu["scales"], cpu["quats"], cpu["opacities"], cpu["features"],
+                                     np_(c.view_matrix), c.fx, c.fy, c.cx, c.cy, c.W, c.H,
+                                     background=np_(bg), margin=True)
+        check_image_strict(batch[k], ref, aux["margin"], tag=f"multi-view batch, view {k}", eps=2e-5)
 
 
 @pytest.fixture
