@@ -65,7 +65,7 @@ def _pinned_info(dev) -> Tensor:
     return p
 
 
-MAX_LDS_TILES = 40956  # (160 KB of LDS - 16 B) / 4 B per tile counter (csrc/binning.hip make_plan)
+MAX_LDS_TILES = 39932  # (160 KB of LDS - 4 KB of static blocks - 16 B) / 4 B per tile counter (csrc/binning.hip make_plan)
 
 
 def lds_row_bands(img_height: int, img_width: int, tile_size: int):

@@ -42,7 +42,8 @@ constexpr int kHistThreads = 1024;
 constexpr int kMaxG = 512;
 constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
 constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
-constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kBandCull = 32;      // bit of the `tight` flags: the band's Gaussians were pre-culled (k_band_precull)
+constexpr size_t kMaxLds = 160 * 1024 - 4096;   // dynamic LDS of the binning kernels: the CU's 160 KB less their static blocks (segment prefix of a band's candidate list, wave totals)
 
 struct Grid {
     int ts, tw, th, row_begin, row_end;
@@ -185,14 +186,14 @@ __device__ __forceinline__ unsigned long long clip_cells(unsigned long long m, i
 }
 
 // One step of a chunk walk: every lane of the workgroup brings the tile box of ONE Gaussian
-// (index base + threadIdx.x, n = 0 if it has none); F(local_tile, gaussian_index) is called for
+// (index gi, n = 0 if it has none); F(local_tile, gaussian_index) is called for
 // every tile of every box.  Small boxes are walked by their own lane, big ones by the whole wave.
 // Must be reached by all lanes of the wave (ballot / shuffles inside).
 template <bool PACK, class F>
-__device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0, int y1, int n, int edges,
+__device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y1, int n, int edges,
                                            const Grid &g, unsigned long long mask, F &&f) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = base + threadIdx.x;
+    const int64_t i = gi;   // this lane's Gaussian (its index in the arrays; a band's candidate list maps to it)
     const bool big = n > kCoopThreshold;
     if (n > 0 && !big) {
         // only the reached tiles: the trip count is popcount, not the box area
@@ -240,7 +241,7 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
         const unsigned long long bm = ((unsigned long long)(unsigned)__shfl((int)(mask >> 32), src) << 32) |
                                       (unsigned)__shfl((int)(mask & 0xffffffffu), src);
         const int be = PACK ? __shfl(edges, src) : 0;
-        const int64_t bi = base + (threadIdx.x & ~63) + src;
+        const int64_t bi = __shfl(gi, src);
         const int w = bx1 - bx0, cnt = w * (by1 - by0);
         for (int k = lane; k < cnt; k += 64) {
             const int r = k / w, c = k % w;
@@ -252,17 +253,73 @@ __device__ __forceinline__ void walk_boxes(int64_t base, int x0, int x1, int y0,
 
 // Walk every (Gaussian, tile) pair of one chunk; F(local_tile, gaussian_index).
 // Small boxes are walked by their own lane, big ones by the whole wave.
+// A band's candidate list (multi-GPU ranks, k_band_precull): segment g of `ids` (capacity seg_cap, the chunk of
+// Gaussians workgroup g of the pre-cull looked at) holds seg_count[g] survivors, compacted.  The count and
+// scatter kernels walk the concatenation of the segments ("positions") in steps of kHistThreads, step s going to
+// workgroup s mod G -- the same assignment in both kernels, so a workgroup's histogram row matches what it
+// scatters -- and find a position's Gaussian through the prefix over the <= kMaxG segment counts (LDS).
+struct Candidates {
+    const int32_t *ids;     // null: every Gaussian, position == index
+    const int32_t *seg_count;
+    int n_segs;
+    int64_t seg_cap;
+};
+
+struct CandMap {
+    uint32_t *pref;   // LDS: pref[g] = survivors in segments < g; pref[n_segs] = total
+    __device__ __forceinline__ void build(const Candidates &c) {   // all threads of the workgroup; ends with a barrier
+        // n_segs <= kMaxG <= blockDim: one segment per thread, a wave scan + the wave totals
+        __shared__ uint32_t s_wtot[16];
+        const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+        const uint32_t v = t < c.n_segs ? (uint32_t)c.seg_count[t] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wtot[w] = incl;
+        __syncthreads();
+        uint32_t run = 0;
+        for (int ww = 0; ww < w; ++ww) run += s_wtot[ww];
+        if (t < c.n_segs) pref[t + 1] = run + incl;
+        if (t == 0) pref[0] = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ int64_t gaussian(const Candidates &c, int64_t pos) const {
+        int lo = 0, hi = c.n_segs;   // largest g with pref[g] <= pos
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((int64_t)pref[mid] <= pos) lo = mid; else hi = mid;
+        }
+        return (int64_t)c.ids[(int64_t)lo * c.seg_cap + (pos - (int64_t)pref[lo])];
+    }
+};
+
 template <bool PACK, class F>
 __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const float *means2d,
                                                const int32_t *radii, const unsigned long long *masks,
                                                const Grid &g,
-                                               int32_t *tiles_per_gauss, unsigned int *s_on_grid, F &&f) {
-    for (int64_t base = i0; base < i1; base += kHistThreads) {
-        const int64_t i = base + threadIdx.x;
-        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
+                                               int32_t *tiles_per_gauss, unsigned int *s_on_grid, Candidates cand, F &&f) {
+    __shared__ uint32_t s_pref[kMaxG + 1];
+    CandMap map{s_pref};
+    int64_t stride = kHistThreads;
+    if (cand.ids) {   // positions of the candidate list, step s -> workgroup s mod G
+        map.build(cand);
+        i0 = (int64_t)blockIdx.x * kHistThreads;
+        i1 = (int64_t)s_pref[cand.n_segs];
+        stride = (int64_t)gridDim.x * kHistThreads;
+    }
+    for (int64_t base = i0; base < i1; base += stride) {
+        const int64_t j = base + threadIdx.x;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0, gi = 0;
         bool on_grid = false;
         unsigned long long mask = ~0ull;
-        if (i < i1) {
+        if (j < i1) {
+            // (a band's candidates: the projected arrays are indexed by POSITION in the candidate list -- the
+            // count kernel wrote them that way, coalesced -- and so are the entries it emits)
+            const int64_t i = j;
+            gi = (int)i;
             const int2 r = reinterpret_cast<const int2 *>(radii)[i];
             if (r.x > 0 && r.y > 0) {
                 const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
@@ -273,8 +330,78 @@ __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const flo
             if (tiles_per_gauss) tiles_per_gauss[i] = n;
         }
         if (s_on_grid) count_on_grid(on_grid, s_on_grid);
-        walk_boxes<PACK>(base, x0, x1, y0, y1, n, edges, g, mask, f);
+        walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, f);
     }
+}
+
+// Multi-GPU bands: which Gaussians can reach the band's rows [y_lo, y_hi) px (and the image's columns) at all?
+// A rank that renders 1/8 of the frame otherwise projects and walks ALL Gaussians (config 5: 190 of the ~330 us
+// of a band frame).  Conservative test from the mean and the largest scale alone: the camera-space covariance
+// has lambda_max <= ||Wv||^2 smax^2, the Jacobian's rows have |J_y|^2 = (fy / z)^2 (1 + v^2) with v the
+// FOV-clamped my / z, so cov2d_yy + eps <= that product + eps, and the tile box's radius is
+// ceil(extend sqrt(.)) <= 3.33 sqrt(.) + 1.  Everything is padded (0.1 % + 2 px); what is dropped here
+// has no tile in the band, what is kept goes through the exact projection.  Survivors are compacted per wave
+// (one atomic per wave); their order only moves the scatter's slots, never the sorted lists.
+__global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const float *__restrict__ means3d,
+                                                               const float *__restrict__ scales,
+                                                               const float *__restrict__ viewmat, ms::ProjParams P,
+                                                               float y_lo, float y_hi, int64_t chunk,
+                                                               int32_t *__restrict__ cand,
+                                                               int32_t *__restrict__ seg_count) {
+    __shared__ uint32_t s_w[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float V[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = viewmat[k];
+    // ||Wv||_2^2 <= the largest Gershgorin row sum of Wv^T Wv (exactly 1 for a rotation)
+    float lam = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float rowsum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) rowsum += fabsf(V[a] * V[b] + V[4 + a] * V[4 + b] + V[8 + a] * V[8 + b]);
+        lam = fmaxf(lam, rowsum);
+    }
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
+    int32_t *seg = cand + i0;
+    uint32_t written = 0;   // survivors of this segment so far (uniform)
+    for (int64_t base = i0; base < i1; base += kHistThreads) {
+        const int64_t i = base + threadIdx.x;
+        bool keep = false;
+        if (i < i1) {
+            const float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
+            const float mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
+            const float my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
+            const float z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
+            if (!(z < P.near_plane || z > P.far_plane)) {   // the exact projection's own depth cull
+                float sm = fmaxf(scales[3 * i], fmaxf(scales[3 * i + 1], scales[3 * i + 2]));
+                if (P.scales_are_log) sm = __expf(sm);
+                const float rz = __builtin_amdgcn_rcpf(z);
+                const float u = fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz)), v = fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
+                const float s2 = lam * sm * sm;
+                const float fxz = P.fx * rz, fyz = P.fy * rz;
+                const float rx = 3.33f * __builtin_amdgcn_sqrtf(fxz * fxz * (1.0f + u * u) * s2 + P.eps2d) * 1.001f + 2.0f;
+                const float ry = 3.33f * __builtin_amdgcn_sqrtf(fyz * fyz * (1.0f + v * v) * s2 + P.eps2d) * 1.001f + 2.0f;
+                const float xs = P.fx * mx * rz + P.cx, ys = P.fy * my * rz + P.cy;
+                // (negated comparisons: a NaN anywhere keeps the Gaussian for the exact path to judge)
+                keep = !(ys + ry < y_lo || ys - ry > y_hi || xs + rx < 0.f || xs - rx > P.W);
+            }
+        }
+        const unsigned long long b = __ballot(keep);
+        __syncthreads();   // s_w of the previous step has been read
+        if (lane == 0) s_w[w] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = written, total = 0;
+#pragma unroll
+        for (int ww = 0; ww < 16; ++ww) {
+            const uint32_t c = s_w[ww];
+            if (ww < w) before += c;
+            total += c;
+        }
+        if (keep) seg[before + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = (int32_t)i;
+        written += total;
+    }
+    if (threadIdx.x == 0) seg_count[blockIdx.x] = (int32_t)written;
 }
 
 // Fused projection + tile counting (the first two kernels of a frame in one): every lane projects
@@ -287,21 +414,37 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
     ms::ProjParams P, Grid g, int64_t chunk, float *__restrict__ means2d, float *__restrict__ conics,
     float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist,
     uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks,
-    const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec) {
+    const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
     if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
-    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for (int64_t base = i0; base < i1; base += kHistThreads) {
-        const int64_t i = base + threadIdx.x;
-        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
+    __shared__ uint32_t s_pref[kMaxG + 1];
+    CandMap map{s_pref};
+    int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk), stride = kHistThreads;
+    if (cand.ids) {   // positions of the band's candidate list, step s -> workgroup s mod G (as the scatter kernel)
+        map.build(cand);
+        i0 = (int64_t)blockIdx.x * kHistThreads;
+        i1 = (int64_t)s_pref[cand.n_segs];
+        stride = (int64_t)gridDim.x * kHistThreads;
+    }
+    for (int64_t base = i0; base < i1; base += stride) {
+        const int64_t j = base + threadIdx.x;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0, gi = 0;
         bool on_grid = false;
         unsigned long long mask = ~0ull;
-        if (i < i1) {
-            const ms::ProjOut o = ms::project_one(i, means3d, scales, quats, opacities, viewmat, P);
+        if (j < i1) {
+            // A band's candidates: the INPUT arrays are gathered through the candidate list; everything this
+            // kernel writes -- and every index the later stages see -- is the POSITION j in that list, so the
+            // projected arrays stay dense and their stores coalesced (scattered 4-48-byte stores by Gaussian
+            // index cost 3.5x the projection itself).  Positions grow with the Gaussian index, so the
+            // (depth bits, id) order of the sorted lists is the same either way.
+            const int64_t src = cand.ids ? map.gaussian(cand, j) : j;
+            const int64_t i = j;
+            gi = (int)i;
+            const ms::ProjOut o = ms::project_one(src, means3d, scales, quats, opacities, viewmat, P);
             reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
             conics[3 * i] = o.c0;
             conics[3 * i + 1] = o.c1;
@@ -314,13 +457,13 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
                 // (tile, Gaussian) pair.  Same expressions as the rasteriser's own staging: same bits.
                 float col[3];
                 if (color_f16) {
-                    const __half *c = reinterpret_cast<const __half *>(colors) + 3 * i;
+                    const __half *c = reinterpret_cast<const __half *>(colors) + 3 * src;
                     col[0] = __half2float(c[0]); col[1] = __half2float(c[1]); col[2] = __half2float(c[2]);
                 } else {
-                    const float *c = reinterpret_cast<const float *>(colors) + 3 * i;
+                    const float *c = reinterpret_cast<const float *>(colors) + 3 * src;
                     col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
                 }
-                const ms::RasterRecord r = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], col[0], col[1], col[2]);
+                const ms::RasterRecord r = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[src], col[0], col[1], col[2]);
                 rec[3 * i] = r.a;
                 rec[3 * i + 1] = r.b;
                 rec[3 * i + 2] = r.c;
@@ -330,16 +473,16 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
                 n = (x1 - x0) * (y1 - y0);
                 if (masks) {
                     if (PACK && n <= 16 && n > 0)   // per half-tile cell (the 16x16 blocks of a 32-px bin)
-                        mask = clip_cells(reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], 2 * x0, 2 * x1,
+                        mask = clip_cells(reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[src], 2 * x0, 2 * x1,
                                                      2 * y0, 2 * y1, g.ts >> 1), edges, x1 - x0, y1 - y0);
                     else
-                        mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[i], x0, x1, y0, y1, g.ts);
+                        mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[src], x0, x1, y0, y1, g.ts);
                     masks[i] = mask;
                 }
             }
         }
         count_on_grid(on_grid, &s_on_grid);
-        walk_boxes<PACK>(base, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
+        walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
@@ -358,7 +501,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect<false>(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid,
+    for_each_isect<false>(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid, Candidates{nullptr, nullptr, 0, 0},
                    [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
@@ -550,7 +693,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
     Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
     const int32_t *__restrict__ tile_ranges, int64_t M, uint64_t *__restrict__ keys,
-    uint32_t *__restrict__ wg_depth) {
+    uint32_t *__restrict__ wg_depth, Candidates cand) {
     extern __shared__ uint32_t s_cur[];
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     const int band0 = g.row_begin * g.tw;
@@ -562,7 +705,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     // depth bits (order preserving for the positive depths that survive) of everything this workgroup
     // emits: k_tile_front spreads its buckets over the frame's range
     uint32_t dmin = 0xffffffffu, dmax = 0u;
-    for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, [&](int t, int64_t i, int q) {
+    for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, cand, [&](int t, int64_t i, int q) {
         const uint32_t slot = atomicAdd(&s_cur[t], 1u);
         const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
         const uint32_t dbits = __float_as_uint(depths[i]);
@@ -1169,7 +1312,7 @@ struct Plan {
     int T, T_local;
     size_t lds_bytes;
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
-        off_redo_list, off_redo_count, off_depth_wg, off_order, total;
+        off_redo_list, off_redo_count, off_depth_wg, off_order, off_cand_count, off_cand, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -1197,7 +1340,9 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_order = o;      o += ms::align_up((size_t)p.T * 4, 256);     // the band's tiles, heaviest first (rasteriser launch order)
     // (the only N-dependent block comes last: everything above -- the clean-up count among it, which a caller
     // reads back one frame later -- stays where it is when the scene grows or shrinks on a fixed grid)
+    p.off_cand_count = o; o += ms::align_up((size_t)kMaxG * 4, 256);   // band pre-cull: survivors per segment
     p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
+    p.off_cand = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 4, 256);  // band pre-cull: candidate list
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -1383,6 +1528,16 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
     unsigned long long *masks = ((tight & 1) && opacities) ? (unsigned long long *)(ws + p.off_mask) : nullptr;
     const ms::ProjParams P = ms::make_proj_params(fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, radius_clip,
                                                   scales_are_log, opacities != nullptr);
+    // bit 5 of `tight`: the band is a rank's share of a frame -- pre-cull the Gaussians that cannot reach it
+    Candidates cand{nullptr, nullptr, 0, 0};
+    if ((tight & kBandCull) && N > 0) {
+        int32_t *seg_count = (int32_t *)(ws + p.off_cand_count);
+        hipLaunchKernelGGL(k_band_precull, dim3(p.G), dim3(kHistThreads), 0, stream, N, means3d, scales, viewmat, P,
+                           (float)(row_begin * tile_size) - 1.0f, (float)(row_end * tile_size) + 1.0f, p.chunk,
+                           (int32_t *)(ws + p.off_cand), seg_count);
+        MS_LAUNCH_CHECK();
+        cand = Candidates{(const int32_t *)(ws + p.off_cand), seg_count, p.G, p.chunk};
+    }
     {   // also for N == 0 (one workgroup that walks nothing): the histogram row and the on-grid slot the
         // scans read must exist
         auto kernel = pack ? k_project_hist<true> : k_project_hist<false>;
@@ -1390,7 +1545,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
                            quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks,
-                           colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records);
+                           colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand);
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
@@ -1429,7 +1584,9 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
-                           g, p.chunk, hist, tile_ranges, cap, sort_keys, lazy ? (uint32_t *)(ws + p.off_depth_wg) : nullptr);
+                           g, p.chunk, hist, tile_ranges, cap, sort_keys, lazy ? (uint32_t *)(ws + p.off_depth_wg) : nullptr,
+                           (tight & kBandCull) ? Candidates{(const int32_t *)(ws + p.off_cand), (const int32_t *)(ws + p.off_cand_count), p.G, p.chunk}
+                                               : Candidates{nullptr, nullptr, 0, 0});
         MS_LAUNCH_CHECK();
     }
 

@@ -46,6 +46,14 @@ static int ms_lazy_enabled() {
     return v;
 }
 
+static int ms_band_cull_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_BAND_CULL");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+
 static int ms_order_enabled() {
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_RASTER_ORDER");
@@ -147,13 +155,6 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     const bool split = lazy && tile_size == 16 && N > 0 && N < (1ll << 28) && r1 > r0 &&
                        (r1 - r0 >= 16 || (r0 == 0 && r1 == th)) && !no_split && ms_split_enabled();
     const int bw = (tw + 1) / 2, bh = (th + 1) / 2, b0 = r0 / 2, b1 = (r1 + 1) / 2;
-    const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0);
-    int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
-    ms::LazyLists lazy_lists;
-    if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, split ? bw : tw, split ? bh : th, &lazy_lists);
-    // (host_info[5] of the record left by the previous frame: the clean-up count it reported, or the buffer size
-    // an exact-path frame asked for -- either way "not a quiet run of frames")
-    if (lazy && (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN)) lazy_lists.redo_grid = host_info[5] > 0 ? 64 : 1;
     // the rasteriser's ready-made records (3-channel forward frames): written by the projection kernel
     const bool use_records = CDIM == 3 && opacities && colors && !render_alphas && !last_ids;
     void *records = use_records ? (void *)(ws + L.off_records) : nullptr;
@@ -161,6 +162,19 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     // grid's tiles in the isect workspace); MOJOSPLAT_RASTER_ORDER=0: image order interleaved over the XCDs
     const int32_t *order = ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, split ? bw : tw, split ? bh : th)
                                               : nullptr;
+    // a band that is a rank's share of a frame (under 60 % of the rows of a scene worth the extra pass): the
+    // Gaussians that cannot reach it are culled before the projection (binning.hip, k_band_precull).
+    // MOJOSPLAT_BAND_CULL=0 switches that off.
+    // (only frames whose rasteriser reads the ready-made records: the lists of a culled band hold POSITIONS in the
+    // band's candidate list, which index the workspace's dense projected arrays and records, not the caller's)
+    const int cull = (use_records && N >= 32768 && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0;
+    const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0) | cull;
+    int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
+    ms::LazyLists lazy_lists;
+    if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, split ? bw : tw, split ? bh : th, &lazy_lists);
+    // (host_info[5] of the record left by the previous frame: the clean-up count it reported, or the buffer size
+    // an exact-path frame asked for -- either way "not a quiet run of frames")
+    if (lazy && (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN)) lazy_lists.redo_grid = host_info[5] > 0 ? 64 : 1;
     bool speculated = false;
     if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);
@@ -177,7 +191,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
         if (int rc = ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
                                              cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,
                                              split ? 32 : tile_size, split ? b0 : r0, split ? b1 : r1,
-                                             /*tight | ranges for the band only (| block masks)=*/split ? bin_flags : 1 | 2,
+                                             /*tight | ranges for the band only (| block masks)=*/split ? bin_flags : 1 | 2 | cull,
                                              means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
                                              split ? bin_ranges : ranges, info, (int64_t *)mirror,
                                              use_records ? colors : nullptr, color_dtype, records, stream))
@@ -217,7 +231,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             } else {
             if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                          ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
-                                                         /*tight=*/opacities != nullptr, lazy, near_plane, far_plane, keys, ids, stream))
+                                                         /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy, near_plane, far_plane, keys, ids, stream))
                 return rc;
             mark(2);
             lazy_lists.keys = keys;
@@ -294,7 +308,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                                        (!speculated && stage_events) ? stage_events[3] : nullptr, stream);
     }
     if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
-                                     L.isect_bytes, ranges, host_info, /*tight=*/opacities != nullptr, lazy, near_plane, far_plane,
+                                     L.isect_bytes, ranges, host_info, /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy, near_plane, far_plane,
                                      keys, tmp, ids, nullptr, stream))
         return rc;
     if (!speculated) mark(2);

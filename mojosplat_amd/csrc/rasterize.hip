@@ -624,17 +624,33 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                     if (e0 + tid < F) {
                         const unsigned int word = (unsigned int)s_key[e0 + tid];
                         const int g = min(max((int)(A.lazy.packed ? word >> 4 : word), 0), A.n_gauss - 1);
-                        const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
-                        const float ca = A.conics[3 * g], cb = A.conics[3 * g + 1], cc = A.conics[3 * g + 2];
-                        const float op = A.opacities[g];
-                        s_pa[tid] = make_float4(m.x, m.y, -0.5f * kLog2e * ca, -kLog2e * cb);
                         // opacity below 1/255 can never blend: log2 -> -inf keeps alpha at 0
                         // (split frames: nor can an entry that is not on this block's list)
                         const bool listed = !A.lazy.packed || ((word >> sub) & 1u);
-                        s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold && listed ? __log2f(op) : -kInf, 0.f, 0.f);
+                        bool from_records = false;
+                        if constexpr (CP == 3) {
+                            if (A.records) {
+                                // the frame's ready-made records: the same staged values, and the only per-Gaussian
+                                // data a pre-culled band frame can be asked for by list id (ids are positions in
+                                // the band's candidate list there, not indices into the caller's arrays)
+                                const float4 *rec = A.records + 3 * (size_t)g;
+                                const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                                s_pa[tid] = ra;
+                                s_pb[tid] = make_float4(rb.x, rc.y > -kInf && listed ? rb.y : -kInf, 0.f, 0.f);
+                                s_pc[tid * CP] = rb.z; s_pc[tid * CP + 1] = rb.w; s_pc[tid * CP + 2] = rc.x;
+                                from_records = true;
+                            }
+                        }
+                        if (!from_records) {
+                            const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
+                            const float ca = A.conics[3 * g], cb = A.conics[3 * g + 1], cc = A.conics[3 * g + 2];
+                            const float op = A.opacities[g];
+                            s_pa[tid] = make_float4(m.x, m.y, -0.5f * kLog2e * ca, -kLog2e * cb);
+                            s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold && listed ? __log2f(op) : -kInf, 0.f, 0.f);
 #pragma unroll
-                        for (int k = 0; k < CP; ++k)
-                            s_pc[tid * CP + k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
+                            for (int k = 0; k < CP; ++k)
+                                s_pc[tid * CP + k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
+                        }
                     }
                     __syncthreads();
                     const int m = min(256, F - e0);

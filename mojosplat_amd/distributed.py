@@ -136,8 +136,25 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     slab = rows * tile_size
     H_pad = max(world * slab, H)
 
+    # A HIP band frame reports how many of ITS Gaussians touch the full grid: the library pre-culls what cannot
+    # reach the band (csrc/binning.hip, k_band_precull), so the frame-level "nothing on the grid -> zeros image"
+    # rule (render.py:73-76) needs the OR over the ranks: one 4-byte all-reduce beside the framebuffer gather.
+    # (A Gaussian on the grid reaches some band and is counted by that band's rank.)  Every rank always takes
+    # part in both collectives.  Injected CPU stages count over all Gaussians and need no exchange.
+    need_flag = stages is None and world > 1 and rehearse is None
+
     def gather(full, on_grid):
-        """-> (image, work): the exchange step, or the frame-level zeros rule."""
+        """-> (image or a callable that yields it, work): the exchange step, or the frame-level zeros rule."""
+        if need_flag:
+            flag = torch.tensor([1 if on_grid > 0 else 0], dtype=torch.int32, device=dev)
+            fwork = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group, async_op=True)
+            work = dist.all_gather_into_tensor(full[:world * slab], full[rank * slab:(rank + 1) * slab],
+                                               group=group, async_op=True)
+
+            def image():
+                fwork.wait()
+                return full[:H] if int(flag.item()) > 0 else torch.zeros(H, W, C, device=dev, dtype=torch.float32)
+            return image, work
         if on_grid == 0:
             # zeros, not background (render.py:73-76); identical inputs -> every rank takes this
             # branch, so skipping the collective is consistent across the group
@@ -148,6 +165,11 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                                            group=group, async_op=True)
         return full[:H], work
 
+    def resolve(img, work):
+        if work is not None:
+            work.wait()
+        return img() if callable(img) else img
+
     if stages is not None or not async_op:
         # a fresh framebuffer per frame (caching allocator: no hipMalloc), handed out as a view
         full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
@@ -155,15 +177,8 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                                bands[rank], full)
         img, work = gather(full, on_grid)
         if not async_op:
-            if work is not None:
-                work.wait()
-            return img
-
-        def finalize_sync():
-            if work is not None:
-                work.wait()
-            return img
-        return PendingFrame(finalize=finalize_sync)
+            return resolve(img, work)
+        return PendingFrame(finalize=lambda: resolve(img, work))
 
     # asynchronous HIP path: band on a lane stream (ms_render_fwd BEGIN, no host wait).  Streams
     # are addressed by handle and ordered with events; torch's current stream is never switched
@@ -195,7 +210,5 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         now = torch.cuda.current_stream(dev)
         now.wait_stream(s)           # the band is complete before the exchange starts
         img, work = gather(full, info["on_grid"])   # RCCL's stream waits for `now`
-        if work is not None:
-            work.wait()              # ... and `now` for the gather
-        return img
+        return resolve(img, work)                   # ... and `now` for the gather
     return PendingFrame(finalize=finalize)
