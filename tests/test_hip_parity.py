@@ -6,9 +6,11 @@ Tolerances (written here, as the north-star asks):
               handful of +-1 flips where extent*sqrt(cov) lands within 1 ulp of an integer
               (expf/logf differ by <= 1 ulp between libm and the GPU);
   binning     bit-exact (integer/index work) given identical inputs;
-  raster      <= 1e-4 abs per pixel fp32 (reference bar tests/test_rasterization.py:110),
-              except pixels where the 1/255 or 1e-4 branch flips on a 1-ulp exp difference
-              (bounded fraction, bounded magnitude).
+  raster      <= 1e-4 abs per pixel fp32 (reference bar tests/test_rasterization.py:110).  A pixel may
+              exceed it ONLY where the oracle's own walk had a branch (alpha >= 1/255, T(1-alpha) <= 1e-4,
+              sigma < 0) within 1e-5 (2e-5 end to end) of its threshold -- helpers.check_image_strict,
+              zero unexplained pixels asserted, counts printed and logged to gpurun_out/parity_counts.jsonl;
+              the small fixed scenes below keep the plain bar with no exception at all.
 """
 import numpy as np
 import pytest
@@ -16,8 +18,8 @@ import torch
 
 import mojosplat_amd as ms
 import oracle
-from helpers import (camera_from_golden, golden_files, load_golden, np_, oracle_project, proj_scene,
-                     raster_scene, simple_camera)
+from helpers import (camera_from_golden, check_image_strict, golden_files, load_golden, np_, oracle_project,
+                     proj_scene, raster_scene, simple_camera)
 from mojosplat_amd.binning import bin_gaussians_to_tiles_hip, isect_offset_encode_hip
 from mojosplat_amd.rasterization import rasterize_gaussians_hip
 from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
@@ -240,7 +242,8 @@ def test_raster_vs_oracle_64(device, N, bg):
     if ids.size == 0:
         pytest.skip("No visible gaussians")
     bgn = np.array(bg, np.float32)
-    ref, ralpha, rlast = oracle.rasterize_fwd(m2, con, np_(colors), np_(opac), bgn, ranges, ids, 64, 64, 16)
+    ref, ralpha, rlast, margin = oracle.rasterize_fwd(m2, con, np_(colors), np_(opac), bgn, ranges, ids, 64, 64, 16,
+                                                      margin=True)
     dcam = simple_camera(device)
     to = lambda a: torch.from_numpy(a).to(device)
     img, alphas, last = rasterize_gaussians_hip(to(m2), to(con), colors.to(device), opac.to(device), to(bgn),
@@ -248,7 +251,8 @@ def test_raster_vs_oracle_64(device, N, bg):
     assert img.shape == (64, 64, 3) and img.dtype == torch.float32 and img.device == device
     check_image(img, ref, max_outlier_frac=0.0)
     np.testing.assert_allclose(np_(alphas), ralpha, atol=1e-5)
-    assert (np_(last) == rlast).mean() > 0.999
+    calm = margin >= 1e-5
+    assert np.array_equal(np_(last)[calm], rlast[calm]) and calm.mean() > 0.99   # equal wherever no branch is close
     img2 = ms.rasterize_gaussians(to(m2), to(con), colors.to(device), opac.to(device), to(bgn), to(ranges),
                                   to(ids), dcam, backend="hip")
     assert torch.equal(img, img2)  # deterministic, run-to-run bit-equal
@@ -268,11 +272,13 @@ def test_raster_generic_branch_opaque_and_indefinite_conics(device):
     con[5::7, 1] = 3.0 * np.sqrt(np.abs(con[5::7, 0] * con[5::7, 2]))   # indefinite: sigma < 0 on one diagonal
     con[6::11] *= -1.0                                                   # negative definite: sigma <= 0 everywhere
     bgn = np.array([0.2, 0.1, 0.4], np.float32)
-    ref, _, _ = oracle.rasterize_fwd(m2, con, np_(colors), np_(opac), bgn, ranges, ids, 64, 64, 16)
+    ref, _, _, margin = oracle.rasterize_fwd(m2, con, np_(colors), np_(opac), bgn, ranges, ids, 64, 64, 16, margin=True)
     to = lambda a: torch.from_numpy(a).to(device)
     img = rasterize_gaussians_hip(to(m2), to(con), colors.to(device), opac.to(device), to(bgn), to(ranges),
                                   to(ids), simple_camera(device), 16)
-    check_image(img, ref, max_outlier_frac=2e-3)
+    # (indefinite conics put sigma = 0 lines through the image: the margin counts |sigma| for them)
+    check_image_strict(img, ref, margin, tag="generic blend loop: opaque / indefinite / negative conics", eps=1e-5,
+                       flip_cap=0.3)
     # and the clamp really binds somewhere in this scene
     lo = oracle.rasterize_fwd(m2, con, np_(colors), np.minimum(np_(opac), 0.999), bgn, ranges, ids, 64, 64, 16)[0]
     assert np.abs(lo - ref).max() > 1e-5
@@ -383,11 +389,11 @@ def test_render_end_to_end_vs_oracle(device, N, W, H, ell):
     cpu = {k: np_(v) for k, v in sc.items()}
     ref, aux = oracle.render_fwd(cpu["means3d"], cpu["scales"], cpu["quats"], cpu["opacities"], cpu["features"],
                                  np_(cam.view_matrix), cam.fx, cam.fy, cam.cx, cam.cy, W, H,
-                                 background=np.array(BACKGROUND_V1, np.float32))
-    # end to end the GPU's own projection feeds its rasteriser: a radius flip or a 1-ulp conic
-    # difference moves a few pixels; the per-stage tests above hold the strict bars
-    bad = check_image(img, ref, atol=1e-4, max_outlier_frac=1e-3, outlier_cap=0.05)
-    print(f"N={N}: M={aux['M']} pixels beyond 1e-4: {bad}")
+                                 background=np.array(BACKGROUND_V1, np.float32), margin=True)
+    # end to end the GPU's own projection feeds its rasteriser (exp(scale) differs by an ulp from libm's): only a
+    # pixel with a branch within 2e-5 of its threshold may move by more than 1e-4
+    rec = check_image_strict(img, ref, aux["margin"], tag=f"render end to end N={N} {W}x{H}", eps=2e-5)
+    print(f"N={N}: M={aux['M']} pixels beyond 1e-4: {rec['beyond_atol']} (all explained)")
 
 
 def test_config2_100k_1080p_stagewise(device):
@@ -398,15 +404,17 @@ def test_config2_100k_1080p_stagewise(device):
     cpu = {k: np_(v) for k, v in sc.items()}
     bgn = np.array(BACKGROUND_V1, np.float32)
     ref, aux = oracle.render_fwd(cpu["means3d"], cpu["scales"], cpu["quats"], cpu["opacities"], cpu["features"],
-                                 np_(cam.view_matrix), cam.fx, cam.fy, cam.cx, cam.cy, W, H, background=bgn)
+                                 np_(cam.view_matrix), cam.fx, cam.fy, cam.cx, cam.cy, W, H, background=bgn, margin=True)
     to = lambda a: torch.from_numpy(a).to(device)
     ids, ranges = bin_gaussians_to_tiles_hip(to(aux["means2d"]), to(aux["radii"]), to(aux["depths"]), 16,
                                              W // 16, -(-H // 16))
     assert np.array_equal(np_(ids), aux["ids"]) and np.array_equal(np_(ranges), aux["ranges"])
-    img = rasterize_gaussians_hip(to(aux["means2d"]), to(aux["conics"]), sc["features"], sc["opacities"], to(bgn),
-                                  ranges, ids, cam)
-    bad = check_image(img, ref, atol=1e-4, max_outlier_frac=2e-5, outlier_cap=5e-3)
-    print(f"cfg2: M={aux['M']}, pixels beyond 1e-4 (threshold flips): {bad}")
+    img, alphas, last = rasterize_gaussians_hip(to(aux["means2d"]), to(aux["conics"]), sc["features"], sc["opacities"],
+                                                to(bgn), ranges, ids, cam, return_aux=True)
+    rec = check_image_strict(img, ref, aux["margin"], tag="cfg2 rasteriser on oracle inputs", eps=1e-5)
+    calm = aux["margin"] >= 1e-5
+    assert np.array_equal(np_(last)[calm], aux["last_ids"][calm])      # last_ids equal wherever no branch is close
+    print(f"cfg2: M={aux['M']}, pixels beyond 1e-4: {rec['beyond_atol']} (all explained by a branch margin < 1e-5)")
 
 
 def test_huge_tile_grid_is_binned_and_rendered_in_bands(device):
