@@ -286,8 +286,12 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  * ------------------------------------------------------------------------------------- */
 enum { MS_RENDER_WHOLE = 0, MS_RENDER_RESUME = 1, MS_RENDER_BEGIN = 2, MS_RENDER_FINISH = 3,
        MS_RENDER_FULL_SORT = 0x100, /* or-ed into `resume`: no lazy sorting for this frame */
-       MS_RENDER_FRONT_LEVEL = 0x200 /* x 0..3, or-ed into `resume`: lazily sorted fronts 2^level times as deep
-                                        (a caller whose previous frame needed the clean-up pass, host_info[5] > 0) */ };
+       MS_RENDER_FRONT_LEVEL = 0x200, /* x 0..3, or-ed into `resume`: lazily sorted fronts 2^level times as deep
+                                        (a caller whose previous frame needed the clean-up pass, host_info[5] > 0) */
+       MS_RENDER_ROWS16 = 0x800 /* or-ed into `resume`: [tile_row_begin, tile_row_end) counts rows of 16 pixels whatever
+                                   tile_size (a multiple of 16) is: the band is binned on the tile rows that cover
+                                   it and rasterised on exactly those 16-px rows -- a multi-GPU rank keeps its band
+                                   while the bin size follows the scene (32- / 64-px bins for dense scenes) */ };
 size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h);
 size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch);
 int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,

@@ -54,6 +54,7 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
 FULL_SORT = 0x100
 FRONT_LEVEL = 0x200  # x level (0..3): deeper lazily sorted fronts
+ROWS16 = 0x800       # row_range counts rows of 16 px whatever the tile size (a band keeps its rows, the bins follow the scene)
 
 
 class _Frame:
@@ -61,7 +62,7 @@ class _Frame:
     `run(phase)` makes the library call; `finish()` completes a frame that was only begun."""
 
     def __init__(self, means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                 stage_events, row_range, out, lane, stream=None, own=False):
+                 stage_events, row_range, out, lane, stream=None, own=False, rows16=False):
         """own=True: the frame gets FRESH scratch (workspace, intersection buffer) and the per-pixel
         records of the backward pass instead of the lane's cached buffers -- a differentiable frame
         keeps them until its backward has run.  Only the size hint, the pinned record and the event
@@ -97,6 +98,8 @@ class _Frame:
         else:
             ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
         self.ws, self.grid = ws, (N, tw, th)
+        # rows16: row_range is in rows of 16 px although tile_size is 32 / 64 (MS_RENDER_ROWS16)
+        self.rows16 = ROWS16 if (rows16 and row_range is not None and tile_size != 16) else 0
         r0, r1 = (0, th) if row_range is None else row_range
         # what the lane's sorting mode (below) was learnt on: scene size class (N to ~9 %: the clean-up count
         # the library reports one frame later lives at an offset that depends on the grid only), grid and band
@@ -104,7 +107,7 @@ class _Frame:
         # sorting mode of this frame, fixed for both of its halves: lazily sorted fronts of the lane's
         # current depth level, or full sorts once the lane has given up on them
         self.level = int(st.get("front_level", 0))
-        self.mode = FULL_SORT if st.get("full_sort") else FRONT_LEVEL * self.level
+        self.mode = (FULL_SORT if st.get("full_sort") else FRONT_LEVEL * self.level) | self.rows16
         if out is not None:
             assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
             assert out.shape[0] >= H and tuple(out.shape[1:]) == (W, C)
@@ -217,7 +220,7 @@ class _Frame:
 
 
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                   stage_events=None, row_range=None, out=None, lane=0, info=None):
+                   stage_events=None, row_range=None, out=None, lane=0, info=None, rows16=False):
     """-> (image (H,W,C) f32, M).  `background` may be None.  stage_events: None or a list of 4
     torch.cuda.Event that have been recorded once (so their handles exist).
     row_range=(r0, r1) renders only tile rows [r0, r1) into `out` (a caller-owned framebuffer of
@@ -227,7 +230,7 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
     FULL tile grid (band-independent)."""
     with _frame_lock:
         return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                      stage_events, row_range, out, lane).finish(WHOLE, info)
+                      stage_events, row_range, out, lane, rows16=rows16).finish(WHOLE, info)
 
 
 def last_frame_list_entries(dev, N, tile_w, tile_h, lane=0):

@@ -97,13 +97,14 @@ const int32_t *isect_order_array(const void *workspace, int64_t N, int tile_w, i
 // rasterize.hip: ms_rasterize_to_pixels_3dgs_fwd with a separate density hint (ms_render_fwd's
 // sync-free frames pass the buffer capacity as M and the previous frame's M as the hint).
 // records: N ready-made RasterRecords (3 channels) or null; order: the band's tiles of the BINNING grid,
-// heaviest list first (isect_order_array; for a split frame these are its 32-px bins), or null
+// heaviest list first (isect_order_array; for a split frame these are its 32-px bins), or null;
+// clip_row16_begin / _end: only the 16x16 blocks of these 16-px rows are rasterised (-1: all of the band's tiles)
 int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means2d, const float *conics,
                   const void *colors, int color_dtype, int CDIM, const float *opacities, const float *backgrounds,
                   int W, int H, int tile_size, int tile_row_begin, int tile_row_end, const int32_t *tile_ranges,
                   const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
-                  const LazyLists *lazy, const void *records, const int32_t *order, void *after_raster_event,
-                  void *stream);
+                  const LazyLists *lazy, const void *records, const int32_t *order, int clip_row16_begin,
+                  int clip_row16_end, void *after_raster_event, void *stream);
 
 // Block lists of a split frame (ms_render_fwd): what the sort kernels of 32-px bins write instead of
 // flatten_ids.  Bin `b` with list [start, start + n) owns block_ids[4 start, 4 (start + n)): its block q

@@ -123,6 +123,18 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "render_fwd: bad sizes");
     MS_REQUIRE(workspace && host_info && render_colors, MS_ERR_INVALID_ARG, "render_fwd: null pointer");
     const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+    // MS_RENDER_ROWS16: the band is given in rows of 16 pixels; bin the tile rows that cover it, rasterise it alone
+    const bool rows16 = (resume & MS_RENDER_ROWS16) != 0 && tile_size != 16;
+    MS_REQUIRE(!rows16 || tile_size % 16 == 0, MS_ERR_INVALID_ARG, "render_fwd: MS_RENDER_ROWS16 needs a tile size that is a multiple of 16");
+    const int k16 = rows16 ? tile_size / 16 : 1, th16 = (H + 15) / 16;
+    int clip0 = -1, clip1 = -1;   // 16-px rows the rasteriser keeps (-1: all of the band's tiles)
+    if (rows16) {
+        MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th16, MS_ERR_INVALID_ARG,
+                   "render_fwd: bad band of 16-px rows [%d,%d) of %d", tile_row_begin, tile_row_end, th16);
+        clip0 = tile_row_begin; clip1 = tile_row_end;
+        tile_row_begin = clip0 / k16;
+        tile_row_end = clip1 > clip0 ? (clip1 + k16 - 1) / k16 : tile_row_begin;
+    }
     MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th, MS_ERR_INVALID_ARG,
                "render_fwd: bad tile row band [%d,%d) of %d", tile_row_begin, tile_row_end, th);
     const int r0 = tile_row_begin, r1 = tile_row_end;
@@ -238,7 +250,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
                                            render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr,
-                                           records, order, stage_events ? stage_events[3] : nullptr, stream))
+                                           records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0);
             }
@@ -315,7 +327,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     lazy_lists.keys = keys;
     if (int rc = ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                                    tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
-                                   lazy ? &lazy_lists : nullptr, records, order,
+                                   lazy ? &lazy_lists : nullptr, records, order, clip0, clip1,
                                    (!speculated && stage_events) ? stage_events[3] : nullptr, stream))
         return rc;
     return MS_OK;

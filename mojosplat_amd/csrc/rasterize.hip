@@ -179,6 +179,10 @@ __global__ __launch_bounds__(SOLO ? 64 : 64 * (4 / NQ), (CP <= 4 ? MS_RASTER_MIN
     }
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
+    if (!A.order_bins) {   // a band cut at 16-px rows inside coarser tiles: blocks outside it are not this call's
+        const int by16 = tile_y * A.nsx + sub_y;
+        if (by16 < A.row0 || by16 >= A.row1) return;
+    }
     const int lane = threadIdx.x & 63;
     const int lx = lane & 7, ly = lane >> 3;
     const int bx = tile_x * A.ts + sub_x * 16, by = tile_y * A.ts + sub_y * 16;
@@ -492,6 +496,9 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
             if (A.lazy.packed) {   // a bin at the edge of a band: only the block rows inside it (uniform)
                 const int brow = tile_y * A.nsx + sub_y;
                 if (brow < A.lazy.row_lo || brow >= A.lazy.row_hi) continue;
+            } else {               // likewise a coarse tile of a band cut at 16-px rows
+                const int brow = tile_y * A.nsx + sub_y;
+                if (brow < A.row0 || brow >= A.row1) continue;
             }
             const int q = w;  // one quad per wave
             const int ox = sub_x * 16 + lx + (q & 1) * 8, oy = sub_y * 16 + ly + (q >> 1) * 8;
@@ -788,8 +795,8 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
                       const float *backgrounds, int W, int H, int tile_size, int tile_row_begin,
                       int tile_row_end, const int32_t *tile_ranges, const int32_t *flatten_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
-                      const ms::LazyLists *lazy, const void *records, const int32_t *order, void *after_raster_event,
-                      void *stream) {
+                      const ms::LazyLists *lazy, const void *records, const int32_t *order, int clip_row16_begin,
+                      int clip_row16_end, void *after_raster_event, void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_fwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_fwd: CDIM %d not in 1..32", CDIM);
@@ -804,7 +811,10 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.backgrounds = backgrounds; A.tile_ranges = tile_ranges; A.flatten_ids = flatten_ids;
     A.render_colors = render_colors; A.render_alphas = render_alphas; A.last_ids = last_ids;
     A.order = order;
-    A.order_bins = 0; A.row0 = tile_row_begin; A.row1 = tile_row_end;
+    A.order_bins = 0;
+    // the 16-px block rows to rasterise: the band's tiles, or the caller's clip inside them
+    A.row0 = clip_row16_begin >= 0 ? clip_row16_begin : 0;
+    A.row1 = clip_row16_begin >= 0 ? clip_row16_end : 0x7fffffff;
     A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     if (lazy) A.lazy = *lazy;
     else A.lazy = ms::LazyLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0x7fffffff, 64};
@@ -852,7 +862,7 @@ extern "C" int ms_rasterize_to_pixels_3dgs_fwd(int64_t N, int64_t M, const float
                                                void *stream) {
     return ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                              tile_size, tile_row_begin, tile_row_end, tile_ranges, flatten_ids, render_colors,
-                             render_alphas, last_ids, nullptr, nullptr, nullptr, nullptr, stream);
+                             render_alphas, last_ids, nullptr, nullptr, nullptr, -1, -1, nullptr, stream);
 }
 
 int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const float *means2d, const float *conics,

@@ -67,6 +67,39 @@ def _band_of(band, th):
     return (min(band[0], th), min(max(band[1], band[0]), th))
 
 
+# Bin size of a rank's band frames (16 = the library's default for 16-px tiles, 32 / 64 = plain coarse bins under a
+# band that keeps its 16-px rows, MS_RENDER_ROWS16): the same rule as render_gaussians (render.bin_rule) applied to
+# the band's own size record -- pairs on its bin rows, its (pre-culled) Gaussians on the grid -- one frame behind.
+# The pixels do not depend on it (tests/test_hip_fused.py); ranks need not agree.
+def _band_key(means3d, camera, band, tile_size):
+    import math
+    n = means3d.shape[0]
+    return ("band", means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H, tuple(band), tile_size)
+
+
+def _band_bin(means3d, camera, band, tile_size):
+    """-> (key, bin px) for this band's next frame."""
+    from . import render as R
+    if tile_size != 16:
+        return None, tile_size
+    forced = R._env_bin_px()
+    if forced is not None:
+        return None, forced
+    key = _band_key(means3d, camera, band, tile_size)
+    with R._bin_lock:
+        return key, R._bin_mode.get(key, 16)
+
+
+def _band_learn(key, mode, m, info, camera, band):
+    if key is None:
+        return
+    from . import render as R
+    # (a frame at mode 16 is a split frame -- 32-px bins, flag bit 3 -- unless the band is too thin for that)
+    grid = (32 if info["flags"] & 8 else 16) if mode == 16 else mode
+    R._settle(key, mode, R.bin_rule(mode, m, info["on_grid"], camera.W, max(16, (band[1] - band[0]) * 16),
+                                    band=True, grid_px=grid))
+
+
 def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size, band, out):
     """Render tile rows `band` into `out`; -> Gaussians touching the full grid (0 = empty frame)."""
     r0, r1 = band
@@ -75,8 +108,11 @@ def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg
     if stages is None:
         from ._fused import render_fwd_hip
         info = {}
-        render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                       row_range=_band_of(band, th), out=out, info=info)
+        b = _band_of(band, th)
+        key, mode = _band_bin(means3d, camera, b, tile_size)
+        _, m = render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, mode,
+                              row_range=b, out=out, info=info, rows16=True)
+        _band_learn(key, mode, m, info, camera, b)
         return info["on_grid"]
     means2d, conics, depths, radii = stages.project(means3d, scales, quats, opacities, camera)
     ids, ranges = stages.bin(means2d, radii, depths, tile_size, tw, th, band)
@@ -195,8 +231,10 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     # Marshal first (non-fp32 / strided inputs and the view matrix are copied by kernels enqueued on the
     # CURRENT stream), then make the lane wait for the current stream, then enqueue the band on the lane:
     # everything the band reads -- the caller's tensors and the marshalled copies -- is ordered before it.
-    frame = _Frame(means3d, scales, quats, opacities, features, camera, bg, tile_size, evs,
-                   _band_of(bands[rank], th), full, 1 + lane, s.cuda_stream)
+    my_band = _band_of(bands[rank], th)
+    bkey, bmode = _band_bin(means3d, camera, my_band, tile_size)
+    frame = _Frame(means3d, scales, quats, opacities, features, camera, bg, bmode, evs,
+                   my_band, full, 1 + lane, s.cuda_stream, rows16=True)
     s.wait_stream(cur)
     frame.begin()
     # tensors allocated on the current stream and used on the lane: the caching allocator must not hand
@@ -206,7 +244,8 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
 
     def finalize():
         info = {}
-        frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
+        _, m = frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
+        _band_learn(bkey, bmode, m, info, camera, my_band)
         now = torch.cuda.current_stream(dev)
         now.wait_stream(s)           # the band is complete before the exchange starts
         img, work = gather(full, info["on_grid"])   # RCCL's stream waits for `now`

@@ -69,12 +69,18 @@ def _rule(d, e, k=1.0):
     return 64 if e > _E_COARSE * k else 32
 
 
-def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int) -> int:
+def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int, band: bool = False, grid_px: Optional[int] = None) -> int:
     """Bin size (16 = split frame, 32, 64) the rule above picks after a frame binned at `mode` that
-    reported `m` (Gaussian, bin) pairs for `on_grid` Gaussians on a W x H image."""
+    reported `m` (Gaussian, bin) pairs for `on_grid` Gaussians on a W x H image.
+    band=True: the frame was a multi-GPU rank's band of height H whose `on_grid` counts every Gaussian that
+    touches the band (csrc/binning.hip, k_band_precull): a Gaussian of diameter d then lies only partly inside,
+    on average h / (h + d + g) of its bin rows, and both estimates are corrected for that.
+    grid_px: the bin size the pairs were counted on when that is not what `mode` implies."""
     if m <= 0 or on_grid <= 0:
         return mode
-    g = 32 if mode == 16 else mode
+    # the grid the pairs were counted on: a frame at mode 16 is a split frame (32-px bins) unless the library
+    # kept a thin band on plain 16-px tiles (grid_px says so)
+    g = grid_px if grid_px else (32 if mode == 16 else mode)
     p = max(m / on_grid, 1.0)
     bins = math.ceil(W / g) * math.ceil(H / g)
     if p >= 0.8 * bins:
@@ -82,9 +88,29 @@ def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int) -> int:
         # clamped by the grid and says nothing; such a scene wants the coarsest bins
         return 64
     d = g * (math.sqrt(p) - 1.0)
-    e = on_grid * (d / 16.0 + 1.0) ** 2 / (math.ceil(W / 16) * math.ceil(H / 16))
+    inside = 1.0
+    if band:
+        for _ in range(8):   # fixed point of p (h + d + g) / h = (d / g + 1)^2
+            d = g * (math.sqrt(p * (H + d + g) / H) - 1.0)
+        inside = H / (H + d + 16.0)
+    e = on_grid * inside * (d / 16.0 + 1.0) ** 2 / (math.ceil(W / 16) * math.ceil(H / 16))
     lo, hi = _rule(d, e, 1.0 - _DEAD_BAND), _rule(d, e, 1.0 + _DEAD_BAND)
     return lo if lo == hi else mode     # inside a dead band: stay
+
+
+def _settle(key, mode, nxt):
+    """Record `nxt` as the grid of the next frame behind `key` -- but never straight back to the grid just left
+    (estimates taken on different grids can disagree at the margins: no frame-by-frame flip-flop); after
+    _MIN_SETTLED frames it may."""
+    with _bin_lock:
+        if len(_bin_mode) >= 256 and key not in _bin_mode:
+            _bin_mode.pop(next(iter(_bin_mode)))
+            _bin_left.pop(next(iter(_bin_left)), None)
+        left, age = _bin_left.get(key, (None, 0))
+        if nxt != mode and nxt == left and age < _MIN_SETTLED:
+            nxt = mode
+        _bin_left[key] = (mode, 0) if nxt != mode else (left, age + 1)
+        _bin_mode[key] = nxt
 
 
 def _bin_key(means3d, camera):
@@ -190,18 +216,7 @@ def render_gaussians(
             img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, mode,
                                     stage_events=evs, info=info)
             if key is not None:
-                nxt = bin_rule(mode, m, info["on_grid"], camera.W, camera.H)
-                with _bin_lock:
-                    if len(_bin_mode) >= 256 and key not in _bin_mode:
-                        _bin_mode.pop(next(iter(_bin_mode)))
-                        _bin_left.pop(next(iter(_bin_left)), None)
-                    # never straight back to the grid just left (estimates taken on different grids can
-                    # disagree at the margins: no frame-by-frame flip-flop); after _MIN_SETTLED frames it may
-                    left, age = _bin_left.get(key, (None, 0))
-                    if nxt != mode and nxt == left and age < _MIN_SETTLED:
-                        nxt = mode
-                    _bin_left[key] = (mode, 0) if nxt != mode else (left, age + 1)
-                    _bin_mode[key] = nxt
+                _settle(key, mode, bin_rule(mode, m, info["on_grid"], camera.W, camera.H))
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer

@@ -36,18 +36,20 @@ def main():
         rows, bands = band_plan(th, world)
         frame = torch.empty((max(world * rows * 16, H), W, 3), device=dev)
         per_rank = []
-        for band in bands:
-            for _ in range(5):
-                _, m = _fused.render_fwd_hip(*g, cam, bg, 16, row_range=band, out=frame)
+        for r, band in enumerate(bands):
+            # the blocking sharded entry point acting as rank r (no exchange): pre-cull, the band's own bin size
+            for _ in range(6):
+                render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                _fused.render_fwd_hip(*g, cam, bg, 16, row_range=band, out=frame)
+                render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world))
             t_host = time.perf_counter() - t0
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            per_rank.append(dict(band=band, M=m, us=round(dt / args.steps * 1e6, 1),
-                                 host_us=round(t_host / args.steps * 1e6, 1)))
+            from mojosplat_amd.render import _bin_mode
+            per_rank.append(dict(band=band, bin_px=[v for k, v in _bin_mode.items() if k[0] == "band" and k[5] == tuple(band)][-1:] or [16],
+                                 us=round(dt / args.steps * 1e6, 1), host_us=round(t_host / args.steps * 1e6, 1)))
         # the same through the asynchronous sharded entry point (frame k+1 begun before frame k is
         # finished; no exchange in rehearsal mode): what a rank's host + GPU can sustain
         for r, rec in enumerate(per_rank):

@@ -1,11 +1,11 @@
-"""One rank's band of a frame, many times, for `rocprofv3 --kernel-trace --stats` (per-kernel picture of a band frame).
+"""One rank's band of a frame through the sharded entry point (rehearse), many times, for
+`rocprofv3 --kernel-trace --stats` (per-kernel picture of a band frame).
 python scripts/band_profile.py cfg3 8 3   -> workload, world, rank"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import WORKLOADS
-from mojosplat_amd import _fused
-from mojosplat_amd.distributed import band_plan
+from mojosplat_amd.distributed import render_gaussians_sharded
 from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
 name, world, rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 N, W, H, ell, fp16 = WORKLOADS[name]
@@ -13,8 +13,6 @@ dev = torch.device("cuda", 0)
 sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=dev)
 bg = torch.tensor(BACKGROUND_V1, device=dev)
 g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
-rows, bands = band_plan(-(-H // 16), world)
-frame = torch.empty((max(world * rows * 16, H), W, 3), device=dev)
-for _ in range(40):
-    _fused.render_fwd_hip(*g, cam, bg, 16, row_range=bands[rank], out=frame)
+for _ in range(44):
+    render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(rank, world))
 torch.cuda.synchronize()

@@ -29,7 +29,7 @@ CFG = {
 
 
 def timed(fn, iters=100, warm=16):
-    for _ in range(warm):   # (render_gaussians races its binning modes over a scene's first frames)
+    for _ in range(warm):   # (render_gaussians moves to the binning rule's grid after a scene's first frame)
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -95,8 +95,7 @@ def main():
             del frame, st, img2, key, tile_of, full
             out["ms_fwd"] = round(timed(lambda: ms.render_gaussians(*g, cam, background_color=bg, backend="hip")), 3)
             from mojosplat_amd import render as R
-            tuner = R._tuner(g[0], cam, 16)
-            out["bin_px"], out["race_ms"] = tuner.choice, {k: round(v * 1e3, 4) for k, v in tuner.times.items()}
+            out["bin_px"] = R._bin_mode.get(R._bin_key(g[0], cam), 16)    # the binning rule's choice (render.py)
             out["fps"] = round(1e3 / out["ms_fwd"], 1)
             out["GBps_alg"] = round((96 * N + (78 if fp16 else 84) * out["M"] + 12 * th * tw + 12 * H * W)
                                     / (out["ms_fwd"] * 1e-3) / 1e9, 1)

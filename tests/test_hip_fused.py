@@ -435,6 +435,27 @@ def test_frame_does_not_depend_on_the_binning_granularity(device):
         _fused._state.clear()
 
 
+def test_bands_of_16px_rows_under_coarse_bins(device):
+    """MS_RENDER_ROWS16: a multi-GPU rank's band keeps its 16-px rows while the bins are 32 or 64 px (dense
+    scenes): the band is binned on the tile rows that cover it and rasterised on exactly its rows.  Bands cut
+    anywhere assemble to the full frame bit for bit, and nothing outside a band's rows is written."""
+    sc, cam = randscene_v1(60_000, 512, 384, ell=-2.6, seed=41, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    ref = stagewise(sc, cam, bg, 16)
+    th = 384 // 16
+    for ts in (32, 64):
+        for cuts in ((0, 5, 6, 13, th), (0, 1, th - 1, th), (0, 9, 9, 18, th)):
+            frame = torch.full_like(ref, -7.0)
+            for r0, r1 in zip(cuts[:-1], cuts[1:]):
+                before = frame.clone()
+                _fused.render_fwd_hip(*g, cam, bg, ts, row_range=(r0, r1), out=frame, rows16=True)
+                keep = torch.ones(384, dtype=torch.bool, device=device)
+                keep[r0 * 16:r1 * 16] = False
+                assert torch.equal(frame[keep], before[keep]), (ts, r0, r1)   # only the band's rows were touched
+            assert torch.equal(frame, ref), (ts, cuts)
+
+
 def test_split_frame_restarts_on_16px_tiles_when_its_bins_hold_too_much(device):
     """A split frame whose 32-px bins hold more entries than 4 block-list slots each can index (2^29;
     lowered to 1000 through the environment here, in a fresh process since the library reads it once)
