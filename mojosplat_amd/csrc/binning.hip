@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
                                                                float y_lo, float y_hi, int64_t chunk,
                                                                int32_t *__restrict__ cand,
                                                                int32_t *__restrict__ seg_count) {
-    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_w[4 * 16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float V[12];
 #pragma unroll
@@ -365,41 +365,57 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
     int32_t *seg = cand + i0;
     uint32_t written = 0;   // survivors of this segment so far (uniform)
-    for (int64_t base = i0; base < i1; base += kHistThreads) {
-        const int64_t i = base + threadIdx.x;
-        bool keep = false;
-        if (i < i1) {
-            const float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
-            const float mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
-            const float my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
-            const float z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
-            if (!(z < P.near_plane || z > P.far_plane)) {   // the exact projection's own depth cull
-                float sm = fmaxf(scales[3 * i], fmaxf(scales[3 * i + 1], scales[3 * i + 2]));
-                if (P.scales_are_log) sm = __expf(sm);
-                const float rz = __builtin_amdgcn_rcpf(z);
-                const float u = fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz)), v = fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
-                const float s2 = lam * sm * sm;
-                const float fxz = P.fx * rz, fyz = P.fy * rz;
-                const float rx = 3.33f * __builtin_amdgcn_sqrtf(fxz * fxz * (1.0f + u * u) * s2 + P.eps2d) * 1.001f + 2.0f;
-                const float ry = 3.33f * __builtin_amdgcn_sqrtf(fyz * fyz * (1.0f + v * v) * s2 + P.eps2d) * 1.001f + 2.0f;
-                const float xs = P.fx * mx * rz + P.cx, ys = P.fy * my * rz + P.cy;
-                // (negated comparisons: a NaN anywhere keeps the Gaussian for the exact path to judge)
-                keep = !(ys + ry < y_lo || ys - ry > y_hi || xs + rx < 0.f || xs - rx > P.W);
-            }
-        }
-        const unsigned long long b = __ballot(keep);
-        __syncthreads();   // s_w of the previous step has been read
-        if (lane == 0) s_w[w] = (uint32_t)__popcll(b);
-        __syncthreads();
-        uint32_t before = written, total = 0;
+    // kSub sub-steps of 1024 Gaussians share one pair of barriers (the pass is a chain of load -> test -> count
+    // round trips, not a bandwidth problem: LDS-staged 16-byte loads made it 1.5x SLOWER)
+    constexpr int kSub = 4;
+    for (int64_t base = i0; base < i1; base += (int64_t)kSub * kHistThreads) {
+        bool keep[kSub];
+        unsigned long long bal[kSub];
 #pragma unroll
-        for (int ww = 0; ww < 16; ++ww) {
-            const uint32_t c = s_w[ww];
-            if (ww < w) before += c;
-            total += c;
+        for (int k = 0; k < kSub; ++k) {
+            const int64_t i = base + (int64_t)k * kHistThreads + threadIdx.x;
+            keep[k] = false;
+            if (i < i1) {
+                const float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
+                const float mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
+                const float my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
+                const float z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
+                if (!(z < P.near_plane || z > P.far_plane)) {   // the exact projection's own depth cull
+                    float sm = fmaxf(scales[3 * i], fmaxf(scales[3 * i + 1], scales[3 * i + 2]));
+                    if (P.scales_are_log) sm = __expf(sm);
+                    const float rz = __builtin_amdgcn_rcpf(z);
+                    const float u = fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz)), v = fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
+                    const float s2 = lam * sm * sm;
+                    const float fxz = P.fx * rz, fyz = P.fy * rz;
+                    const float rx = 3.33f * __builtin_amdgcn_sqrtf(fxz * fxz * (1.0f + u * u) * s2 + P.eps2d) * 1.001f + 2.0f;
+                    const float ry = 3.33f * __builtin_amdgcn_sqrtf(fyz * fyz * (1.0f + v * v) * s2 + P.eps2d) * 1.001f + 2.0f;
+                    const float xs = P.fx * mx * rz + P.cx, ys = P.fy * my * rz + P.cy;
+                    // (negated comparisons: a NaN anywhere keeps the Gaussian for the exact path to judge)
+                    keep[k] = !(ys + ry < y_lo || ys - ry > y_hi || xs + rx < 0.f || xs - rx > P.W);
+                }
+            }
+            bal[k] = __ballot(keep[k]);
         }
-        if (keep) seg[before + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = (int32_t)i;
-        written += total;
+        __syncthreads();   // s_w of the previous step has been read
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kSub; ++k) s_w[k * 16 + w] = (uint32_t)__popcll(bal[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSub; ++k) {   // list order = Gaussian order: sub-step by sub-step, wave by wave
+            uint32_t before = written, total = 0;
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) {
+                const uint32_t c = s_w[k * 16 + ww];
+                if (ww < w) before += c;
+                total += c;
+            }
+            if (keep[k])
+                seg[before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], 0u))] =
+                    (int32_t)(base + (int64_t)k * kHistThreads + threadIdx.x);
+            written += total;
+        }
     }
     if (threadIdx.x == 0) seg_count[blockIdx.x] = (int32_t)written;
 }
