@@ -168,7 +168,8 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                        (r1 - r0 >= 16 || (r0 == 0 && r1 == th)) && !no_split && ms_split_enabled();
     const int bw = (tw + 1) / 2, bh = (th + 1) / 2, b0 = r0 / 2, b1 = (r1 + 1) / 2;
     // the rasteriser's ready-made records (3-channel forward frames): written by the projection kernel
-    const bool use_records = CDIM == 3 && opacities && colors && !render_alphas && !last_ids;
+    const bool use_records = CDIM == 3 && opacities && colors;
+    const bool aux_frame = render_alphas || last_ids;   // a differentiable frame: ids must stay Gaussian indices
     void *records = use_records ? (void *)(ws + L.off_records) : nullptr;
     // the rasteriser launches its blocks heaviest list first (the count pass leaves the order of the binning
     // grid's tiles in the isect workspace); MOJOSPLAT_RASTER_ORDER=0: image order interleaved over the XCDs
@@ -179,7 +180,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     // MOJOSPLAT_BAND_CULL=0 switches that off.
     // (only frames whose rasteriser reads the ready-made records: the lists of a culled band hold POSITIONS in the
     // band's candidate list, which index the workspace's dense projected arrays and records, not the caller's)
-    const int cull = (use_records && N >= 32768 && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0;
+    const int cull = (use_records && !aux_frame && N >= 32768 && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0;
     const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0) | cull;
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
     ms::LazyLists lazy_lists;

@@ -732,8 +732,9 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
     } while (0)
     bool done = false;
     if constexpr (CP == 3) {
-        if (A.records && !aux) {
-            MS_LAUNCH_RASTER_NQ(false, true);
+        if (A.records) {
+            if (aux) MS_LAUNCH_RASTER_NQ(true, true);
+            else MS_LAUNCH_RASTER_NQ(false, true);
             done = true;
         }
     }
