@@ -18,6 +18,8 @@
  *   ms_project_gaussians_bwd          render.py:11); gsplat's backward semantics
  *   ms_render_fwd                     the whole of render_gaussians' device work
  *                                     (mojosplat/render.py:63-101) in one call
+ *   ms_render_fwd_batch               the same for C cameras: the camera dimension of the reference's
+ *                                     kernels (kernels/projection.mojo:32-37) that its wrappers pin to 1
  *
  * Conventions (same as the reference's op convention, projection.py:438-454):
  *   - destination passing: the caller (PyTorch) owns and pre-allocates every buffer,
@@ -35,7 +37,7 @@
  *     crosses this boundary.  ms_last_error_string() describes the last failure on the
  *     calling thread.
  *   - single camera (C = 1), like every wrapper of the reference (projection.py:431,
- *     rasterization.py:175).
+ *     rasterization.py:175); ms_render_fwd_batch is the one entry point with C > 1.
  */
 #ifndef MOJOSPLAT_HIP_H
 #define MOJOSPLAT_HIP_H
@@ -303,6 +305,45 @@ int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scal
                   void *isect_buf, size_t isect_bytes, int64_t *host_info, int resume,
                   float *render_colors, float *render_alphas, int32_t *last_ids,
                   void **stage_events, void *sync_event, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Camera batch: the same Gaussians from C cameras in one call -> render_colors f32[C,H,W,CDIM].
+ * The reference's kernels carry a camera dimension (kernels/projection.mojo:32-37,
+ * kernels/rasterization.mojo:66) that every wrapper pins to 1 (projection.py:431,
+ * rasterization.py:175); this is the entry point with C > 1.  View v equals what ms_render_fwd
+ * renders for camera v, bit for bit (incl. the zeros image for a view with nothing on the grid).
+ * MI355X mapping: a frame is a VALU-bound rasteriser behind latency-bound binning kernels and one
+ * host wait for its size record, so the batch keeps n_lanes (1..4, normally 2) views IN FLIGHT on
+ * as many streams: view v+1's projection / binning overlaps view v's rasteriser and is enqueued
+ * (MS_RENDER_BEGIN) before the host waits for view v's record (MS_RENDER_FINISH).  A pass over
+ * (camera, Gaussian) in one kernel would save nothing: the projection is VALU bound, not
+ * bandwidth bound.
+ *   viewmats   : DEVICE f32[C,16], row-major world->camera;  intrinsics: HOST f32[C,4] = fx fy cx cy
+ *   lanes      : HOST array of n_lanes scratch sets, each as ms_render_fwd wants them (workspace of
+ *                ms_render_workspace_bytes, isect_buf, pinned host_info i64[8], a hipEvent_t, a
+ *                hipStream_t).  The caller orders the lanes' streams after its inputs and itself after
+ *                the lanes' streams.
+ *   flags      : MS_RENDER_FULL_SORT / MS_RENDER_FRONT_LEVEL bits applied to every view (0 = defaults)
+ *   counts     : HOST i64[C] or NULL: intersections of each view
+ *   views_done : HOST, in: first view to render (0); out: views completed.  On MS_ERR_WORKSPACE the
+ *                isect_buf of lane *need_lane is too small for view *views_done (*need_isect_bytes
+ *                needed): nothing is in flight any more; grow it and call again with the same arrays.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ms_view_lane {
+    void *workspace;
+    size_t workspace_bytes;
+    void *isect_buf;
+    size_t isect_bytes;
+    int64_t *host_info;
+    void *sync_event;
+    void *stream;
+} ms_view_lane;
+int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                        const float *quats, const float *opacities, const void *colors, int color_dtype,
+                        int CDIM, const float *viewmats, const float *intrinsics, int W, int H, float eps2d,
+                        float near_plane, float far_plane, int tile_size, const float *backgrounds, int n_lanes,
+                        const ms_view_lane *lanes, int flags, float *render_colors, int64_t *counts,
+                        int *views_done, size_t *need_isect_bytes, int *need_lane);
 
 /* Where ms_render_fwd keeps its intermediates inside `workspace` (byte offsets), for callers that
  * go on to differentiate the frame: offsets[0..4] = means2d f32[N,2], conics f32[N,3],

@@ -262,43 +262,72 @@ def render_begin_hip(means3d, scales, quats, opacities, colors, camera, backgrou
 
 @torch.no_grad()
 def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, background, tile_size):
-    """Render the same Gaussians from several cameras -> (C, H, W, channels) f32.
+    """Render the same Gaussians from several cameras -> (C, H, W, channels) f32: ONE library call,
+    ms_render_fwd_batch (the camera dimension the reference's kernels carry and its wrappers pin to 1).
 
-    Views are independent, so two are kept in flight: view i+1's projection / counting (memory and
-    latency bound) runs on a second stream beside view i's rasteriser (VALU bound), and view i+1 is
-    enqueued (ms_render_fwd BEGIN) before the host waits for view i's size record (FINISH).  Each
-    lane has its own scratch; the caller's stream waits for both lanes before the batch is handed
-    back."""
+    Views are independent, so the library keeps two in flight on the two lane streams: view i+1's
+    projection / counting (memory and latency bound) runs beside view i's rasteriser (VALU bound), and
+    view i+1 is enqueued before the host waits for view i's size record.  Each lane has its own scratch;
+    the caller's stream waits for both lanes before the batch is handed back."""
+    L = _hip.lib()
     dev = means3d.device
     H, W = cameras[0].H, cameras[0].W
     assert all(c.H == H and c.W == W for c in cameras), "all cameras of a batch share one image size"
-    C = colors.shape[1]
-    out = torch.empty((len(cameras), H, W, C), dtype=torch.float32, device=dev)
+    near, far = cameras[0].near, cameras[0].far
+    assert all(c.near == near and c.far == far for c in cameras), "all cameras of a batch share near / far planes"
+    C = len(cameras)
+    N = means3d.shape[0]
+    means3d, scales, quats = _hip.f32c(means3d), _hip.f32c(scales), _hip.f32c(quats)
+    op = _hip.f32c(opacities.reshape(-1))
+    if colors.dtype == torch.float16:
+        cdt, colors = 1, colors.contiguous()
+    else:
+        cdt, colors = 0, _hip.f32c(colors)
+    CD = colors.shape[1]
+    bg = None if background is None else _hip.f32c(background.reshape(-1))
+    out = torch.empty((C, H, W, CD), dtype=torch.float32, device=dev)
+    if C == 0:
+        return out, []
+    vms = torch.stack([c._viewmat_f32().to(dev) for c in cameras]).contiguous()       # (C, 4, 4) on the device
+    intr = (ctypes.c_float * (4 * C))(*[v for c in cameras for v in (c.fx, c.fy, c.cx, c.cy)])
+    th, tw = -(-H // tile_size), -(-W // tile_size)
     cur = torch.cuda.current_stream(dev)
-    lanes = _lane_streams(dev)
-    ready = torch.cuda.Event()
-    ready.record(cur)
-    counts, pending = [], None
-    for i, cam in enumerate(cameras):
-        lane = 1 + (i % len(lanes))
-        s = lanes[lane - 1]
-        s.wait_event(ready)
-        with torch.cuda.stream(s):
-            frame = render_begin_hip(means3d, scales, quats, opacities, colors, cam, background, tile_size,
-                                     out=out[i], lane=lane)
-        if pending is not None:  # the previous view's record is long written by now
-            with torch.cuda.stream(pending[1]):
-                counts.append(pending[0].finish()[1])
-        pending = (frame, s)
-    if pending is not None:
-        with torch.cuda.stream(pending[1]):
-            counts.append(pending[0].finish()[1])
-    for s in lanes:
-        cur.wait_stream(s)
-    for t in (out, means3d, scales, quats, opacities, colors):
-        for s in lanes:
-            t.record_stream(s)
-    return out, counts
+    streams = _lane_streams(dev)
+    n_lanes = min(len(streams), 2, C)
+    with _frame_lock:
+        sts = [_dev_state(dev, 1 + k) for k in range(n_lanes)]
+        for st in sts:
+            assert not st.get("busy"), "a begun frame still occupies this lane: finish it first"
+            _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
+        for s_ in streams[:n_lanes]:
+            s_.wait_stream(cur)      # inputs (and the marshalled copies above) are ready
+        counts = (ctypes.c_int64 * C)()
+        done, need, lane_i = ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_int(0)
+        with _hip.on_device(dev):
+            while True:
+                lanes = (_hip.ViewLane * n_lanes)()
+                for k, st in enumerate(sts):
+                    isect = st["isect"]
+                    lanes[k] = _hip.ViewLane(st["ws"].data_ptr(), st["ws"].numel(),
+                                             None if isect is None else isect.data_ptr(),
+                                             0 if isect is None else isect.numel(), st["host"].data_ptr(),
+                                             st["ev"].cuda_event, streams[k].cuda_stream)
+                rc = L.ms_render_fwd_batch(C, N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(op),
+                                           _hip.ptr(colors), cdt, CD, _hip.ptr(vms), ctypes.cast(intr, ctypes.c_void_p),
+                                           W, H, EPS2D, near, far, tile_size, _hip.ptr(bg), n_lanes, lanes, 0,
+                                           _hip.ptr(out), ctypes.cast(counts, ctypes.c_void_p), ctypes.byref(done),
+                                           ctypes.byref(need), ctypes.byref(lane_i))
+                if rc == 2 and need.value > 0:   # MS_ERR_WORKSPACE: that lane's intersection buffer is too small
+                    _grow(sts[lane_i.value], "isect", need.value, dev, slack=1.25)
+                    continue
+                _hip.check(rc, "ms_render_fwd_batch")
+                break
+    for s_ in streams[:n_lanes]:
+        cur.wait_stream(s_)
+    for t in (out, means3d, scales, quats, op, colors, vms) + (() if bg is None else (bg,)):
+        for s_ in streams[:n_lanes]:
+            t.record_stream(s_)
+    return out, [int(c) for c in counts]
 
 
 _lanes = {}

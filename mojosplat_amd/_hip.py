@@ -70,6 +70,20 @@ _SIGNATURES = {
                                          c_void_p, c_void_p]),
 }
 
+
+
+class ViewLane(ctypes.Structure):
+    """ms_view_lane (include/mojosplat_hip.h): one scratch set of ms_render_fwd_batch."""
+    _fields_ = [("workspace", c_void_p), ("workspace_bytes", c_size_t), ("isect_buf", c_void_p),
+                ("isect_bytes", c_size_t), ("host_info", c_void_p), ("sync_event", c_void_p), ("stream", c_void_p)]
+
+
+_SIGNATURES["ms_render_fwd_batch"] = (c_int, [c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float,
+                                              c_int, c_void_p, c_int, ctypes.POINTER(ViewLane), c_int, c_void_p,
+                                              c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t),
+                                              ctypes.POINTER(c_int)])
+
 # entry points added after ABI v1's first cut; bound when present
 _OPTIONAL = {}
 

@@ -348,3 +348,77 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                            backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info, resume,
                            render_colors, render_alphas, last_ids, stage_events, sync_event, stream_);
 }
+
+
+// Camera batch: n_lanes views in flight (begin view v + 1 before finishing view v).  See the header.
+extern "C" int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *scales, int scales_are_log,
+                                   const float *quats, const float *opacities, const void *colors, int color_dtype,
+                                   int CDIM, const float *viewmats, const float *intrinsics, int W, int H,
+                                   float eps2d, float near_plane, float far_plane, int tile_size,
+                                   const float *backgrounds, int n_lanes, const ms_view_lane *lanes, int flags,
+                                   float *render_colors, int64_t *counts, int *views_done,
+                                   size_t *need_isect_bytes, int *need_lane) {
+    MS_REQUIRE(C >= 0 && n_lanes >= 1 && n_lanes <= 4 && lanes && views_done && need_isect_bytes && need_lane,
+               MS_ERR_INVALID_ARG, "render_fwd_batch: bad batch / lane arguments");
+    MS_REQUIRE(C == 0 || (viewmats && intrinsics && render_colors), MS_ERR_INVALID_ARG, "render_fwd_batch: null pointer");
+    MS_REQUIRE(*views_done >= 0 && *views_done <= C, MS_ERR_INVALID_ARG, "render_fwd_batch: views_done out of range");
+    MS_REQUIRE(W > 0 && H > 0 && tile_size > 0 && CDIM >= 1, MS_ERR_INVALID_ARG, "render_fwd_batch: bad sizes");
+    for (int l = 0; l < n_lanes; ++l)
+        MS_REQUIRE(lanes[l].workspace && lanes[l].host_info, MS_ERR_INVALID_ARG, "render_fwd_batch: lane %d lacks scratch", l);
+    const int th = (H + tile_size - 1) / tile_size;
+    const size_t view_floats = (size_t)H * W * CDIM;
+    const int mode = flags & (MS_RENDER_FULL_SORT | (3 * MS_RENDER_FRONT_LEVEL));
+    auto call = [&](int v, int phase) {
+        const ms_view_lane &L = lanes[v % n_lanes];
+        const float *K = intrinsics + 4 * (size_t)v;
+        return ms_render_fwd(N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM,
+                             viewmats + 16 * (size_t)v, K[0], K[1], K[2], K[3], W, H, eps2d, near_plane, far_plane,
+                             tile_size, 0, th, backgrounds, L.workspace, L.workspace_bytes, L.isect_buf, L.isect_bytes,
+                             L.host_info, phase | mode, render_colors + view_floats * (size_t)v, nullptr, nullptr, nullptr,
+                             L.sync_event, L.stream);
+    };
+    int pending[4] = {-1, -1, -1, -1};
+    int first_fail = -1, fail_rc = MS_OK;
+    size_t fail_need = 0;
+    auto finish = [&](int lane) {
+        const int u = pending[lane];
+        if (u < 0) return;
+        pending[lane] = -1;
+        const int rc = call(u, MS_RENDER_FINISH);
+        if (rc == MS_OK) {
+            if (counts) counts[u] = lanes[lane].host_info[0];
+        } else if (first_fail < 0 || u < first_fail) {
+            first_fail = u;
+            fail_rc = rc;
+            fail_need = rc == MS_ERR_WORKSPACE ? (size_t)lanes[lane].host_info[5] : 0;
+        }
+    };
+    for (int v = *views_done; v < C && first_fail < 0; ++v) {
+        const int lane = v % n_lanes;
+        finish(lane);                       // the view this lane rendered n_lanes views ago
+        if (first_fail >= 0) break;
+        const int rc = call(v, MS_RENDER_BEGIN);
+        if (rc != MS_OK) {
+            first_fail = v;
+            fail_rc = rc;
+            break;
+        }
+        pending[lane] = v;
+    }
+    // drain, oldest view first, so that nothing is in flight when the call returns
+    for (;;) {
+        int lane = -1;
+        for (int l = 0; l < n_lanes; ++l)
+            if (pending[l] >= 0 && (lane < 0 || pending[l] < pending[lane])) lane = l;
+        if (lane < 0) break;
+        finish(lane);
+    }
+    if (first_fail >= 0) {
+        *views_done = first_fail;
+        *need_lane = first_fail % n_lanes;
+        *need_isect_bytes = fail_need;
+        return fail_rc;
+    }
+    *views_done = C;
+    return MS_OK;
+}

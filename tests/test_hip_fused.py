@@ -322,7 +322,7 @@ def test_random_row_bands_fuzz_against_stagewise(device, seed):
     framebuffer, twice (exact, then sync-free): the per-stage frame, bit for bit."""
     g = torch.Generator().manual_seed(7000 + seed)
     r = lambda lo, hi: lo + (hi - lo) * torch.rand(1, generator=g).item()
-    N = int(10 ** r(3.0, 5.0))
+    N = int(10 ** r(3.0, 5.3))     # (>= 32 768 Gaussians: bands under 60 % of the rows are pre-culled)
     W, H = int(r(100, 800)), int(r(260, 900))
     sc, cam = randscene_v1(N, W, H, ell=r(-4.0, -2.0), seed=100 + seed, device=device)
     sc["opacities"] = (sc["opacities"] * r(0.05, 1.0)).clamp(max=1.0)
@@ -334,10 +334,12 @@ def test_random_row_bands_fuzz_against_stagewise(device, seed):
     bands = list(zip(cuts[:-1], cuts[1:]))
     args = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     frame = torch.full((H, W, 3), -1.0, device=device)
+    # the bands keep their 16-px rows; the bins under them are 16 (split / plain), 32 or 64 px (MS_RENDER_ROWS16)
+    ts = [16, 16, 32, 64][seed % 4]
     for _ in range(2):
         for band in bands:
-            _fused.render_fwd_hip(*args, cam, bg, 16, row_range=band, out=frame)
-        assert torch.equal(frame, want), (N, W, H, bands)
+            _fused.render_fwd_hip(*args, cam, bg, ts, row_range=band, out=frame, rows16=True)
+        assert torch.equal(frame, want), (N, W, H, bands, ts)
     _fused._state.clear()
 
 

@@ -222,3 +222,23 @@ def test_bin_rule_on_the_baseline_configs():
         assert R.bin_rule(mode, int(n * p_at(R._D_SPLIT * 1.02, g)), n, W, H) == mode
         assert R.bin_rule(mode, int(n * p_at(R._D_SPLIT * 0.98, g)), n, W, H) == mode
     assert R.bin_rule(16, 0, 0, W, H) == 16 and R.bin_rule(64, 0, 5, W, H) == 64    # empty frames decide nothing
+
+
+def test_render_fwd_batch_argument_checks_without_a_gpu():
+    """ms_render_fwd_batch (the camera-batch entry point, reference kernels/projection.mojo:32-37) validates its
+    host-side arguments before it touches a device: callable on a box with no GPU."""
+    import ctypes
+    L = _hip.load()
+    done, need, lane = ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_int(0)
+    lanes = (_hip.ViewLane * 2)()
+    args = lambda C, n_lanes, lanes_p, d: (C, 10, None, None, 1, None, None, None, 0, 3, None, None, 64, 64, 0.3, 0.1, 100.0,
+                                           16, None, n_lanes, lanes_p, 0, None, None, ctypes.byref(d), ctypes.byref(need),
+                                           ctypes.byref(lane))
+    err = lambda: L.ms_last_error_string().decode()
+    assert L.ms_render_fwd_batch(*args(2, 0, lanes, done)) == 1 and "lane" in err()          # n_lanes out of 1..4
+    assert L.ms_render_fwd_batch(*args(2, 2, lanes, done)) == 1 and "null pointer" in err()   # no view matrices
+    bad = ctypes.c_int(5)
+    assert L.ms_render_fwd_batch(*args(0, 1, lanes, bad)) == 1 and "views_done" in err()
+    ok = ctypes.c_int(0)
+    one = (_hip.ViewLane * 1)()
+    assert L.ms_render_fwd_batch(*args(0, 1, one, ok)) == 1 and "lacks scratch" in err()      # lanes without buffers
