@@ -35,27 +35,30 @@ _STAGE_HOOK = None
 # The frame does not depend on the grid the Gaussians are binned on: a pixel blends the same Gaussians
 # in the same order whatever the bins, and the rasteriser works in 16x16 blocks inside any tile
 # (bit-identical for every mode below at every BASELINE config; tests/test_hip_fused.py,
-# tests/test_hip_configs.py).  What the grid moves is cost, by up to 2x either way
-# (profiles/r01_bin_modes.txt, ms per frame at split / 32 / 64):
+# tests/test_hip_configs.py).  What the grid moves is cost, by up to 2x either way.  Measured with round 2's
+# rasteriser (profiles/r02_bin_modes.txt, ms per frame at split / 32 / 64; scripts/scene_scan.py for the rest):
 #   16  the library's default for 16-px tiles: 32-px bins whose sorted lists are cut into per-block
-#       lists (a "split" frame) -- best while footprints are small against a bin (config 3: 0.26 /
-#       0.31 / 0.62; config 2: 0.12 / 0.15 / 0.28);
-#   32 / 64  plain coarse bins, every block walks its bin's whole list -- best once footprints span
-#       several blocks (the block lists of a split frame then hold four copies of everything:
-#       100k Gaussians at l = -3: 0.34 / 0.19 / 0.22) and, the denser the scene, the coarser (lazily
-#       sorted lists are only read ~300-450 entries deep, so binning cost = pairs scattered: config 5
-#       1.18 / 1.08 / 0.77; 1M at l = -3: 0.31 / 0.28 / 0.24; config 4 0.69 / 0.64 / 0.66).
+#       lists (a "split" frame) -- best only while footprints are small against a BLOCK (1M Gaussians at
+#       l = -5, footprint 6 px: 0.22 / 0.32 / 1.05), where a 32-px bin's list would be mostly misses for the
+#       8x8 quad that stages it;
+#   32  plain 32-px bins, every quad's wave walks its bin's list -- best for footprints of 9-17 px now that
+#       staging is three 16-byte gathers per entry (config 3: 0.222 / 0.201 / 0.273; config 2: 0.109 / 0.101 /
+#       0.134; config 4: 0.569 / 0.528 / 0.526; round 1's rasteriser, whose staging was seven gathers plus
+#       arithmetic, still preferred the split frame there: 0.262 / 0.305);
+#   64  plain 64-px bins -- best once footprints span several blocks (100k at l = -3: 0.172 / 0.146 / 0.136;
+#       1M at l = -3: 0.286 / 0.238 / 0.192; config 5: 1.09 / 0.91 / 0.68; 1M at l = -3.5, 20 px: 0.245 / 0.206 /
+#       0.187): lazily sorted lists are only read ~300-450 entries deep, so binning cost = pairs scattered.
 # The choice is a RULE on two statistics every frame's size record already carries -- no timing, no
 # synchronisation, same answer for the same sequence of scenes: with M pairs on a g-px grid and n
 # Gaussians on the grid, p = M / n pairs per Gaussian give the mean footprint diameter
-# d = g (sqrt(p) - 1) px and the density e = n (d / 16 + 1)^2 / T16 entries per 16-px tile;
-#   d < 24 px:  split frame (32 px when e > 2000);   d >= 24 px:  64 px when e > 600, else 32 px.
+# d = g (sqrt(p) - 1) px (the same within 2 % whichever grid the frame ran on):
+#   d < 9 px: split frame;   9 <= d < 17 px: 32 px;   d >= 17 px: 64 px.
 # A frame is binned by the rule applied to the PREVIOUS frame of the same (device, N class, image
 # size); the first one is a split frame.  Thresholds carry a +-10 % dead band so that a scene sitting
 # on one does not flip every frame.  `bin_size=` (or MOJOSPLAT_BIN_PX) overrides the rule;
 # `tune_binning()` measures instead, for callers who want that.
 _BIN_MODES = (16, 32, 64)
-_D_SPLIT, _E_SPLIT_DENSE, _E_COARSE = 24.0, 2000.0, 600.0
+_D_SPLIT, _D_COARSE = 9.0, 17.0
 _DEAD_BAND = 0.10
 _MIN_SETTLED = 64
 _bin_mode = {}            # (device, N to ~9 %, W, H) -> bin px of the next frame
@@ -65,8 +68,8 @@ _bin_lock = threading.Lock()
 
 def _rule(d, e, k=1.0):
     if d < _D_SPLIT * k:
-        return 32 if e > _E_SPLIT_DENSE * k else 16
-    return 64 if e > _E_COARSE * k else 32
+        return 16
+    return 32 if d < _D_COARSE * k else 64
 
 
 def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int, band: bool = False, grid_px: Optional[int] = None) -> int:
@@ -216,7 +219,10 @@ def render_gaussians(
             img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, mode,
                                     stage_events=evs, info=info)
             if key is not None:
-                _settle(key, mode, bin_rule(mode, m, info["on_grid"], camera.W, camera.H))
+                # (a frame at mode 16 is a split frame -- 32-px bins, flag bit 3 -- unless its lane has fallen back
+                # to fully sorted 16-px tiles: then the pairs were counted on those)
+                grid = (32 if info["flags"] & 8 else 16) if mode == TILE_SIZE else mode
+                _settle(key, mode, bin_rule(mode, m, info["on_grid"], camera.W, camera.H, grid_px=grid))
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer

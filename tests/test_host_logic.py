@@ -195,33 +195,41 @@ def test_c_abi_argument_validation_returns_status_codes():
 
 
 def test_bin_rule_on_the_baseline_configs():
-    """render.py's binning-granularity rule: footprint diameter and density estimated from a frame's
-    size record (pairs M on the grid it ran on, Gaussians on the grid) pick split / 32 / 64 px.  The
-    records below are the measured ones of profiles/r01_bin_modes.txt (M per mode; on-grid counts from
-    the scenes), with the mode that was fastest on the GPU."""
+    """render.py's binning-granularity rule: the footprint diameter estimated from a frame's size record
+    (pairs M on the grid it ran on, Gaussians on the grid) picks split / 32 / 64 px.  The records below are
+    measured ones (profiles/r02_bin_modes.txt: M per mode; on-grid counts from the scenes), with the mode that
+    was fastest on the GPU with round 2's rasteriser."""
     from mojosplat_amd import render as R
     W, H = 1920, 1080
     cases = {   # name: (on_grid, {mode: M}, W, H, fastest)
-        "cfg2": (95_000, {16: 195_694, 32: 195_858, 64: 140_298}, W, H, 16),
-        "cfg3": (950_000, {16: 1_966_222, 32: 1_967_590, 64: 1_406_830}, W, H, 16),
-        "cfg2-heavy": (95_000, {16: 472_816, 32: 473_006, 64: 245_133}, W, H, 32),
-        "cfg3-heavy": (950_000, {16: 4_763_542, 32: 4_765_457, 64: 2_463_575}, W, H, 64),
-        "cfg5": (4_700_000, {16: 17_106_998, 32: 17_119_671, 64: 9_899_012}, 3840, 2160, 64),
+        "cfg2": (95_000, {16: 195_694, 32: 195_858, 64: 140_298}, W, H, 32),            # 0.109 / 0.101 / 0.134 ms
+        "cfg3": (950_000, {16: 1_966_222, 32: 1_967_590, 64: 1_406_830}, W, H, 32),     # 0.222 / 0.201 / 0.273
+        "cfg4": (5_700_000, {16: 10_933_155, 32: 10_942_475, 64: 8_128_726}, 1600, 1063, 32),   # 0.569 / 0.528 / 0.526
+        "cfg2-heavy": (95_000, {16: 472_816, 32: 473_006, 64: 245_133}, W, H, 64),      # 0.172 / 0.146 / 0.136
+        "cfg3-heavy": (950_000, {16: 4_763_542, 32: 4_765_457, 64: 2_463_575}, W, H, 64),   # 0.286 / 0.238 / 0.192
+        "cfg5": (4_700_000, {16: 17_106_998, 32: 17_119_671, 64: 9_899_012}, 3840, 2160, 64),   # 1.09 / 0.91 / 0.68
     }
     for name, (n, ms_, w, h, best) in cases.items():
         for mode, m in ms_.items():       # whatever grid the previous frame ran on, the verdict is the same
             assert R.bin_rule(mode, m, n, w, h) == best, (name, mode)
-    # config 4 (small footprints, 2700 entries per tile): 32 px from a split frame's record; 0.64 vs 0.66 ms
-    # at 64 px, so a record taken at 64 px may keep 64
-    assert R.bin_rule(16, 10_933_155, 5_700_000, 1600, 1063) == 32
-    assert R.bin_rule(64, 8_128_726, 5_700_000, 1600, 1063) in (32, 64)
-    # dead band: a scene sitting on a threshold keeps the mode it has
-    n, T = 100_000, 120 * 68
+    # tiny footprints (1M Gaussians at l = -5: 6 px): the split frame (0.22 / 0.32 / 1.05 ms)
+    n = 900_000
     p_at = lambda d, g: (d / g + 1.0) ** 2
-    for mode, g in ((16, 32), (32, 32)):
-        assert R.bin_rule(mode, int(n * p_at(R._D_SPLIT * 1.02, g)), n, W, H) == mode
-        assert R.bin_rule(mode, int(n * p_at(R._D_SPLIT * 0.98, g)), n, W, H) == mode
+    assert R.bin_rule(16, int(n * p_at(6.0, 32)), n, W, H) == 16 and R.bin_rule(32, int(n * p_at(6.0, 32)), n, W, H) == 16
+    # dead band: a scene sitting on a threshold keeps the mode it has
+    for thr, modes in ((R._D_SPLIT, (16, 32)), (R._D_COARSE, (32, 64))):
+        for mode in modes:
+            g = 32 if mode == 16 else mode
+            assert R.bin_rule(mode, int(n * p_at(thr * 1.02, g)), n, W, H) == mode
+            assert R.bin_rule(mode, int(n * p_at(thr * 0.98, g)), n, W, H) == mode
     assert R.bin_rule(16, 0, 0, W, H) == 16 and R.bin_rule(64, 0, 5, W, H) == 64    # empty frames decide nothing
+    # a rank's band (multi-GPU): its Gaussians lie only partly inside; the band-aware estimate undoes that
+    # (config 5, 17-row band of 272 px: footprints of 29 px -> 64-px bins, as for the whole frame)
+    h, d, g = 272.0, 29.0, 32
+    n_band = 600_000
+    m_band = int(n_band * p_at(d, g) * h / (h + d + g))
+    assert R.bin_rule(16, m_band, n_band, 3840, int(h), band=True) == 64
+    assert R.bin_rule(16, m_band, n_band, 3840, int(h), band=True, grid_px=32) == 64
 
 
 def test_render_fwd_batch_argument_checks_without_a_gpu():
