@@ -11,6 +11,8 @@
 // ds_bpermute), waves whose quad cannot see the Gaussian skip it on a ballot, the four waves
 // of a block meet in an LDS accumulator, and ONE global float atomic per (tile, Gaussian,
 // component) leaves the CU at the end of each 256-intersection batch.
+#include <stdlib.h>
+
 #include "ms_common.hpp"
 
 namespace {
@@ -194,8 +196,47 @@ constexpr int kRow = 16;  // floats per packed gradient row: mx my ca cb cc op c
 struct RasterBwd2Args {
     RasterBwdArgs a;
     float *packed;  // f32[N][kRow], zeroed by the caller of the kernel
+    const int32_t *order;   // blocks, heaviest list first (k_bwd_order), or null: image order
     int nblocks, n_gauss;
 };
+
+// Launch order of the blocks: heaviest list first (counting sort of the tiles over 128 length buckets, 4 per
+// octave; one workgroup).  The backward walks every block's list as deep as its pixels blended, in waves that
+// hold 90 VGPRs (5 per SIMD, 5 120 slots for >= 8 160 waves): in image order the heavy centre tiles that start
+// late finish alone.  Round 2 measured the same effect on the forward kernel (profiles/r02_raster_waves.md).
+__global__ __launch_bounds__(1024) void k_bwd_order(int n_tiles, int nsub, const int32_t *__restrict__ tile_ranges,
+                                                     int32_t *__restrict__ order) {
+    __shared__ unsigned int s_bkt[128], s_base[128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto bucket_of = [](unsigned int c) -> int {
+        if (c == 0) return 0;
+        const int l = 31 - __clz((int)c);
+        const int frac = l >= 2 ? (int)((c >> (l - 2)) & 3u) : (int)((c << (2 - l)) & 3u);
+        return 1 + 4 * l + frac;
+    };
+    if (threadIdx.x < 128) s_bkt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += 1024)
+        atomicAdd(&s_bkt[bucket_of((unsigned)max(tile_ranges[2 * t + 1] - tile_ranges[2 * t], 0))], 1u);
+    __syncthreads();
+    if (w == 0) {   // s_base[b] = tiles in heavier buckets
+        const unsigned int c0 = s_bkt[127 - 2 * lane], c1 = s_bkt[126 - 2 * lane];
+        unsigned int incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int o = (unsigned int)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        const unsigned int excl = incl - (c0 + c1);
+        s_base[127 - 2 * lane] = excl;
+        s_base[126 - 2 * lane] = excl + c0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += 1024) {
+        const unsigned int slot = atomicAdd(&s_base[bucket_of((unsigned)max(tile_ranges[2 * t + 1] - tile_ranges[2 * t], 0))], 1u);
+        for (int s_ = 0; s_ < nsub; ++s_) order[slot * nsub + s_] = t * nsub + s_;
+    }
+}
 
 __device__ __forceinline__ void wave_lds_sync_bwd() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -235,17 +276,29 @@ __device__ __forceinline__ float wave_allreduce8(const float (&v)[8], int lane) 
     return y;
 }
 
-template <int CP>
+// NQ = quads per wave: 4 = one wave per 16x16 block; 2 = two waves per block (upper / lower strip; each stages the
+// list but blends only its quads): the longest wave's work halves and twice as many waves fill the slots.
+template <int CP, int NQ>
 __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
     const RasterBwdArgs &A = B2.a;
     constexpr int NG = 6 + CP;
+    constexpr int kParts = 4 / NQ;
     constexpr float kLog2e = 1.4426950408889634f;
     __shared__ float4 s_a[64];       // mean.x, mean.y, a', b'   (conic pre-scaled by -log2e/2, -log2e)
     __shared__ float4 s_b[64];       // c', opacity, colour0, colour1
     __shared__ float4 s_c[64];       // colour2, colour3, Gaussian id (bits), -
     __shared__ float s_grad[64 * kRow];
 
-    const int item = blockIdx.x;
+    // the kParts waves of a block sit 8 blockIdx apart (dealt round-robin over the 8 XCDs: one XCD, shared L2)
+    int wg = blockIdx.x, part = 0;
+    if constexpr (kParts > 1) {
+        const int j = blockIdx.x >> 3;
+        part = j % kParts;
+        wg = ((j / kParts) << 3) | (blockIdx.x & 7);
+        if (wg >= B2.nblocks) return;
+    }
+    const int qbase = part * NQ;
+    const int item = B2.order ? B2.order[wg] : wg;
     const int tile = item / A.nsub, sub = item - tile * A.nsub;
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
@@ -257,13 +310,14 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
     const int start = A.tile_ranges[2 * tile], end = A.tile_ranges[2 * tile + 1];
     if (end <= start) return;
 
-    float T[4], tb[4], v_out[4][CP], buf[4][CP];
-    int binf[4], qmax[4];
+    float T[NQ], tb[NQ], v_out[NQ][CP], buf[NQ][CP];
+    int binf[NQ], qmax[NQ];
     int wave_final = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int X = bx + lx + (q & 1) * 8, Y = by + ly + (q >> 1) * 8;
-        const bool in = (ox + (q & 1) * 8) < A.ts && (oy + (q >> 1) * 8) < A.ts && X < A.W && Y < A.H;
+    for (int q = 0; q < NQ; ++q) {
+        const int qq = qbase + q;
+        const int X = bx + lx + (qq & 1) * 8, Y = by + ly + (qq >> 1) * 8;
+        const bool in = (ox + (qq & 1) * 8) < A.ts && (oy + (qq >> 1) * 8) < A.ts && X < A.W && Y < A.H;
         const size_t p = in ? (size_t)Y * A.W + X : 0;
         const float T_final = in ? 1.0f - A.render_alphas[p] : 1.0f;
         T[q] = T_final;
@@ -305,9 +359,10 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
                     const float smax = __logf(op * 255.0f) * 1.0001f + 1e-4f;
                     const float nb_c = -cb * __builtin_amdgcn_rcpf(cc), nb_a = -cb * __builtin_amdgcn_rcpf(ca);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float xl = fbx + (float)((q & 1) * 8) - mx, xh = xl + 7.0f;
-                        const float yl = fby + (float)((q >> 1) * 8) - my, yh = yl + 7.0f;
+                    for (int q = 0; q < NQ; ++q) {
+                        const int qq = qbase + q;
+                        const float xl = fbx + (float)((qq & 1) * 8) - mx, xh = xl + 7.0f;
+                        const float yl = fby + (float)((qq >> 1) * 8) - my, yh = yl + 7.0f;
                         const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
                         float best = (in_x && in_y) ? 0.f : 3.0e38f;
                         if (!in_x) {
@@ -327,9 +382,9 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
                 }
             }
         }
-        unsigned long long Bq[4], U = 0ull;
+        unsigned long long Bq[NQ], U = 0ull;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             Bq[q] = __ballot((mask >> q) & 1);
             // entries behind the last one any pixel of this quad blended cannot matter to it
             const int lim = qmax[q] - b0;
@@ -358,9 +413,10 @@ __global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
             for (int j = 0; j < NG; ++j) acc[j] = 0.f;
             unsigned long long anyv = 0ull;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (!((Bq[q] >> t) & 1ull)) continue;  // wave-uniform
-                const float dx = ra.x - (px0 + (float)((q & 1) * 8)), dy = ra.y - (py0 + (float)((q >> 1) * 8));
+                const int qq = qbase + q;
+                const float dx = ra.x - (px0 + (float)((qq & 1) * 8)), dy = ra.y - (py0 + (float)((qq >> 1) * 8));
                 const float lp = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), rb.x * dy * dy);  // -sigma*log2(e)
                 const float vis = __builtin_amdgcn_exp2f(lp);
                 const float ov = rb.y * vis;
@@ -502,8 +558,32 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
         B2.nblocks = (int)blocks;
         B2.n_gauss = (int)N;
         MS_HIP(hipMemsetAsync(workspace, 0, packed_bytes, st));
-        if (CDIM <= 3) hipLaunchKernelGGL(k_rasterize_bwd_v2<3>, grid, dim3(64), 0, st, B2);
-        else hipLaunchKernelGGL(k_rasterize_bwd_v2<4>, grid, dim3(64), 0, st, B2);
+        // heaviest blocks first when the workspace has room for the order (ms_rasterize_bwd_workspace_bytes
+        // reserves it); two waves per block while the launch is a few rounds at most
+        B2.order = nullptr;
+        const size_t order_off = ms::align_up(packed_bytes, 256);
+        if (workspace_bytes >= order_off + (size_t)blocks * sizeof(int32_t)) {
+            int32_t *order = (int32_t *)((char *)workspace + order_off);
+            hipLaunchKernelGGL(k_bwd_order, dim3(1), dim3(1024), 0, st, A.tw * th, A.nsub, tile_ranges, order);
+            MS_LAUNCH_CHECK();
+            B2.order = order;
+        }
+        // waves per block: ONE (measured at config 3, forward + backward step, with the heaviest-first order:
+        // 1 wave 0.698 ms, 2 waves 0.732, 4 waves 0.832 -- each wave stages the list from four arrays and the
+        // per-entry reduction + flush does not shrink with the quads; without the order 1 wave: 0.779).
+        // MOJOSPLAT_BWD_PARTS=1|2|4 pins it (measurements).
+        static const int forced = [] { const char *e = getenv("MOJOSPLAT_BWD_PARTS"); const int n = e ? atoi(e) : 0; return (n == 1 || n == 2 || n == 4) ? n : 0; }();
+        const int parts = forced ? forced : 1;
+        const dim3 grid2((unsigned)(parts > 1 ? ((blocks + 7) / 8) * 8 * parts : blocks));
+#define MS_LAUNCH_BWD(CPV)                                                                              \
+    do {                                                                                                 \
+        if (parts == 4) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 1>), grid2, dim3(64), 0, st, B2);      \
+        else if (parts == 2) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 2>), grid2, dim3(64), 0, st, B2); \
+        else hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 4>), grid2, dim3(64), 0, st, B2);                 \
+    } while (0)
+        if (CDIM <= 3) MS_LAUNCH_BWD(3);
+        else MS_LAUNCH_BWD(4);
+#undef MS_LAUNCH_BWD
         MS_LAUNCH_CHECK();
         if (overwrite)
             hipLaunchKernelGGL(k_unpack_grads<true>, dim3((unsigned)ms::ceil_div(N, 256)), dim3(256), 0, st, N, CDIM,
@@ -523,6 +603,7 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     return MS_OK;
 }
 
+// packed gradient rows + room for the launch order of up to 2^18 blocks (any frame up to 8K x 8K at 16-px tiles)
 extern "C" size_t ms_rasterize_bwd_workspace_bytes(int64_t N, int CDIM) {
-    return (CDIM >= 1 && CDIM <= 4 && N > 0) ? (size_t)N * kRow * sizeof(float) : 0;
+    return (CDIM >= 1 && CDIM <= 4 && N > 0) ? ms::align_up((size_t)N * kRow * sizeof(float), 256) + ((size_t)4 << 18) : 0;
 }
