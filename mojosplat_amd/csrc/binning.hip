@@ -38,6 +38,9 @@
 
 namespace {
 
+#ifndef MS_CHUNK
+#define MS_CHUNK 2048
+#endif
 constexpr int kHistThreads = 1024;
 constexpr int kMaxG = 512;
 constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
@@ -1335,7 +1338,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.T = tw * th;
     p.T_local = (row_end - row_begin) * tw;
     p.lds_bytes = (size_t)p.T_local * 4 + 16;  // + the on-grid counter of the count kernels
-    int64_t G = ms::ceil_div(N > 0 ? N : 1, 2048);
+    int64_t G = ms::ceil_div(N > 0 ? N : 1, MS_CHUNK);
     G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
     if (p.lds_bytes > 64 * 1024 && G > 256) G = 256;
     p.chunk = ms::ceil_div(N > 0 ? N : 1, G);
