@@ -29,6 +29,7 @@
 //                     their entry and whose sorted lists leave the sort kernels as four 16x16-block
 //                     lists (emit_block_lists)
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -1653,7 +1654,10 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             // split frames (bl): 1280 of a 32-px bin's nearest entries saturate its four blocks on the BASELINE
             // scenes (1024: one bin of config 3 falls short; 2048: +9 us).  A caller that saw the clean-up pass
             // run asks for deeper fronts (lazy bits 1-2: front level, x2 each, up to the LDS room).
-            int front_k = bl.block_ids ? 1280 : min(kFrontK * blocks_per_tile, 2048);
+            static const int front_env = [] { const char *e = getenv("MOJOSPLAT_FRONT_K"); return e ? atoi(e) : 0; }();
+            // plain 32-px bins: 1536 (config 3: 2048 costs +5 us per frame, 1024 sends one bin to the clean-up pass)
+            int front_k = bl.block_ids ? 1280 : blocks_per_tile == 4 ? 1536 : min(kFrontK * blocks_per_tile, 2048);
+            if (front_env >= 256 && front_env <= kFrontCap && blocks_per_tile > 1) front_k = front_env;   // (measurements)
             front_k = min(front_k << ((lazy >> 1) & 3), kFrontCap);   // (3072: 1-3 % slower, no fewer clean-ups on the BASELINE scenes)
             hipLaunchKernelGGL(front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
