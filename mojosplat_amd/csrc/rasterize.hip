@@ -129,13 +129,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 constexpr int kGroup = MS_RASTER_GROUP;   // records evaluated per trip of the blend loop
 
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool SOLO>
-__global__ __launch_bounds__(SOLO ? 64 : 64 * (4 / NQ), (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasterize_fwd(RasterArgs A) {
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
+__global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasterize_fwd(RasterArgs A) {
     static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
-    // SOLO: every wave is a workgroup of its own (wave slots refill one by one instead of four at a time); the
-    // 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16, ...: dealt round-robin over the 8 XCDs, they land
-    // on ONE XCD back to back and share its L2 for the list they all stage (speed only, never correctness)
-    constexpr int WPB = SOLO ? 1 : 4 / NQ;
+    // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
+    // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
+    // ...: dealt round-robin over the 8 XCDs, they land on ONE XCD back to back and share its L2 for the list they
+    // all stage (speed only, never correctness)
+    constexpr int WPB = 1;
     constexpr int kParts = 4 / NQ;
     constexpr int CS = (CP == 3) ? 4 : CP;       // CP == 3: r, g ride in the second word; blue heads a third 16-byte word
     constexpr int kSlots = kBatch + kGroup;      // room for the neutral records that pad a list to a multiple of kGroup
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(SOLO ? 64 : 64 * (4 / NQ), (CP <= 4 ? MS_RASTER_MIN
     __shared__ Stage s_stage[WPB][NQ];
     const int wib = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wg = blockIdx.x, part = wib;   // workgroup index in units of blocks, and which of the block's waves this is
-    if constexpr (SOLO && kParts > 1) {
+    if constexpr (kParts > 1) {
         const int j = blockIdx.x >> 3;
         part = j % kParts;
         wg = ((j / kParts) << 3) | (blockIdx.x & 7);
@@ -707,28 +708,18 @@ static int raster_parts_override() {
 
 static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 64 ? A.lazy.redo_grid : 64); }
 
-// MOJOSPLAT_RASTER_SOLO=0: the waves of a block share a workgroup (one CU) instead of being workgroups of their own
-static bool raster_solo() {
-    static const bool v = [] {
-        const char *e = getenv("MOJOSPLAT_RASTER_SOLO");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return v;
-}
-
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
     const bool aux = A.render_alphas || A.last_ids;
-    const bool solo = raster_solo() && A.parts > 1;
-    // solo: parts single-wave workgroups per block, the block count rounded up to the 8 XCDs
-    const dim3 grid(solo ? (unsigned)(((A.nblocks + 7) / 8) * 8 * A.parts) : (unsigned)A.nblocks);
-#define MS_LAUNCH_RASTER(AUXV, NQV, PK, SOLOV) \
-    hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, NQV, PK, SOLOV>), grid, dim3(SOLOV ? 64 : 64 * (4 / NQV)), 0, stream, A)
-#define MS_LAUNCH_RASTER_NQ(AUXV, PK)                                             \
-    do {                                                                          \
-        if (A.parts == 2) { if (solo) MS_LAUNCH_RASTER(AUXV, 2, PK, true); else MS_LAUNCH_RASTER(AUXV, 2, PK, false); }      \
-        else if (A.parts == 4) { if (solo) MS_LAUNCH_RASTER(AUXV, 1, PK, true); else MS_LAUNCH_RASTER(AUXV, 1, PK, false); } \
-        else MS_LAUNCH_RASTER(AUXV, 4, PK, false);                                \
+    // parts single-wave workgroups per block, the block count rounded up to the 8 XCDs
+    const dim3 grid(A.parts > 1 ? (unsigned)(((A.nblocks + 7) / 8) * 8 * A.parts) : (unsigned)A.nblocks);
+#define MS_LAUNCH_RASTER(AUXV, NQV, PK) \
+    hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, NQV, PK>), grid, dim3(64), 0, stream, A)
+#define MS_LAUNCH_RASTER_NQ(AUXV, PK)                          \
+    do {                                                       \
+        if (A.parts == 2) MS_LAUNCH_RASTER(AUXV, 2, PK);       \
+        else if (A.parts == 4) MS_LAUNCH_RASTER(AUXV, 1, PK);  \
+        else MS_LAUNCH_RASTER(AUXV, 4, PK);                    \
     } while (0)
     bool done = false;
     if constexpr (CP == 3) {
