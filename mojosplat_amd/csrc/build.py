@@ -11,6 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "project.hip", "binning.hip", "rasterize.hip", "rasterize_bwd.hip",
            "project_bwd.hip", "pipeline.hip", "sh.hip"]
+# per-source flags.  rasterize.hip: fp32 denormals flushed -- its blend loop selects by underflow
+# (ms::kFlushK in ms_common.hpp; scripts/ubench/flush_select.hip)
+SOURCE_FLAGS = {"rasterize.hip": ["-fgpu-flush-denormals-to-zero"]}
 HEADERS = ["ms_common.hpp", os.path.join("..", "..", "include", "mojosplat_hip.h")]
 LIB = os.path.join(HERE, "libmojosplat_hip.so")
 ARCH = "gfx950"
@@ -45,7 +48,8 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     for src in _sources():
         obj = os.path.splitext(src)[0] + (f".{variant}.o" if variant else ".diag.o" if diag else ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"] + (["-DMS_DIAG"] if diag else []) + extra
+               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"] + SOURCE_FLAGS.get(os.path.basename(src), []) + \
+            (["-DMS_DIAG"] if diag else []) + extra
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
             print(" ".join(cmd))

@@ -34,6 +34,14 @@ void set_error(const char *fmt, ...);
 constexpr float kAlphaThreshold = 1.0f / 255.0f;
 constexpr float kMaxAlpha = 0.999f;
 constexpr float kTransmittanceStop = 1e-4f;
+// The forward rasteriser's select without a compare (rasterize.hip is compiled with fp32 denormals flushed):
+// kFlushK = 255 * 2^-126 is the smallest float k with fl(1/255) * k >= 2^-126, so alpha * k is a normal number
+// iff alpha >= fl(1/255) and +0 otherwise; kFlushKInv = fl(1 / k) scales a hit back to alpha (to an ulp).
+constexpr float kFlushK = 0x1.fep-119f;
+constexpr float kFlushKInv = 0x1.010102p+118f;
+static_assert((double)kAlphaThreshold * (double)kFlushK >= 0x1p-126 &&
+                  (double)(kAlphaThreshold * (1.0f - 0x1p-24f)) * (double)kFlushK < 0x1p-126,
+              "flush select: the threshold must sit exactly on the smallest normal number");
 
 // The rasteriser's staged record of one Gaussian (3 channels), as the fused frame's projection kernel
 // writes it once per Gaussian and as the rasteriser's own staging computes it from the per-stage arrays:

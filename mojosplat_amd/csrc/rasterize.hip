@@ -191,7 +191,9 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
     const float px0 = (float)(bx + lx) + 0.5f, py0 = (float)(by + ly) + 0.5f;
 
     constexpr float kInf = __builtin_huge_valf();
-    float T[NQ], thr[NQ], pix[NQ][CP];
+    // kq: the lane's multiplier of the flush select (ms::kFlushK while the pixel is live, 0 once it has stopped
+    // or when it lies outside the image: alpha * 0 = 0, so a finished pixel blends nothing and keeps its T)
+    float T[NQ], kq[NQ], pix[NQ][CP];
     int last[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
         const int X = bx + lx + (q & 1) * 8, Y = by + ly + (q >> 1) * 8;
         const bool in = (ox + (q & 1) * 8) < A.ts && (oy + (q >> 1) * 8) < A.ts && X < A.W && Y < A.H;
         T[qi] = 1.0f;
-        thr[qi] = in ? ms::kAlphaThreshold : kInf;
+        kq[qi] = in ? ms::kFlushK : 0.f;
         last[qi] = 0;
 #pragma unroll
         for (int k = 0; k < CP; ++k) pix[qi][k] = 0.f;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 const int q = qbase + qi;
-                if (!__any(thr[qi] < kInf)) continue;  // every pixel of this quad is finished (or outside)
+                if (!__any(kq[qi] != 0.f)) continue;  // every pixel of this quad is finished (or outside)
                 const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
                 const Stage &S = s_stage[wib][qi];
                 const int n = __popcll(B[qi]);
@@ -368,26 +370,52 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                             if constexpr (AUX) rt[j] = __float_as_int(rb[j].z);
                         }
                     }
-                    float la[kGroup], alpha[kGroup];
+                    // The select without a compare (v_cmp / v_cndmask issue at half the FMA rate on gfx950): this
+                    // file is compiled with fp32 denormals flushed, and alpha * (255 * 2^-126) is a normal number
+                    // iff alpha >= fl(1/255) -- bit for bit the reference's test (scripts/ubench/flush_select.hip
+                    // checks every float around the threshold) -- so (alpha * kq) * K is alpha to an ulp for a
+                    // hit on a live pixel and exactly 0 otherwise.
+                    float a_eff[kGroup], Tpre[kGroup];
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
                         const float dx = ra[j].x - px, dy = ra[j].y - py;
                         // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
-                        la[j] = fmaf(dx, fmaf(ra[j].z, dx, ra[j].w * dy), fmaf(rb[j].x * dy, dy, rb[j].y));
-                        alpha[j] = __builtin_amdgcn_exp2f(la[j]);
-                        if constexpr (CHECK) alpha[j] = fminf(ms::kMaxAlpha, alpha[j]);
+                        const float la = fmaf(dx, fmaf(ra[j].z, dx, ra[j].w * dy), fmaf(rb[j].x * dy, dy, rb[j].y));
+                        float alpha = __builtin_amdgcn_exp2f(la);
+                        if constexpr (CHECK) {
+                            alpha = fminf(ms::kMaxAlpha, alpha);
+                            alpha = la <= rb[j].y ? alpha : 0.f;                    // sigma >= 0
+                        }
+                        a_eff[j] = (alpha * kq[qi]) * ms::kFlushKInv;
                     }
+                    // T after each record of the group; T(1 - alpha) only shrinks along the group, so ONE test of
+                    // the last value tells whether any pixel stops inside it
+                    float t = T[qi];
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
                         MS_DIAG_ONLY(++diag_evals;)
-                        bool hit = alpha[j] >= thr[qi];                               // alpha >= 1/255, pixel live
-                        if constexpr (CHECK) hit = hit && la[j] <= rb[j].y;           // sigma >= 0
-                        const float next_T = fmaf(-alpha[j], T[qi], T[qi]);          // T (1 - alpha)
-                        const bool add = hit && next_T > ms::kTransmittanceStop;
-                        // one select (v_cmp / v_cndmask issue at half the FMA rate on gfx950, v_exp at a
-                        // quarter): alpha -> 0 for lanes that do not blend, then everything else is FMAs
-                        const float a_eff = add ? alpha[j] : 0.f;
-                        const float vis = a_eff * T[qi];
+                        Tpre[j] = t;
+                        t = fmaf(-a_eff[j], t, t);                                   // T (1 - alpha)
+                    }
+                    // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path, which
+                    // redoes the group's T chain with the stopping record (and what follows it) taken out.
+                    if (__ballot(!(t > ms::kTransmittanceStop))) {
+                        asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
+                        t = T[qi];
+                        bool dead = false;
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j) {
+                            const float nt = fmaf(-a_eff[j], t, t);
+                            dead = dead || !(nt > ms::kTransmittanceStop);
+                            a_eff[j] = dead ? 0.f : a_eff[j];
+                            Tpre[j] = t;
+                            t = dead ? t : nt;
+                        }
+                        kq[qi] = dead ? 0.f : kq[qi];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) {
+                        const float vis = a_eff[j] * Tpre[j];
                         if constexpr (CP == 3) {
                             pix[qi][0] += rb[j].z * vis;
                             pix[qi][1] += rb[j].w * vis;
@@ -396,16 +424,11 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
 #pragma unroll
                             for (int c = 0; c < CP; ++c) pix[qi][c] += rc[j][c] * vis;
                         }
-                        if constexpr (AUX) last[qi] = add ? b0 + rt[j] : last[qi];
-                        T[qi] = fmaf(-a_eff, T[qi], T[qi]);                          // next_T where blended, T elsewhere
-                        // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path.
-                        if (__ballot(hit && !add)) {
-                            asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
-                            thr[qi] = (hit && !add) ? kInf : thr[qi];
-                        }
+                        if constexpr (AUX) last[qi] = a_eff[j] != 0.f ? b0 + rt[j] : last[qi];
                     }
+                    T[qi] = t;
                 }
-                any_live = any_live || __any(thr[qi] < kInf);
+                any_live = any_live || __any(kq[qi] != 0.f);
             }
         };
         if (check_sigma) blend_batch(std::true_type{});
@@ -431,7 +454,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
     if (redo_tile >= 0) {
         bool alive = false;
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) alive = alive || __any(thr[qi] < kInf);
+        for (int qi = 0; qi < NQ; ++qi) alive = alive || __any(kq[qi] != 0.f);
         if (alive) {
             // pixels outlived the sorted front: the clean-up kernel redoes the whole tile (and
             // overwrites what is stored below); once per tile, whichever wave gets there first
@@ -506,7 +529,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
             const int X = tile_x * A.ts + ox, Y = tile_y * A.ts + oy;
             const bool in = ox < A.ts && oy < A.ts && X < A.W && Y < A.H;
             const float px = (float)X + 0.5f, py = (float)Y + 0.5f;
-            float T = 1.0f, thr = in ? ms::kAlphaThreshold : kInf, pix[CP];
+            float T = 1.0f, kq = in ? ms::kFlushK : 0.f, pix[CP];   // kq: k_rasterize_fwd's flush select
 #pragma unroll
             for (int k = 0; k < CP; ++k) pix[k] = 0.f;
             unsigned long long lower = 0ull;   // keys consumed so far are <= lower (exclusive bound once !first)
@@ -666,20 +689,22 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                         const float4 ra = s_pa[t], rb = s_pb[t];
                         const float dx = ra.x - px, dy = ra.y - py;
                         const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
-                        const float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
-                        const bool hit = alpha >= thr && la <= rb.y;
-                        const float next_T = fmaf(-alpha, T, T);
-                        const bool add = hit && next_T > ms::kTransmittanceStop;
-                        const float a_eff = add ? alpha : 0.f;
+                        // k_rasterize_fwd's generic (CHECK) arithmetic, operation for operation
+                        float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
+                        alpha = la <= rb.y ? alpha : 0.f;
+                        float a_eff = (alpha * kq) * ms::kFlushKInv;
+                        const float nt = fmaf(-a_eff, T, T);
+                        const bool dead = !(nt > ms::kTransmittanceStop);
+                        a_eff = dead ? 0.f : a_eff;
+                        kq = dead ? 0.f : kq;
                         const float vis = a_eff * T;
 #pragma unroll
                         for (int k = 0; k < CP; ++k) pix[k] += s_pc[t * CP + k] * vis;
-                        T = fmaf(-a_eff, T, T);
-                        if (hit && !add) thr = kInf;
+                        T = dead ? T : nt;
                     }
                 }
                 // ---- (3) anyone still alive?
-                const bool wa = __any(thr < kInf);
+                const bool wa = __any(kq != 0.f);
                 __syncthreads();
                 if (lane == 0) s_alive[w] = wa ? 1 : 0;
                 __syncthreads();
