@@ -1050,6 +1050,9 @@ __global__ __launch_bounds__(1024, (E <= 8 ? 8 : 4)) void k_tile_sort_list(const
 //   go to LDS, rank themselves inside their bucket (as in sort_segment_lds) and leave as ids.
 // Three streams over the tile's keys (fresh from the scatter, mostly L2 / Infinity-Cache hits)
 // instead of a full sort; tiles of any length, no merge scratch, no host knowledge of sizes.
+#ifndef MS_MERGED_WAVES
+#define MS_MERGED_WAVES 6   // waves per SIMD the merged sort kernel is compiled for (8: spills; 6 measured best, profiles/r02_merged_sort.md)
+#endif
 constexpr int kFrontK = 1024;
 constexpr int kFrontCap = 4096;   // LDS room for selected keys (32 KB)
 constexpr int kFrontThreads = 512;           // more workgroups in flight than with 1024 (heavy tiles are latency bound)
@@ -1058,8 +1061,14 @@ constexpr int kFrontLogNB = 11;
 static_assert((1 << kFrontLogNB) == kFrontNB, "bucket count");
 constexpr size_t kFrontLds = (size_t)kFrontCap * 8 + (size_t)kFrontNB * 4 + 64 * 4 + 16;
 
-template <bool SPLIT>
-__global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__restrict__ medium,
+// MERGED (plain bins of a lazily sorted frame): ONE launch sorts every list of the band -- block b takes tile
+// order[b] (the count pass's heaviest-first order), sorts it whole if it is short (sort_segment_lds<512, 2>, what
+// k_tile_sort_small does with 256 threads) and selects + sorts its front otherwise.  The heavy tiles' latency
+// chains (two streams over their keys, seven barriers) start first and the short sorts fill the chip beside
+// and behind them, instead of a front launch (480 workgroups at config 3: 16 us) FOLLOWED by a small-sort
+// launch (10 us).  No list of heavy tiles, no host knowledge of their number.
+template <bool SPLIT, bool MERGED>
+__global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void k_tile_front(const int32_t *__restrict__ medium,
                                                      const int32_t *__restrict__ large,
                                                      const int32_t *__restrict__ xl,
                                                      const int64_t *__restrict__ info_dev, int nm_host, int nl_host,
@@ -1069,22 +1078,26 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
                                                      int32_t *__restrict__ front_count, int64_t cap,
                                                      uint32_t fixed_min, int fixed_shift, int front_k,
                                                      ms::BlockLists blocks, int bin_w,
-                                                     const uint32_t *__restrict__ wg_depth, int n_wg) {
+                                                     const uint32_t *__restrict__ wg_depth, int n_wg,
+                                                     const int32_t *__restrict__ order, int n_order, int front_cap) {
+    static_assert(!(SPLIT && MERGED), "block lists are cut by the two-launch path");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem_dyn);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + kFrontCap);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + front_cap);   // front_cap <= kFrontCap keys of LDS room
     uint32_t *s_red = s_cnt + kFrontNB;          // 64 words of reduction scratch
     int *s_sel = reinterpret_cast<int *>(s_red + 64);  // [0] = b*, [1] = F
     constexpr int THREADS = kFrontThreads, NW = kFrontThreads / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nm = info_dev ? (int)info_dev[2] : nm_host, nl = info_dev ? (int)info_dev[3] : nl_host;
     const int nx = info_dev ? (int)info_dev[4] : nx_host;
-    const int total = nm + nl + nx;
+    const int total = MERGED ? n_order : nm + nl + nx;
     if ((int)blockIdx.x >= total) return;   // (uniform; a sync-free launch is sized for the worst case)
     // The frame's own depth range (per-workgroup min / max left by the scatter) beats the camera planes:
     // the scene fills a fraction of (near, far), and buckets that are several times finer make the
-    // ranking inside a bucket as many times shorter.
-    if (wg_depth) {
+    // ranking inside a bucket as many times shorter.  (MERGED: only a block that meets a heavy tile needs it.)
+    bool range_known = false;
+    auto frame_range = [&]() {
+      if (wg_depth && !range_known) {
         uint32_t lo = 0xffffffffu, hi = 0u;
         for (int j = tid; j < n_wg; j += THREADS) {
             lo = min(lo, wg_depth[2 * j]);
@@ -1106,10 +1119,23 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
             fixed_min = lo;
             fixed_shift = max(0, bits - kFrontLogNB);
         }
-    }
+      }
+      range_known = true;
+    };
+    if constexpr (!MERGED) frame_range();
     for (int li = blockIdx.x; li < total; li += gridDim.x) {
-        const int tile = li < nm ? medium[li] : (li < nm + nl ? large[li - nm] : xl[li - nm - nl]);
+        const int tile = MERGED ? order[li] : li < nm ? medium[li] : (li < nm + nl ? large[li - nm] : xl[li - nm - nl]);
         const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+        if constexpr (MERGED) {
+            if (n <= kSmallCap) {   // a short list: sorted whole (uniform per workgroup)
+                if (n > 0 && (int64_t)start + n <= cap)
+                    sort_segment_lds<kFrontThreads, kSmallCap / kFrontThreads>(smem_dyn, keys, start, n, tile, flatten_ids,
+                                                                               nullptr, nullptr);
+                __syncthreads();   // LDS is reused by the next list entry
+                continue;
+            }
+            frame_range();
+        }
         if ((int64_t)start + n > cap) {   // speculative overflow: the frame is redone (uniform)
             if (SPLIT) {       // ... but its rasteriser must find ranges it can walk
                 if (tid < 4) {
@@ -1201,7 +1227,7 @@ __global__ __launch_bounds__(kFrontThreads) void k_tile_front(const int32_t *__r
         for (int j = 0; j < kBpt; ++j) {
             const uint32_t e = run, i = run + c[j];   // exclusive / inclusive prefix of bucket kBpt * tid + j
             if (c[j] && e < want && i >= want) {
-                if (i <= (uint32_t)kFrontCap) { s_sel[0] = kBpt * tid + j; s_sel[1] = (int)i; }
+                if (i <= (uint32_t)front_cap) { s_sel[0] = kBpt * tid + j; s_sel[1] = (int)i; }
                 else { s_sel[0] = kBpt * tid + j - 1; s_sel[1] = (int)e; }
             }
             s_cnt[kBpt * tid + j] = e;
@@ -1623,8 +1649,12 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
     if (lazy) {
         // heavy tiles: sorted front only (k_tile_front); everything else as usual
         static_assert(kFrontK == kSmallCapDecl, "the front kernel takes over exactly where the small class ends");
-        if (spec || n_medium + n_large + n_xl > 0) {
-            auto front = bl.block_ids ? k_tile_front<true> : k_tile_front<false>;
+        // plain bins: one merged launch over the band's tiles, heaviest first (MOJOSPLAT_MERGED_SORT=0: the two
+        // launches, for measurements)
+        static const bool merged_env = [] { const char *e = getenv("MOJOSPLAT_MERGED_SORT"); return !e || atoi(e) != 0; }();
+        const bool merged = merged_env && !bl.block_ids && p.T_local > 0;
+        if (merged || spec || n_medium + n_large + n_xl > 0) {
+            auto front = bl.block_ids ? k_tile_front<true, false> : merged ? k_tile_front<false, true> : k_tile_front<false, false>;
             if (int rc = allow_big_lds(front)) return rc;
             const int64_t heavy = n_medium + n_large + n_xl;
             // (sync-free frame: the previous frame's heavy-tile count sizes the launch; the kernel strides over
@@ -1659,12 +1689,19 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             int front_k = bl.block_ids ? 1280 : blocks_per_tile == 4 ? 1536 : min(kFrontK * blocks_per_tile, 2048);
             if (front_env >= 256 && front_env <= kFrontCap && blocks_per_tile > 1) front_k = front_env;   // (measurements)
             front_k = min(front_k << ((lazy >> 1) & 3), kFrontCap);   // (3072: 1-3 % slower, no fewer clean-ups on the BASELINE scenes)
-            hipLaunchKernelGGL(front, dim3(grid), dim3(kFrontThreads), kFrontLds, stream, medium, large, xl,
+            // LDS room for the selected keys: the front plus the bucket that completes it; the merged launch
+            // keeps it small (2048 keys: 25 KB per workgroup, four 512-thread workgroups per CU)
+            const int front_cap = merged ? min(kFrontCap, max(2048, (front_k * 4 / 3 + 511) & ~511)) : kFrontCap;
+            const size_t front_lds = kFrontLds - (size_t)(kFrontCap - front_cap) * 8;
+            hipLaunchKernelGGL(front, dim3(merged ? (unsigned)p.T_local : grid), dim3(kFrontThreads), front_lds, stream,
+                               medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift,
-                               front_k, bl, tile_w, (const uint32_t *)(ws + p.off_depth_wg), p.G);
+                               front_k, bl, tile_w, (const uint32_t *)(ws + p.off_depth_wg), p.G,
+                               (const int32_t *)(ws + p.off_order), p.T_local, front_cap);
             MS_LAUNCH_CHECK();
         }
+        if (merged) return MS_OK;
         if (p.T_local > 0 && !bl.block_ids)
             hipLaunchKernelGGL(k_tile_sort_small<false>, dim3((unsigned)p.T_local), dim3(256), 0, stream, tile_ranges,
                                sort_keys, flatten_ids, isect_ids, cap, row_begin * tile_w, bl, tile_w);

@@ -124,10 +124,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef MS_RASTER_GROUP
 #define MS_RASTER_GROUP 2
 #endif
+#ifndef MS_RASTER_UNROLL
+#define MS_RASTER_UNROLL 2
+#endif
 #ifndef MS_RASTER_MINW
 #define MS_RASTER_MINW 8
 #endif
 constexpr int kGroup = MS_RASTER_GROUP;   // records evaluated per trip of the blend loop
+constexpr int kUnroll = MS_RASTER_UNROLL; // trips unrolled
 
 template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
 __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasterize_fwd(RasterArgs A) {
@@ -143,10 +147,11 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
     // One LDS block per (wave, quad): the records of the entries that REACH the quad, compacted in list order.
     // The three arrays sit at fixed offsets, so a record's words share one index * 16 B and the blend loop
     // reaches kGroup consecutive records from ONE address register through the instructions' offset fields.
+    // (colours first: a pair's two blues are then within ds_read2_b32's 1 KB offset reach of the same address)
     struct Stage {
+        float col[kSlots * CS];  // CP == 3: (blue, index in batch, -, -)
         float4 a[kSlots];        // mean.x, mean.y, a', b'
         float4 b[kSlots];        // c', log2(opacity), (r, g | index in batch, -)
-        float col[kSlots * CS];  // CP == 3: (blue, index in batch, -, -)
     };
     __shared__ Stage s_stage[WPB][NQ];
     const int wib = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -351,7 +356,9 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                 const int n = __popcll(B[qi]);
                 // kGroup records per trip: their LDS reads go out together, the kGroup log2(alpha) chains and
                 // exp2 are independent of each other (and of the T chain), then the blends run in list order
-                for (int k0 = 0; k0 < n; k0 += kGroup) {
+                // one trip: kGroup records from LDS address k0, transmittance t in and out (by value, so that two
+                // unrolled trips take turns on two registers instead of copying T back at the loop's end)
+                auto trip = [&](const int k0, float t) __attribute__((always_inline)) -> float {
                     float4 ra[kGroup], rb[kGroup];
                     float rc[kGroup][CP == 3 ? 1 : CP];
                     int rt[kGroup];
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                     }
                     // T after each record of the group; T(1 - alpha) only shrinks along the group, so ONE test of
                     // the last value tells whether any pixel stops inside it
-                    float t = T[qi];
+                    const float t_in = t;
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
                         MS_DIAG_ONLY(++diag_evals;)
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                     // redoes the group's T chain with the stopping record (and what follows it) taken out.
                     if (__ballot(!(t > ms::kTransmittanceStop))) {
                         asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
-                        t = T[qi];
+                        t = t_in;
                         bool dead = false;
 #pragma unroll
                         for (int j = 0; j < kGroup; ++j) {
@@ -415,7 +422,12 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                     }
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
-                        const float vis = a_eff[j] * Tpre[j];
+                        // (the empty asm statements keep the group's products apart: v_pk_mul_f32 costs 2.2 v_mul_f32
+                        // on gfx950 and needs its operands in register pairs, i.e. a copy of T per trip)
+                        float tp = Tpre[j];
+                        asm volatile("" : "+v"(tp));
+                        float vis = a_eff[j] * tp;
+                        asm volatile("" : "+v"(vis));
                         if constexpr (CP == 3) {
                             pix[qi][0] += rb[j].z * vis;
                             pix[qi][1] += rb[j].w * vis;
@@ -426,8 +438,18 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                         }
                         if constexpr (AUX) last[qi] = a_eff[j] != 0.f ? b0 + rt[j] : last[qi];
                     }
-                    T[qi] = t;
+                    return t;
+                };
+                float t = T[qi];
+                int k0 = 0;
+                if constexpr (kUnroll == 2) {
+                    for (; k0 + kGroup < n; k0 += 2 * kGroup) {
+                        const float u = trip(k0, t);
+                        t = trip(k0 + kGroup, u);
+                    }
                 }
+                for (; k0 < n; k0 += kGroup) t = trip(k0, t);
+                T[qi] = t;
                 any_live = any_live || __any(kq[qi] != 0.f);
             }
         };
