@@ -508,6 +508,7 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
     if (threadIdx.x == 0) wg_on_grid[blockIdx.x] = s_on_grid;
+    if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
 }
 
 __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
@@ -527,60 +528,37 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     uint32_t *row = hist + (size_t)blockIdx.x * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
     if (threadIdx.x == 0) wg_on_grid[blockIdx.x] = s_on_grid;
-}
-
-// hist[g][t] -> exclusive prefix over g (in place); tile_count[t] = sum over g.
-__global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
-                                                       uint32_t *__restrict__ hist,
-                                                       uint32_t *__restrict__ tile_count) {
-    __shared__ uint32_t s_part[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + lane;
-    const int per = (G + 15) / 16;
-    const int g0 = w * per, g1 = min(G, g0 + per);
-    uint32_t v[kMaxG / 16];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxG / 16; ++k) {
-        const int gg = g0 + k;
-        v[k] = (gg < g1 && t < T_local) ? hist[(size_t)gg * T_local + t] : 0u;
-        sum += v[k];
-    }
-    s_part[w][lane] = sum;
-    __syncthreads();
-    uint32_t run = 0, total = 0;
-#pragma unroll
-    for (int ww = 0; ww < 16; ++ww) {
-        const uint32_t p = s_part[ww][lane];
-        if (ww < w) run += p;
-        total += p;
-    }
-#pragma unroll
-    for (int k = 0; k < kMaxG / 16; ++k) {
-        const int gg = g0 + k;
-        if (gg < g1 && t < T_local) {
-            hist[(size_t)gg * T_local + t] = run;
-            run += v[k];
-        }
-    }
-    if (w == 0 && t < T_local) tile_count[t] = total;
+    if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
 }
 
 // One workgroup: exclusive scan of the per-tile counts over the FULL grid (tiles outside
 // the band count 0), tile_ranges, totals and the work lists of over-sized tiles.  Each wave owns
 // a contiguous run of tiles and walks it 64 tiles at a time (coalesced loads / int2 stores,
 // wave-level scans), so the kernel is three dependent memory round trips long.
-__global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t *__restrict__ tile_count,
-                                                          int32_t *__restrict__ tile_ranges,
-                                                          int32_t *__restrict__ medium_list,
-                                                          int32_t *__restrict__ large_list,
-                                                          int32_t *__restrict__ xl_list,
-                                                          const uint32_t *__restrict__ wg_on_grid, int G,
-                                                          int32_t *__restrict__ redo_flag,
-                                                          int32_t *__restrict__ redo_count,
-                                                          int band_only, int64_t *__restrict__ info,
-                                                          int64_t *__restrict__ info_mirror,
-                                                          int32_t *__restrict__ order) {
+struct ScanTotalArgs {
+    Grid g;
+    const uint32_t *tile_count;
+    int32_t *tile_ranges, *medium_list, *large_list, *xl_list;
+    const uint32_t *wg_on_grid;
+    int G;
+    int32_t *redo_flag, *redo_count;
+    int band_only;
+    int64_t *info, *info_mirror;
+    int32_t *order;
+    uint32_t *ticket;   // k_tile_scan_wg: arrival counter of its workgroups (zeroed by the frame's count kernel)
+};
+
+__device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
+    const Grid &g = A.g;
+    const uint32_t *__restrict__ tile_count = A.tile_count;
+    int32_t *__restrict__ tile_ranges = A.tile_ranges;
+    int32_t *__restrict__ medium_list = A.medium_list, *__restrict__ large_list = A.large_list,
+            *__restrict__ xl_list = A.xl_list;
+    const uint32_t *__restrict__ wg_on_grid = A.wg_on_grid;
+    const int G = A.G, band_only = A.band_only;
+    int32_t *__restrict__ redo_flag = A.redo_flag, *__restrict__ redo_count = A.redo_count;
+    int64_t *__restrict__ info = A.info, *__restrict__ info_mirror = A.info_mirror;
+    int32_t *__restrict__ order = A.order;
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
     // heaviest-first order of the band's tiles for the rasteriser's launch (order[0 .. band tiles)): counting
@@ -601,9 +579,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
     const int per_wave = ((t_hi - t_lo + 15) / 16 + 63) & ~63;   // tiles per wave, a multiple of 64
     const int w0 = t_lo + w * per_wave, w1 = min(t_hi, w0 + per_wave);
     if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; }
+    // (loads whose values are only needed at the end go out first: the pass is a chain of dependent round trips)
+    const int prev_redo = threadIdx.x == 0 ? *redo_count : 0;
+    unsigned int on_grid_part = (int)threadIdx.x < G ? wg_on_grid[threadIdx.x] : 0u;   // G <= kMaxG <= blockDim
     // (s_bkt is zeroed above and first added to after the __syncthreads() between the two passes)
     auto count_of = [&](int t) -> unsigned int {
-        return (t < w1 && t >= band0 && t < band1) ? tile_count[t - band0] : 0u;
+        // (agent scope: written by the other workgroups of the same launch when this runs inside k_tile_scan_wg)
+        return (t < w1 && t >= band0 && t < band1)
+                   ? __hip_atomic_load(&tile_count[t - band0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     };
     // pass 1: this wave's total.  The first kPre steps' counts are loaded in one go (independent loads:
     // one memory round trip instead of one per step) and kept in registers for pass 2 -- the kernel is
@@ -628,9 +611,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
         if (ww < w) run += s_wave[ww];
         grand += s_wave[ww];
     }
-    if ((int)threadIdx.x < G) {  // G <= kMaxG <= blockDim
-        const unsigned int v = wg_on_grid[threadIdx.x];
-        if (v) atomicAdd(&s_on_grid, v);
+    {   // a wave sum, then one LDS atomic per wave
+        unsigned int v = on_grid_part;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += (unsigned int)__shfl_xor((int)v, d);
+        if (lane == 0 && v) atomicAdd(&s_on_grid, v);
     }
     // pass 2: offsets, ranges, classes
     unsigned int lmax = 0;
@@ -692,7 +677,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
         info[2] = (int64_t)s_nmedium;
         info[3] = (int64_t)s_nlarge;
         info[4] = (int64_t)s_nxl;
-        info[5] = (int64_t)*redo_count;  // tiles the PREVIOUS frame on this workspace had to redo (lazy sorting)
+        info[5] = (int64_t)prev_redo;  // tiles the PREVIOUS frame on this workspace had to redo (lazy sorting)
         *redo_count = 0;
         info[6] = (int64_t)s_on_grid;  // Gaussians whose tile box touches the FULL grid (band-independent)
         info[7] = 0;
@@ -702,10 +687,77 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(Grid g, const uint32_t
             // recorded after this kernel has completed.  Word 7 belongs to the host side.
 #pragma unroll
             for (int k = 0; k < 7; ++k) info_mirror[k] = info[k];
-            __threadfence_system();
+            __threadfence_system();   // (measured free: 12.9 us with and without)
         }
     }
 }
+
+// hist[g][t] -> exclusive prefix over g (in place); tile_count[t] = sum over g.
+// 16 tiles per workgroup (round 2, second session: 64 tiles per workgroup left a 1080p frame's 2 040 bins to 32
+// workgroups, i.e. 32 CUs moving 8 MB): thread = (tile, slice of G / 64 partial rows); the slices of a tile are
+// combined by two shuffles inside the wave and one LDS step across the 16 waves.
+// The workgroup that arrives LAST (a ticket zeroed by the frame's count kernel; release / acquire fences at
+// agent scope around it) goes on to run the total pass (tile_scan_total) in the same launch: one kernel
+// boundary and one launch latency fewer on the frame's critical path.
+constexpr int kScanTiles = 16, kScanSlices = 1024 / kScanTiles;
+__global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
+                                                       uint32_t *__restrict__ hist,
+                                                       uint32_t *__restrict__ tile_count, ScanTotalArgs A) {
+    __shared__ uint32_t s_part[16][kScanTiles];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tl = threadIdx.x & (kScanTiles - 1), sl = threadIdx.x / kScanTiles;
+    const int t = blockIdx.x * kScanTiles + tl;
+    constexpr int kRows = kMaxG / kScanSlices;   // partial rows per slice (8)
+    const int per = (G + kScanSlices - 1) / kScanSlices;
+    const int g0 = sl * per, g1 = min(G, g0 + per);
+    uint32_t v[kRows];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int gg = g0 + k;
+        v[k] = (k < per && gg < g1 && t < T_local) ? hist[(size_t)gg * T_local + t] : 0u;
+        sum += v[k];
+    }
+    // the 4 slices of a tile inside this wave sit 16 lanes apart: inclusive prefix over them
+    uint32_t incl = sum;
+    uint32_t o = (uint32_t)__shfl_up((int)incl, 16);
+    if (lane >= 16) incl += o;
+    o = (uint32_t)__shfl_up((int)incl, 32);
+    if (lane >= 32) incl += o;
+    if (lane >= 48) s_part[w][tl] = incl;   // the wave's total for tile tl
+    __syncthreads();
+    uint32_t run = incl - sum, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) {
+        const uint32_t p = s_part[ww][tl];
+        if (ww < w) run += p;
+        total += p;
+    }
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int gg = g0 + k;
+        if (k < per && gg < g1 && t < T_local) {
+            hist[(size_t)gg * T_local + t] = run;
+            run += v[k];
+        }
+    }
+    // The hand-off to the last workgroup is the tile counts alone (the prefixes are for the next KERNEL): agent-scope
+    // stores (write-through: the XCDs' L2s are not coherent with each other), drained (vmcnt(0), which the
+    // workgroup-scope release waits for) before the ticket; the total pass reads them with agent-scope loads.  A
+    // full agent-scope fence here would write back every dirty line of the 4 MB of prefixes first: measured 61 us.
+    if (sl == 0 && t < T_local) __hip_atomic_store(&tile_count[t], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!A.ticket) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    tile_scan_total(A);
+}
+
+// The total pass alone (an empty band has no per-tile prefix to take)
+__global__ __launch_bounds__(1024) void k_tile_scan_total(ScanTotalArgs A) { tile_scan_total(A); }
 
 template <bool PACK>
 __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
@@ -1377,7 +1429,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_medium = o; o += ms::align_up((size_t)p.T * 4, 256);
     p.off_large = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
-    p.off_on_grid = o; o += ms::align_up((size_t)kMaxG * 4, 256);
+    p.off_on_grid = o; o += ms::align_up((size_t)kMaxG * 4 + 64, 256);   // + the scan kernel's arrival ticket (word kMaxG)
     p.off_front = o;      o += ms::align_up((size_t)p.T * 4, 256);  // lazy sorting: sorted-front length per tile
     p.off_redo_flag = o;  o += ms::align_up((size_t)p.T * 4, 256);  //   tiles whose front did not saturate them
     p.off_redo_list = o;  o += ms::align_up((size_t)p.T * 4, 256);
@@ -1427,14 +1479,17 @@ namespace {
 int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t *count, int32_t *medium,
                int32_t *large, int32_t *xl, const uint32_t *wg_on_grid, int n_wg, int32_t *tile_ranges,
                int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream) {
+    ScanTotalArgs A{g, count, tile_ranges, medium, large, xl, wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag),
+                    (int32_t *)(ws + p.off_redo_count), band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order),
+                    (uint32_t *)wg_on_grid + kMaxG};
     if (p.T_local > 0) {
-        hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
-                           p.G, p.T_local, hist, count);
-        MS_LAUNCH_CHECK();
+        // (the last workgroup to arrive runs the total pass)
+        hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, kScanTiles)), dim3(1024), 0, stream,
+                           p.G, p.T_local, hist, count, A);
+    } else {
+        A.ticket = nullptr;
+        hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, A);
     }
-    hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, g, count, tile_ranges, medium, large, xl,
-                       wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count),
-                       band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order));
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
