@@ -103,6 +103,22 @@ __device__ __forceinline__ unsigned long long reach_mask(float mx, float my, flo
     return mask;
 }
 
+// Workgroup -> chunk of the count / scatter kernels.  A tile's segment of the key buffer is laid out chunk by
+// chunk (the prefix over the partial histograms), each chunk contributing an entry or two: with chunk = blockIdx
+// the eight XCDs (blocks are dealt round-robin over them; their L2s do not share lines) interleave at 16-byte
+// granularity inside every 64-byte line, and each line leaves as several partial writes (k_isect_scatter: 96 % of
+// its write requests were 32-byte partials, profiles/r01_pmc_binning.md).  Giving XCD x the x-th contiguous
+// EIGHTH of the chunks makes one L2 own whole stretches of every segment, so lines are completed before they are
+// written back.  Any bijection is correct (both kernels use the same one); the XCD placement is speed only.
+__device__ __forceinline__ int chunk_of_block(int b, int G) {
+#ifdef MS_NO_CHUNK_REMAP
+    return b;
+#else
+    const int n8 = G >> 3, rem = G & 7, x = b & 7, k = b >> 3;
+    return x * n8 + min(x, rem) + k;
+#endif
+}
+
 __device__ __forceinline__ int clampi(float v, int lo, int hi) {
     if (!(v > (float)lo)) return lo;  // also NaN
     if (v >= (float)hi) return hi;
@@ -310,7 +326,7 @@ __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const flo
     int64_t stride = kHistThreads;
     if (cand.ids) {   // positions of the candidate list, step s -> workgroup s mod G
         map.build(cand);
-        i0 = (int64_t)blockIdx.x * kHistThreads;
+        i0 = (int64_t)chunk_of_block(blockIdx.x, gridDim.x) * kHistThreads;
         i1 = (int64_t)s_pref[cand.n_segs];
         stride = (int64_t)gridDim.x * kHistThreads;
     }
@@ -443,10 +459,11 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
     __syncthreads();
     __shared__ uint32_t s_pref[kMaxG + 1];
     CandMap map{s_pref};
-    int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk), stride = kHistThreads;
+    const int wg = chunk_of_block(blockIdx.x, gridDim.x);   // this workgroup's chunk (and histogram row)
+    int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk), stride = kHistThreads;
     if (cand.ids) {   // positions of the band's candidate list, step s -> workgroup s mod G (as the scatter kernel)
         map.build(cand);
-        i0 = (int64_t)blockIdx.x * kHistThreads;
+        i0 = (int64_t)wg * kHistThreads;
         i1 = (int64_t)s_pref[cand.n_segs];
         stride = (int64_t)gridDim.x * kHistThreads;
     }
@@ -505,9 +522,9 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
         walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     }
     __syncthreads();
-    uint32_t *row = hist + (size_t)blockIdx.x * T_local;
+    uint32_t *row = hist + (size_t)wg * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
-    if (threadIdx.x == 0) wg_on_grid[blockIdx.x] = s_on_grid;
+    if (threadIdx.x == 0) wg_on_grid[wg] = s_on_grid;
     if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
 }
 
@@ -521,13 +538,14 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
     if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
-    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
+    const int wg = chunk_of_block(blockIdx.x, gridDim.x);
+    const int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk);
     for_each_isect<false>(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid, Candidates{nullptr, nullptr, 0, 0},
                    [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
-    uint32_t *row = hist + (size_t)blockIdx.x * T_local;
+    uint32_t *row = hist + (size_t)wg * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
-    if (threadIdx.x == 0) wg_on_grid[blockIdx.x] = s_on_grid;
+    if (threadIdx.x == 0) wg_on_grid[wg] = s_on_grid;
     if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
 }
 
@@ -769,11 +787,12 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     extern __shared__ uint32_t s_cur[];
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     const int band0 = g.row_begin * g.tw;
-    const uint32_t *row = hist + (size_t)blockIdx.x * T_local;
+    const int wg = chunk_of_block(blockIdx.x, gridDim.x);   // the chunk (and histogram row) the count kernel gave this index
+    const uint32_t *row = hist + (size_t)wg * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads)
         s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
     __syncthreads();
-    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
+    const int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk);
     // depth bits (order preserving for the positive depths that survive) of everything this workgroup
     // emits: k_tile_front spreads its buckets over the frame's range
     uint32_t dmin = 0xffffffffu, dmax = 0u;

@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     for src in _sources():
         obj = os.path.splitext(src)[0] + (f".{variant}.o" if variant else ".diag.o" if diag else ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"] + SOURCE_FLAGS.get(os.path.basename(src), []) + \
+               "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-fno-slp-vectorize"] + SOURCE_FLAGS.get(os.path.basename(src), []) + \
             (["-DMS_DIAG"] if diag else []) + extra
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
