@@ -56,7 +56,7 @@ struct RasterArgs {
     float *render_colors;
     float *render_alphas;
     int32_t *last_ids;
-    int W, H, ts, tw, nsx, nsub, cdim, tile0, nblocks, max_isects, n_gauss, parts;
+    int W, H, ts, tw, nsx, nsub, cdim, tile0, nblocks, ngrid, max_isects, n_gauss, parts;   // ngrid: workgroup indices in use (>= nblocks)
     const int32_t *order;  // the band's tiles (order_bins: the 32-px bins of a split frame), heaviest first; null: xcd_remap
     int order_bins, row0, row1;
     const float4 *records; // ready-made ms::RasterRecord per Gaussian (3 channels), or null: stage from the arrays
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
         const int j = blockIdx.x >> 3;
         part = j % kParts;
         wg = ((j / kParts) << 3) | (blockIdx.x & 7);
-        if (wg >= A.nblocks) return;
+        if (wg >= A.ngrid) return;
     }
 
     MS_DIAG_ONLY(const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime(), diag_c0 = __builtin_amdgcn_s_memtime(); unsigned diag_evals = 0, diag_batches = 0;)
@@ -175,8 +175,17 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
         tile = by16 * A.tw + bx16;
         sub = 0;
     } else if (A.order) {
+#ifdef MS_RASTER_SUBS_APART
         tile = A.order[wg / A.nsub];
         sub = wg % A.nsub;
+#else
+        // the nsub 16x16 blocks of a coarse tile on ONE XCD (wg & 7 labels it), back to back: they gather the
+        // same records, so the tile's list and records cross into that L2 once instead of nsub times
+        const int e = ((wg >> 3) / A.nsub) * 8 + (wg & 7);
+        if (e >= A.nblocks / A.nsub) return;   // (uniform per workgroup; the grid is padded to 8 tiles)
+        tile = A.order[e];
+        sub = (wg >> 3) % A.nsub;
+#endif
     } else {
         const int item = xcd_remap(wg, A.nblocks);
         const int bt = item / A.nsub;
@@ -759,7 +768,7 @@ template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
     const bool aux = A.render_alphas || A.last_ids;
     // parts single-wave workgroups per block, the block count rounded up to the 8 XCDs
-    const dim3 grid(A.parts > 1 ? (unsigned)(((A.nblocks + 7) / 8) * 8 * A.parts) : (unsigned)A.nblocks);
+    const dim3 grid(A.parts > 1 ? (unsigned)(((A.ngrid + 7) / 8) * 8 * A.parts) : (unsigned)A.ngrid);
 #define MS_LAUNCH_RASTER(AUXV, NQV, PK) \
     hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, NQV, PK>), grid, dim3(64), 0, stream, A)
 #define MS_LAUNCH_RASTER_NQ(AUXV, PK)                          \
@@ -876,6 +885,10 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
     A.parts = choose_parts(blocks, density_hint, A.records != nullptr);
     A.nblocks = (int)blocks;
+    A.ngrid = (int)blocks;
+#ifndef MS_RASTER_SUBS_APART
+    if (order) A.ngrid = ((band_tiles + 7) / 8) * 8 * A.nsub;   // tiles dealt over the 8 XCDs, each with its nsub blocks
+#endif
     A.max_isects = (int)M;
     MS_REQUIRE(N > 0 || M == 0, MS_ERR_INVALID_ARG, "rasterize_fwd: M > 0 with N == 0");
     A.n_gauss = (int)(N < 0x7fffffffll ? (N > 0 ? N : 1) : 0x7fffffffll);
@@ -945,6 +958,7 @@ int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const 
     A.parts = choose_parts(blocks, density_hint, A.records != nullptr);
     // with an order: four workgroups per 32-px bin of the band (those outside the image or the band leave at once)
     A.nblocks = order ? 4 * ((r1 + 1) / 2 - r0 / 2) * bw : (int)blocks;
+    A.ngrid = A.nblocks;
     A.max_isects = (int)(4 * cap);
     A.n_gauss = (int)(N < 0x7fffffffll ? N : 0x7fffffffll);
     if (int rc = color_dtype == MS_COLOR_F16 ? launch_fwd<__half>(A, stream, after_raster_event)
