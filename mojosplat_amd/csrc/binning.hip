@@ -42,6 +42,9 @@ namespace {
 #ifndef MS_CHUNK
 #define MS_CHUNK 2048
 #endif
+#ifndef MS_PH_WAVES
+#define MS_PH_WAVES 8
+#endif
 constexpr int kHistThreads = 1024;
 constexpr int kMaxG = 512;
 constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
 // its Gaussian (project_device.hpp), stores the projected record, and counts the tiles of its box
 // in the workgroup's LDS histogram.  Same chunking as k_isect_hist / k_isect_scatter.
 template <bool PACK>
-__global__ __launch_bounds__(kHistThreads, 8) void k_project_hist(
+__global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     ms::ProjParams P, Grid g, int64_t chunk, float *__restrict__ means2d, float *__restrict__ conics,

@@ -36,9 +36,12 @@ constexpr float kMaxAlpha = 0.999f;
 constexpr float kTransmittanceStop = 1e-4f;
 // The forward rasteriser's select without a compare (rasterize.hip is compiled with fp32 denormals flushed):
 // kFlushK = 255 * 2^-126 is the smallest float k with fl(1/255) * k >= 2^-126, so alpha * k is a normal number
-// iff alpha >= fl(1/255) and +0 otherwise; kFlushKInv = fl(1 / k) scales a hit back to alpha (to an ulp).
+// iff alpha >= fl(1/255) and +0 otherwise.
 constexpr float kFlushK = 0x1.fep-119f;
-constexpr float kFlushKInv = 0x1.010102p+118f;
+// alpha * kFlushK is never scaled back: the rasteriser carries the transmittance as S = T * kTScale, so that
+// (alpha kFlushK) S = 255 alpha T, and divides by 255 (kInv255 = fl(1/255)) where it needs alpha T itself.
+constexpr float kTScale = 0x1p+126f, kTUnscale = 0x1p-126f, kInv255 = kAlphaThreshold;
+constexpr float kAlphaOfV = 0x1.010102p+118f;   // 2^126 / 255: alpha S from v = 255 alpha T
 static_assert((double)kAlphaThreshold * (double)kFlushK >= 0x1p-126 &&
                   (double)(kAlphaThreshold * (1.0f - 0x1p-24f)) * (double)kFlushK < 0x1p-126,
               "flush select: the threshold must sit exactly on the smallest normal number");

@@ -76,6 +76,14 @@ __device__ unsigned long long *g_diag_stamps = nullptr;
 #define MS_DIAG_ONLY(...)
 #endif
 
+// accumulated 255 * colour and scaled transmittance S = T * 2^126 -> the pixel's channel.  ONE spelling for the
+// rasteriser and its clean-up kernel: left to the compiler, either product of `pix / 255 + T bg` may be the one
+// that is fused into the addition, and the two kernels must round alike.
+__device__ __forceinline__ float finish_channel(float pix255, float S, float bg) {
+    const float tb = (S * ms::kTUnscale) * bg;   // (the first product is exact)
+    return __builtin_fmaf(pix255, ms::kInv255, tb);
+}
+
 __device__ __forceinline__ float load_color(const float *p) { return *p; }
 __device__ __forceinline__ float load_color(const __half *p) { return __half2float(*p); }
 
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
         const int q = qbase + qi;
         const int X = bx + lx + (q & 1) * 8, Y = by + ly + (q >> 1) * 8;
         const bool in = (ox + (q & 1) * 8) < A.ts && (oy + (q >> 1) * 8) < A.ts && X < A.W && Y < A.H;
-        T[qi] = 1.0f;
+        T[qi] = ms::kTScale;   // the transmittance is carried as S = T * 2^126 (see the blend loop)
         kq[qi] = in ? ms::kFlushK : 0.f;
         last[qi] = 0;
 #pragma unroll
@@ -387,11 +395,14 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                         }
                     }
                     // The select without a compare (v_cmp / v_cndmask issue at half the FMA rate on gfx950): this
-                    // file is compiled with fp32 denormals flushed, and alpha * (255 * 2^-126) is a normal number
+                    // file is compiled with fp32 denormals flushed, and m = alpha * (255 * 2^-126) is a normal number
                     // iff alpha >= fl(1/255) -- bit for bit the reference's test (scripts/ubench/flush_select.hip
-                    // checks every float around the threshold) -- so (alpha * kq) * K is alpha to an ulp for a
-                    // hit on a live pixel and exactly 0 otherwise.
-                    float a_eff[kGroup], Tpre[kGroup];
+                    // checks every float around the threshold) -- and exactly 0 otherwise (kq = 0: a finished pixel).
+                    // m is never scaled back: the transmittance is carried as S = T * 2^126 (exact; S <= 8.5e37), so
+                    // v = m * S = 255 alpha T is the blend weight times 255, S (1 - alpha) = S - v * (2^126 / 255) is ONE fma,
+                    // and the accumulated colours are divided by 255 once per pixel at the end: six VALU instructions
+                    // per evaluation behind the exp2 instead of nine.
+                    float m[kGroup], v[kGroup];
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
                         const float dx = ra[j].x - px, dy = ra[j].y - py;
@@ -402,50 +413,47 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                             alpha = fminf(ms::kMaxAlpha, alpha);
                             alpha = la <= rb[j].y ? alpha : 0.f;                    // sigma >= 0
                         }
-                        a_eff[j] = (alpha * kq[qi]) * ms::kFlushKInv;
+                        m[j] = alpha * kq[qi];
+                        // (keeps the group's products apart: v_pk_mul_f32 costs 2.2 v_mul_f32 on gfx950 and wants
+                        // its operands in register pairs)
+                        asm volatile("" : "+v"(m[j]));
                     }
-                    // T after each record of the group; T(1 - alpha) only shrinks along the group, so ONE test of
-                    // the last value tells whether any pixel stops inside it
+                    // S after each record of the group; it only shrinks along the group, so ONE test of the last
+                    // value tells whether any pixel stops inside it
                     const float t_in = t;
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
                         MS_DIAG_ONLY(++diag_evals;)
-                        Tpre[j] = t;
-                        t = fmaf(-a_eff[j], t, t);                                   // T (1 - alpha)
+                        v[j] = m[j] * t;
+                        t = fmaf(v[j], -ms::kAlphaOfV, t);                               // S (1 - alpha)
                     }
                     // stop BEFORE adding: the pixel is finished.  Happens once per pixel -> rare path, which
-                    // redoes the group's T chain with the stopping record (and what follows it) taken out.
-                    if (__ballot(!(t > ms::kTransmittanceStop))) {
+                    // redoes the group's chain with the stopping record (and what follows it) taken out.
+                    if (__ballot(!(t > ms::kTransmittanceStop * ms::kTScale))) {
                         asm volatile("" ::: "memory");  // keep this a real (rarely taken) scalar branch
                         t = t_in;
                         bool dead = false;
 #pragma unroll
                         for (int j = 0; j < kGroup; ++j) {
-                            const float nt = fmaf(-a_eff[j], t, t);
-                            dead = dead || !(nt > ms::kTransmittanceStop);
-                            a_eff[j] = dead ? 0.f : a_eff[j];
-                            Tpre[j] = t;
+                            const float vj = m[j] * t;
+                            const float nt = fmaf(vj, -ms::kAlphaOfV, t);
+                            dead = dead || !(nt > ms::kTransmittanceStop * ms::kTScale);
+                            v[j] = dead ? 0.f : vj;
                             t = dead ? t : nt;
                         }
                         kq[qi] = dead ? 0.f : kq[qi];
                     }
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
-                        // (the empty asm statements keep the group's products apart: v_pk_mul_f32 costs 2.2 v_mul_f32
-                        // on gfx950 and needs its operands in register pairs, i.e. a copy of T per trip)
-                        float tp = Tpre[j];
-                        asm volatile("" : "+v"(tp));
-                        float vis = a_eff[j] * tp;
-                        asm volatile("" : "+v"(vis));
                         if constexpr (CP == 3) {
-                            pix[qi][0] += rb[j].z * vis;
-                            pix[qi][1] += rb[j].w * vis;
-                            pix[qi][2] += rc[j][0] * vis;
+                            pix[qi][0] += rb[j].z * v[j];
+                            pix[qi][1] += rb[j].w * v[j];
+                            pix[qi][2] += rc[j][0] * v[j];
                         } else {
 #pragma unroll
-                            for (int c = 0; c < CP; ++c) pix[qi][c] += rc[j][c] * vis;
+                            for (int c = 0; c < CP; ++c) pix[qi][c] += rc[j][c] * v[j];
                         }
-                        if constexpr (AUX) last[qi] = a_eff[j] != 0.f ? b0 + rt[j] : last[qi];
+                        if constexpr (AUX) last[qi] = v[j] != 0.f ? b0 + rt[j] : last[qi];
                     }
                     return t;
                 };
@@ -504,9 +512,9 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
 #pragma unroll
         for (int k = 0; k < CP; ++k)
             if (k < A.cdim)
-                A.render_colors[p * A.cdim + k] = pix[qi][k] + (A.backgrounds ? T[qi] * A.backgrounds[k] : 0.f);
+                A.render_colors[p * A.cdim + k] = finish_channel(pix[qi][k], T[qi], A.backgrounds ? A.backgrounds[k] : 0.f);
         if constexpr (AUX) {
-            if (A.render_alphas) A.render_alphas[p] = 1.0f - T[qi];
+            if (A.render_alphas) A.render_alphas[p] = 1.0f - T[qi] * ms::kTUnscale;
             if (A.last_ids) A.last_ids[p] = last[qi];
         }
     }
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
             const int X = tile_x * A.ts + ox, Y = tile_y * A.ts + oy;
             const bool in = ox < A.ts && oy < A.ts && X < A.W && Y < A.H;
             const float px = (float)X + 0.5f, py = (float)Y + 0.5f;
-            float T = 1.0f, kq = in ? ms::kFlushK : 0.f, pix[CP];   // kq: k_rasterize_fwd's flush select
+            float T = ms::kTScale, kq = in ? ms::kFlushK : 0.f, pix[CP];   // k_rasterize_fwd's flush select and scaled state
 #pragma unroll
             for (int k = 0; k < CP; ++k) pix[k] = 0.f;
             unsigned long long lower = 0ull;   // keys consumed so far are <= lower (exclusive bound once !first)
@@ -723,12 +731,12 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                         // k_rasterize_fwd's generic (CHECK) arithmetic, operation for operation
                         float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
                         alpha = la <= rb.y ? alpha : 0.f;
-                        float a_eff = (alpha * kq) * ms::kFlushKInv;
-                        const float nt = fmaf(-a_eff, T, T);
-                        const bool dead = !(nt > ms::kTransmittanceStop);
-                        a_eff = dead ? 0.f : a_eff;
+                        const float mj = alpha * kq;
+                        const float vj = mj * T;
+                        const float nt = fmaf(vj, -ms::kAlphaOfV, T);
+                        const bool dead = !(nt > ms::kTransmittanceStop * ms::kTScale);
+                        const float vis = dead ? 0.f : vj;
                         kq = dead ? 0.f : kq;
-                        const float vis = a_eff * T;
 #pragma unroll
                         for (int k = 0; k < CP; ++k) pix[k] += s_pc[t * CP + k] * vis;
                         T = dead ? T : nt;
@@ -745,7 +753,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                 const size_t p = (size_t)Y * A.W + X;
 #pragma unroll
                 for (int k = 0; k < CP; ++k)
-                    if (k < A.cdim) A.render_colors[p * A.cdim + k] = pix[k] + (A.backgrounds ? T * A.backgrounds[k] : 0.f);
+                    if (k < A.cdim) A.render_colors[p * A.cdim + k] = finish_channel(pix[k], T, A.backgrounds ? A.backgrounds[k] : 0.f);
             }
             __syncthreads();
         }

@@ -188,6 +188,10 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                                                group=group, async_op=True)
 
             def image():
+                # the OR over the ranks is at least this rank's own bit: only a rank whose band holds nothing has
+                # to WAIT for the reduced flag (a device-to-host read, i.e. a host stall per frame otherwise)
+                if on_grid > 0:
+                    return full[:H]
                 fwork.wait()
                 return full[:H] if int(flag.item()) > 0 else torch.zeros(H, W, C, device=dev, dtype=torch.float32)
             return image, work
