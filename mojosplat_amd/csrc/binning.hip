@@ -569,6 +569,9 @@ struct ScanTotalArgs {
     uint32_t *ticket;   // k_tile_scan_wg: arrival counter of its workgroups (zeroed by the frame's count kernel)
 };
 
+// HANDOFF: the counts were written by other workgroups of the SAME launch (k_tile_scan_wg's last workgroup runs
+// this): agent-scope loads; a launch of its own reads them plainly.
+template <bool HANDOFF>
 __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
     const Grid &g = A.g;
     const uint32_t *__restrict__ tile_count = A.tile_count;
@@ -605,9 +608,9 @@ __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
     unsigned int on_grid_part = (int)threadIdx.x < G ? wg_on_grid[threadIdx.x] : 0u;   // G <= kMaxG <= blockDim
     // (s_bkt is zeroed above and first added to after the __syncthreads() between the two passes)
     auto count_of = [&](int t) -> unsigned int {
-        // (agent scope: written by the other workgroups of the same launch when this runs inside k_tile_scan_wg)
-        return (t < w1 && t >= band0 && t < band1)
-                   ? __hip_atomic_load(&tile_count[t - band0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (!(t < w1 && t >= band0 && t < band1)) return 0u;
+        if constexpr (HANDOFF) return __hip_atomic_load(&tile_count[t - band0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return tile_count[t - band0];
     };
     // pass 1: this wave's total.  The first kPre steps' counts are loaded in one go (independent loads:
     // one memory round trip instead of one per step) and kept in registers for pass 2 -- the kernel is
@@ -714,16 +717,20 @@ __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
 }
 
 // hist[g][t] -> exclusive prefix over g (in place); tile_count[t] = sum over g.
-// 16 tiles per workgroup (round 2, second session: 64 tiles per workgroup left a 1080p frame's 2 040 bins to 32
+// kScanTiles tiles per workgroup (round 2, second session: 64 tiles per workgroup left a 1080p frame's 2 040 bins to 32
 // workgroups, i.e. 32 CUs moving 8 MB): thread = (tile, slice of G / 64 partial rows); the slices of a tile are
 // combined by two shuffles inside the wave and one LDS step across the 16 waves.
 // The workgroup that arrives LAST (a ticket zeroed by the frame's count kernel; release / acquire fences at
 // agent scope around it) goes on to run the total pass (tile_scan_total) in the same launch: one kernel
 // boundary and one launch latency fewer on the frame's critical path.
-constexpr int kScanTiles = 16, kScanSlices = 1024 / kScanTiles;
+// (kScanTiles = 16 for grids up to 4 096 tiles; larger ones -- 8 160 tiles of 16 px at 1080p: 17 MB of partial
+// rows -- take 64 tiles per workgroup: 64-byte row pieces waste half of every 128-byte line once the rows no
+// longer sit in the caches, measured 29 us against 17.)
+template <int kScanTiles>
 __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
                                                        uint32_t *__restrict__ hist,
                                                        uint32_t *__restrict__ tile_count, ScanTotalArgs A) {
+    constexpr int kScanSlices = 1024 / kScanTiles;
     __shared__ uint32_t s_part[16][kScanTiles];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -740,13 +747,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
         v[k] = (k < per && gg < g1 && t < T_local) ? hist[(size_t)gg * T_local + t] : 0u;
         sum += v[k];
     }
-    // the 4 slices of a tile inside this wave sit 16 lanes apart: inclusive prefix over them
+    // the 64 / kScanTiles slices of a tile inside this wave sit kScanTiles lanes apart: inclusive prefix over them
     uint32_t incl = sum;
-    uint32_t o = (uint32_t)__shfl_up((int)incl, 16);
-    if (lane >= 16) incl += o;
-    o = (uint32_t)__shfl_up((int)incl, 32);
-    if (lane >= 32) incl += o;
-    if (lane >= 48) s_part[w][tl] = incl;   // the wave's total for tile tl
+#pragma unroll
+    for (int d = kScanTiles; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane >= 64 - kScanTiles) s_part[w][tl] = incl;   // the wave's total for tile tl
     __syncthreads();
     uint32_t run = incl - sum, total = 0;
 #pragma unroll
@@ -767,18 +775,21 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
     // stores (write-through: the XCDs' L2s are not coherent with each other), drained (vmcnt(0), which the
     // workgroup-scope release waits for) before the ticket; the total pass reads them with agent-scope loads.  A
     // full agent-scope fence here would write back every dirty line of the 4 MB of prefixes first: measured 61 us.
+    if (!A.ticket) {   // the total pass is a launch of its own
+        if (sl == 0 && t < T_local) tile_count[t] = total;
+        return;
+    }
     if (sl == 0 && t < T_local) __hip_atomic_store(&tile_count[t], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!A.ticket) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    tile_scan_total(A);
+    tile_scan_total<true>(A);
 }
 
 // The total pass alone (an empty band has no per-tile prefix to take)
-__global__ __launch_bounds__(1024) void k_tile_scan_total(ScanTotalArgs A) { tile_scan_total(A); }
+__global__ __launch_bounds__(1024) void k_tile_scan_total(ScanTotalArgs A) { tile_scan_total<false>(A); }
 
 template <bool PACK>
 __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
@@ -1506,8 +1517,17 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
                     (uint32_t *)wg_on_grid + kMaxG};
     if (p.T_local > 0) {
         // (the last workgroup to arrive runs the total pass)
-        hipLaunchKernelGGL(k_tile_scan_wg, dim3((unsigned)ms::ceil_div(p.T_local, kScanTiles)), dim3(1024), 0, stream,
-                           p.G, p.T_local, hist, count, A);
+        if (p.T_local <= 4096)
+            hipLaunchKernelGGL(k_tile_scan_wg<16>, dim3((unsigned)ms::ceil_div(p.T_local, 16)), dim3(1024), 0, stream,
+                               p.G, p.T_local, hist, count, A);
+        else {
+            // (and the total pass in a launch of its own: 17 us in two launches, 24 in one, on 8 160 tiles)
+            ScanTotalArgs A0 = A;
+            A0.ticket = nullptr;
+            hipLaunchKernelGGL(k_tile_scan_wg<64>, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
+                               p.G, p.T_local, hist, count, A0);
+            hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, A0);
+        }
     } else {
         A.ticket = nullptr;
         hipLaunchKernelGGL(k_tile_scan_total, dim3(1), dim3(1024), 0, stream, A);

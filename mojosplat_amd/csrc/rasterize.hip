@@ -803,6 +803,8 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
     if (after_raster_event) (void)hipEventRecord((hipEvent_t)after_raster_event, stream);
     if constexpr (CP <= 4) {
         // lazily sorted frame: redo the (normally zero) tiles whose front did not saturate them
+        // (measured by leaving it out: the launch costs the frame 2.4 us -- 0.1826 -> 0.1802 ms at config 3 -- although
+        // rocprofv3 shows the empty kernel at 4.5 us)
         if (A.lazy.front_count)
             hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(redo_grid(A)), dim3(256), 0, stream, A);
     }
