@@ -287,7 +287,7 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
     bg = None if background is None else _hip.f32c(background.reshape(-1))
     out = torch.empty((C, H, W, CD), dtype=torch.float32, device=dev)
     if C == 0:
-        return out, []
+        return out, [], None
     vms = torch.stack([c._viewmat_f32().to(dev) for c in cameras]).contiguous()       # (C, 4, 4) on the device
     intr = (ctypes.c_float * (4 * C))(*[v for c in cameras for v in (c.fx, c.fy, c.cx, c.cy)])
     th, tw = -(-H // tile_size), -(-W // tile_size)
@@ -327,7 +327,9 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
     for t in (out, means3d, scales, quats, op, colors, vms) + (() if bg is None else (bg,)):
         for s_ in streams[:n_lanes]:
             t.record_stream(s_)
-    return out, [int(c) for c in counts]
+    # the last view's size record on the first lane (for the binning rule): pairs, Gaussians on the grid, flags
+    h = sts[0]["host"]
+    return out, [int(c) for c in counts], dict(m=int(h[0]), on_grid=int(h[6]), flags=int(h[7]))
 
 
 _lanes = {}

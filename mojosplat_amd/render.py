@@ -277,5 +277,20 @@ def render_gaussians_batch(means3d, scales, quats, opacities, features, cameras,
                          f"channels ({C})")
     assert opacities.shape == (means3d.shape[0],)
     from ._fused import render_batch_hip
-    out, _ = render_batch_hip(means3d, scales, quats, opacities, features, list(cameras), bg, tile_size)
+    cameras = list(cameras)
+    # binning granularity: the same rule as render_gaussians (pixels do not depend on it), learnt per scene / image
+    # size from the batch's last view and shared with the single-view entry point
+    key, mode = None, tile_size
+    if tile_size == TILE_SIZE and cameras:
+        explicit = _env_bin_px()
+        if explicit is not None:
+            mode = explicit
+        else:
+            key = _bin_key(means3d, cameras[0])
+            with _bin_lock:
+                mode = _bin_mode.get(key, TILE_SIZE)
+    out, _, rec = render_batch_hip(means3d, scales, quats, opacities, features, cameras, bg, mode)
+    if key is not None and rec is not None:
+        grid = (32 if rec["flags"] & 8 else 16) if mode == TILE_SIZE else mode
+        _settle(key, mode, bin_rule(mode, rec["m"], rec["on_grid"], cameras[0].W, cameras[0].H, grid_px=grid))
     return out

@@ -1,0 +1,14 @@
+#!/bin/bash
+# The round's profile artefacts, on the GPU box from the repo root (outputs under gpurun_out/final_*):
+#   kernel stats of the default bench command, the un-profiled bench line (with extras), FETCH_SIZE / WRITE_SIZE passes
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/fp_stats /tmp/fp_fetch /tmp/fp_write
+python3 $R/bench.py --extras > $O/final_bench.json 2> $O/final_bench.err && echo "bench ok" &&
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fp_stats -- python3 $R/bench.py > $O/final_bench_under_rocprof.json 2> $O/final_prof.err &&
+cp $(find /tmp/fp_stats -name "*kernel_stats.csv" | head -1) $O/final_kernel_stats.csv && echo "stats ok" &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/fp_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-verify > /dev/null 2> $O/final_pmc_fetch.err &&
+python3 $R/scripts/pmc_summary.py $(find /tmp/fp_fetch -name "*counter_collection.csv" | head -1) > $O/final_pmc_fetch.txt && echo "fetch ok" &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/fp_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-verify > /dev/null 2> $O/final_pmc_write.err &&
+python3 $R/scripts/pmc_summary.py $(find /tmp/fp_write -name "*counter_collection.csv" | head -1) > $O/final_pmc_write.txt && echo "write ok"

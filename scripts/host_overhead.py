@@ -4,7 +4,6 @@ ms_render_fwd ctypes call (arguments marshalled once), on a scene so small the G
     python scripts/host_overhead.py
 """
 import cProfile
-import ctypes
 import os
 import pstats
 import sys
@@ -14,8 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import mojosplat_amd as ms  # noqa: E402
-from mojosplat_amd import _fused, _hip  # noqa: E402
-from mojosplat_amd.projection import EPS2D  # noqa: E402
+from mojosplat_amd import _fused  # noqa: E402
 from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1  # noqa: E402
 
 
@@ -37,22 +35,6 @@ def main():
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     print("render_gaussians        us/frame", round(timeit(lambda: ms.render_gaussians(*g, cam, background_color=bg, backend="hip")), 1))
     print("render_fwd_hip          us/frame", round(timeit(lambda: _fused.render_fwd_hip(*g, cam, bg, 16)), 1))
-
-    L = _hip.lib()
-    st = _fused._dev_state(dev, 0)
-    ws, isect, host = st["ws"], st["isect"], st["host"]
-    img = torch.empty((cam.H, cam.W, 3), device=dev)
-    vm = cam._viewmat_f32()
-    args = (2000, _hip.ptr(g[0]), _hip.ptr(g[1]), 1, _hip.ptr(g[2]), _hip.ptr(g[3]), _hip.ptr(g[4]), 0, 3,
-            _hip.ptr(vm), cam.fx, cam.fy, cam.cx, cam.cy, cam.W, cam.H, EPS2D, cam.near, cam.far, 16, 0, 8,
-            _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect), isect.numel(),
-            ctypes.c_void_p(host.data_ptr()), 0, _hip.ptr(img), None, ctypes.c_void_p(st["ev"].cuda_event),
-            _hip.stream(dev))
-    print("bare ms_render_fwd      us/frame", round(timeit(lambda: L.ms_render_fwd(*args)), 1))
-    noev = args[:-2] + (None, args[-1])
-    print("bare, stream-sync path  us/frame", round(timeit(lambda: L.ms_render_fwd(*noev)), 1))
-    print("torch.empty             us", round(timeit(lambda: torch.empty((cam.H, cam.W, 3), device=dev)), 2))
-    print("_hip.stream             us", round(timeit(lambda: _hip.stream(dev)), 2))
 
     from mojosplat_amd.distributed import render_gaussians_sharded
 
