@@ -486,6 +486,8 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             gi = (int)i;
             const ms::ProjOut o = ms::project_one(src, means3d, scales, quats, opacities, viewmat, P);
             reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
+            // (leaving the conics out -- a plain forward frame's rasteriser reads the records -- was measured: 32.0 ->
+            // 31.8 us, the kernel is VALU bound)
             conics[3 * i] = o.c0;
             conics[3 * i + 1] = o.c1;
             conics[3 * i + 2] = o.c2;

@@ -17,6 +17,14 @@
 //       a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
 //       = 4.1), so ~96 M instructions over 1024 SIMDs at 2.3 GHz are 164 us of pure issue time.
 //
+//   round 2  ready-made 48-byte records from the projection kernel, one wave per 8x8 QUAD (NQ = 1), compacted record
+//       streams, heaviest-first launch order: 96-102 us; then the select by underflow (fp32 denormals flushed in this
+//       file: alpha * 255 * 2^-126 is normal iff alpha >= 1/255), the transmittance carried as T * 2^126 so that the
+//       product is never scaled back, one stop test per pair of records, the blocks of a coarse tile on one XCD:
+//       15 VALU instructions per 64-pixel evaluation, 94-96 us (profiles/r02_raster_isa.md).
+//   The notes below describe the one-wave-per-block shape (NQ = 4), which the per-stage API and the backward's
+//   forward still use for dense lists; the kernel comment further down has the round-2 shape.
+//
 //   * ONE wave64 owns a 16x16 block; every lane carries four pixels (the same lane position in
 //     each of the four 8x8 quads), so a staged Gaussian is read from LDS once per block;
 //   * staging: 64 intersections per batch, one per lane.  The staging lane folds log2(e) into

@@ -11,9 +11,11 @@ so this is new design, MI355X-first:
     the output (in-place form, no staging copy).  Slabs are padded to `rows` tile rows; rows
     below H are never read;
   * the "no intersections anywhere -> zeros image" rule of the reference (render.py:73-76)
-    needs a frame-level fact; since every rank projects every Gaussian, the count pass reports
-    how many Gaussians touch the FULL tile grid (isect_info[6]) next to the band's own M, so
-    every rank reaches the same verdict locally: no flag collective, no extra device pass;
+    needs a frame-level fact.  A HIP band frame pre-culls the Gaussians that cannot reach its band
+    (csrc/binning.hip, k_band_precull) and reports how many of the REST touch the full grid, so the
+    fact is the OR over the ranks: one 4-byte all-reduce(MAX) enqueued beside the framebuffer gather;
+    only a rank whose own band holds nothing waits for its result.  (Injected CPU stages count over
+    all Gaussians and need no exchange.)
   * frames are independent, so the gather of frame k can overlap the render of frame k+1:
     `async_op=True` hands back a PendingFrame right after the all-gather is enqueued on RCCL's
     stream; the caller's stream only waits for it in `.wait()`.

@@ -61,7 +61,7 @@ def main():
                         cur.wait()
                     cur = nxt
                 cur.wait()
-            run(5)
+            run(24)   # (a rank's first pipelined frames grow its lanes' buffers and settle its bin size)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             run(args.steps)
