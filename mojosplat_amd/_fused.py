@@ -32,7 +32,10 @@ def _dev_state(dev, lane=0):
         ev = torch.cuda.Event()
         with torch.cuda.device(dev):
             ev.record()  # materialises the hipEvent_t the library re-records for its size hand-off
-        st = dict(ws=None, isect=None, host=torch.zeros(8, dtype=torch.int64).pin_memory(), ev=ev)
+        host = torch.zeros(8, dtype=torch.int64).pin_memory()
+        # host_np: the same pinned memory as a numpy array (reading a torch tensor element costs ~1.5 us, and a
+        # frame reads eight of them)
+        st = dict(ws=None, isect=None, host=host, host_np=host.numpy(), ev=ev)
         _state[(dev, lane)] = st
     return st
 
@@ -142,7 +145,7 @@ class _Frame:
     def finish(self, phase=FINISH, info=None):
         """-> (image, M) of the band.  Waits for the frame's size record, redoes the frame on the
         exact path if the speculation did not hold (growing the intersection buffer if needed)."""
-        st, host = self.st, self.st["host"]
+        st, host = self.st, self.st["host_np"]
         with _hip.on_device(self.dev):
             rc = self.run(phase)
             if rc == 2:  # MS_ERR_WORKSPACE: the intersection buffer is too small for this frame's M
@@ -328,7 +331,7 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
         for s_ in streams[:n_lanes]:
             t.record_stream(s_)
     # the last view's size record on the first lane (for the binning rule): pairs, Gaussians on the grid, flags
-    h = sts[0]["host"]
+    h = sts[0]["host_np"]
     return out, [int(c) for c in counts], dict(m=int(h[0]), on_grid=int(h[6]), flags=int(h[7]))
 
 

@@ -92,9 +92,18 @@ def _band_bin(means3d, camera, band, tile_size):
         return key, R._bin_mode.get(key, 16)
 
 
+_learnt = {}   # band key -> the last size record the rule was applied to (a static scene repeats it frame after frame)
+
+
 def _band_learn(key, mode, m, info, camera, band):
     if key is None:
         return
+    rec = (mode, m, info["on_grid"], info["flags"])
+    if _learnt.get(key) == rec:
+        return       # same record as the previous frame: the rule's answer stands
+    if len(_learnt) > 256:
+        _learnt.clear()
+    _learnt[key] = rec
     from . import render as R
     # (a frame at mode 16 is a split frame -- 32-px bins, flag bit 3 -- unless the band is too thin for that)
     grid = (32 if info["flags"] & 8 else 16) if mode == 16 else mode
@@ -139,6 +148,33 @@ class PendingFrame:
 
 
 _turn = {}  # device -> which of the two lanes the next asynchronous frame takes
+_events = {}  # (device, lane) -> (event the lane waits for before a band, event the caller waits for after it)
+
+
+_streams = {}  # (device index, raw handle) -> torch Stream object of that handle
+
+
+def _current_stream(dev):
+    """torch.cuda.current_stream(dev) without its ~5 us of Python per call: the raw handle of the current stream
+    is one C call, and the Stream object for a handle never changes."""
+    from . import _hip
+    if _hip._raw_stream is None:
+        return torch.cuda.current_stream(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    raw = _hip._raw_stream(idx)
+    st = _streams.get((idx, raw))
+    if st is None:
+        st = torch.cuda.current_stream(dev)
+        _streams[(idx, raw)] = st
+    return st
+
+
+def _lane_events(dev, lane):
+    e = _events.get((dev, lane))
+    if e is None:
+        e = (torch.cuda.Event(), torch.cuda.Event())
+        _events[(dev, lane)] = e
+    return e
 
 
 @torch.no_grad()
@@ -226,7 +262,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     # are addressed by handle and ordered with events; torch's current stream is never switched
     # (the context managers would cost more host time than the band's kernels take to launch).
     from ._fused import _Frame, _lane_streams
-    cur = torch.cuda.current_stream(dev)
+    cur = _current_stream(dev)
     lanes = _lane_streams(dev)
     lane = _turn.get(dev, 0)
     _turn[dev] = 1 - lane
@@ -241,19 +277,26 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     bkey, bmode = _band_bin(means3d, camera, my_band, tile_size)
     frame = _Frame(means3d, scales, quats, opacities, features, camera, bg, bmode, evs,
                    my_band, full, 1 + lane, s.cuda_stream, rows16=True)
-    s.wait_stream(cur)
+    # (persistent events per lane: Stream.wait_stream creates a fresh event per call, ~8 us of host time each)
+    ev_in, ev_out = _lane_events(dev, lane)
+    ev_in.record(cur)
+    s.wait_event(ev_in)
     frame.begin()
     # tensors allocated on the current stream and used on the lane: the caching allocator must not hand
     # their memory out again before the lane is done with it
+    seen = set()
     for t in (means3d, scales, quats, opacities, features, bg, full) + tuple(x for x in frame.keep[:-1] if x is not None):
-        t.record_stream(s)
+        if id(t) not in seen:     # (already-fp32 contiguous inputs ARE their marshalled copies)
+            seen.add(id(t))
+            t.record_stream(s)
 
     def finalize():
         info = {}
         _, m = frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
         _band_learn(bkey, bmode, m, info, camera, my_band)
-        now = torch.cuda.current_stream(dev)
-        now.wait_stream(s)           # the band is complete before the exchange starts
+        now = _current_stream(dev)
+        ev_out.record(s)
+        now.wait_event(ev_out)       # the band is complete before the exchange starts
         img, work = gather(full, info["on_grid"])   # RCCL's stream waits for `now`
         return resolve(img, work)                   # ... and `now` for the gather
     return PendingFrame(finalize=finalize)
