@@ -1453,6 +1453,9 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.T_local = (row_end - row_begin) * tw;
     p.lds_bytes = (size_t)p.T_local * 4 + 16;  // + the on-grid counter of the count kernels
     int64_t G = ms::ceil_div(N > 0 ? N : 1, MS_CHUNK);
+    // scenes too small to give every CU a workgroup at MS_CHUNK Gaussians each (100k: 49 workgroups on 256 CUs,
+    // k_project_hist 20.5 us against 32 for ten times as many): one step of kHistThreads Gaussians per workgroup
+    if (G < 256) G = ms::ceil_div(N > 0 ? N : 1, kHistThreads) < 256 ? ms::ceil_div(N > 0 ? N : 1, kHistThreads) : 256;
     G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
     if (p.lds_bytes > 64 * 1024 && G > 256) G = 256;
     p.chunk = ms::ceil_div(N > 0 ? N : 1, G);
