@@ -158,8 +158,10 @@ int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_t *radii,
  * selection use fixed depth buckets and skip a pass; 0, 0 = unknown.  Only ms_render_fwd's
  * rasteriser understands such lists (it redoes a tile whose front did not saturate its pixels);
  * pass lazy = 0 for lists that anyone else reads.  Bits 1-2 of `lazy`: front level, fronts 2^level
- * times as deep (up to the 4096 entries of LDS room).  MOJOSPLAT_LAZY_SORT=0 in the environment makes
- * ms_render_fwd sort fully. */
+ * times as deep (up to the 4096 entries of LDS room).  Bit 3 of `lazy` on the SPECULATIVE emit: the caller
+ * expects no tile of more than 1024 entries (its previous frame had none) -- only the short lists are
+ * sorted, and the caller must redo the frame if the size record then reports such tiles.
+ * MOJOSPLAT_LAZY_SORT=0 in the environment makes ms_render_fwd sort fully. */
 int ms_project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
                            const float *quats, const float *opacities, const float *viewmat, float fx,
                            float fy, float cx, float cy, int W, int H, float eps2d, float near_plane,

@@ -1754,8 +1754,12 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
         // plain bins: one merged launch over the band's tiles, heaviest first (MOJOSPLAT_MERGED_SORT=0: the two
         // launches, for measurements)
         static const bool merged_env = [] { const char *e = getenv("MOJOSPLAT_MERGED_SORT"); return !e || atoi(e) != 0; }();
-        const bool merged = merged_env && !bl.block_ids && p.T_local > 0;
-        if (merged || spec || n_medium + n_large + n_xl > 0) {
+        // no tile beyond the small class (known on the exact path; the caller's bet on a speculative frame,
+        // bit 3 of `lazy`): the 256-thread small-sort launch alone -- 7.8 us at config 2 against 14.6 for the merged
+        // launch, whose 512-thread workgroups are sized for the fronts
+        const bool no_heavy = !bl.block_ids && (spec ? (lazy & 8) != 0 : n_medium + n_large + n_xl == 0);
+        const bool merged = merged_env && !bl.block_ids && p.T_local > 0 && !no_heavy;
+        if (!no_heavy && (merged || spec || n_medium + n_large + n_xl > 0)) {
             auto front = bl.block_ids ? k_tile_front<true, false> : merged ? k_tile_front<false, true> : k_tile_front<false, false>;
             if (int rc = allow_big_lds(front)) return rc;
             const int64_t heavy = n_medium + n_large + n_xl;

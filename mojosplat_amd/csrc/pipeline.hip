@@ -242,9 +242,13 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                 host_info[7] = 1 | 8;
                 if (phase == MS_RENDER_BEGIN) return MS_OK;
             } else {
+            // the previous frame on this record (same scratch, same grid) had no tile beyond the small sort class:
+            // bet that this one has none either (bit 5 of host_info[7]; checked against the size record below)
+            const bool bet_light = lazy && prev[0] > 0 && prev[2] + prev[3] + prev[4] == 0 && !(prev[7] & 4);
             if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                          ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
-                                                         /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy, near_plane, far_plane, keys, ids, stream))
+                                                         /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy | (bet_light ? 8 : 0),
+                                                         near_plane, far_plane, keys, ids, stream))
                 return rc;
             mark(2);
             lazy_lists.keys = keys;
@@ -253,7 +257,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                                            render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr,
                                            records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
-            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0);
+            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0);
             }
         }
         if (phase == MS_RENDER_BEGIN) return MS_OK;
@@ -270,7 +274,9 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             const int64_t c = cap > cmax ? cmax : cap;
             const int64_t Ms = host_info[0];
             const bool large_ok = lazy || host_info[3] == 0 || (host_info[7] & 2);  // large class sorted iff launched
-            if (Ms > 0 && Ms <= c && (lazy || host_info[4] == 0) && large_ok) return MS_OK;  // the common case
+            // (bit 5: only the short lists were sorted -- holds iff the frame has no heavy tile)
+            const bool light_ok = !(host_info[7] & 32) || host_info[2] + host_info[3] + host_info[4] == 0;
+            if (Ms > 0 && Ms <= c && (lazy || host_info[4] == 0) && large_ok && light_ok) return MS_OK;  // the common case
             // else: empty scene, overflow or a tile needing the merge path -> exact path below
         }
     } else {

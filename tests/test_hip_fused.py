@@ -484,3 +484,35 @@ print("OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_light_frame_bet_is_repaired_when_heavy_tiles_appear(device):
+    """A frame whose predecessor (same scratch, same grid) had no list beyond the small sort class only launches
+    the small sorts (ms_render_fwd bets on it, bit 5 of the size record's flag word).  When the next scene DOES
+    hold heavy tiles -- the same number of Gaussians, fewer pairs, all in a few bins, so the intersection buffer
+    still fits and nothing else sends the frame to the exact path -- the bet fails, the frame is redone, and
+    the image is still the per-stage path's, bit for bit."""
+    _fused._state.clear()
+    N, W, H = 10_000, 640, 360
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    sc, cam = randscene_v1(N, W, H, ell=-3.5, seed=5, device=device)
+    args = lambda s: (s["means3d"], s["scales"], s["quats"], s["opacities"], s["features"])
+    for _ in range(3):   # settle on a grid; the last of these frames runs on the bet
+        a = ms.render_gaussians(*args(sc), cam, background_color=bg, bin_size=32)
+    st = _fused._dev_state(device, 0)
+    assert int(st["host_np"][2]) + int(st["host_np"][3]) + int(st["host_np"][4]) == 0, "the light scene must hold no heavy bin"
+    assert int(st["host_np"][7]) & 32, "the frame after a light frame runs on the bet"
+    assert torch.equal(a, stagewise(sc, cam, bg))
+    m_light = int(st["host_np"][0])
+    # the same Gaussians pulled towards the view axis and shrunk: fewer pairs, a few crowded bins
+    dense = dict(sc)
+    dense["means3d"] = sc["means3d"] * torch.tensor([0.12, 0.12, 1.0], device=device)
+    dense["scales"] = sc["scales"] - 1.2
+    b = ms.render_gaussians(*args(dense), cam, background_color=bg, bin_size=32)
+    heavy = int(st["host_np"][2]) + int(st["host_np"][3]) + int(st["host_np"][4])
+    assert heavy > 0 and int(st["host_np"][0]) <= 1.2 * m_light, (heavy, int(st["host_np"][0]), m_light)
+    assert int(st["host_np"][7]) & 4, "the failed bet sends the frame to the exact path"
+    assert torch.equal(b, stagewise(dense, cam, bg))
+    # and the frame after it (its predecessor had heavy bins) does not bet
+    b2 = ms.render_gaussians(*args(dense), cam, background_color=bg, bin_size=32)
+    assert not (int(st["host_np"][7]) & 32) and torch.equal(b, b2)
