@@ -273,6 +273,13 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  *                before it waits for frame k's size record.  Every frame in flight needs its
  *                own workspace, isect_buf, host_info and sync_event; host_info[7] is the
  *                library's own slot between BEGIN and FINISH.
+ *                The record a frame leaves in host_info is also the NEXT frame's hint when the same
+ *                host_info is passed again (what a caller that renders frame after frame does): its M
+ *                sizes nothing but launch shapes, and a previous frame without any list beyond the
+ *                small sort class (1024 entries) makes the library bet that this one has none either
+ *                and launch the short sorts alone -- a lost bet is read off this frame's own record
+ *                and the frame redone on the exact path, like an overflowing one.  Pass a zeroed
+ *                record to start afresh.
  *   stage_events: NULL, or 4 hipEvent_t recorded on `stream` at: start, after projection,
  *                after binning, after rasterisation (for in-situ kernel timing).
  * SPLIT FRAMES.  A plain forward frame (no render_alphas / last_ids, CDIM <= 4) at tile_size 16 over the
