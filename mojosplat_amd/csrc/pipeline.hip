@@ -254,7 +254,9 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             lazy_lists.keys = keys;
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
-                                           render_colors, render_alphas, last_ids, lazy ? &lazy_lists : nullptr,
+                                           render_colors, render_alphas, last_ids,
+                                           // (a light frame has no sorted FRONT a pixel could outlive: no clean-up launch)
+                                           lazy && !bet_light ? &lazy_lists : nullptr,
                                            records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0);
@@ -334,7 +336,8 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     lazy_lists.keys = keys;
     if (int rc = ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                                    tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
-                                   lazy ? &lazy_lists : nullptr, records, order, clip0, clip1,
+                                   lazy && host_info[2] + host_info[3] + host_info[4] > 0 ? &lazy_lists : nullptr,
+                                   records, order, clip0, clip1,
                                    (!speculated && stage_events) ? stage_events[3] : nullptr, stream))
         return rc;
     return MS_OK;
