@@ -437,3 +437,40 @@ def test_huge_tile_grid_is_binned_and_rendered_in_bands(device):
     ref = rasterize_gaussians_hip(to(m2), to(con), sc["features"], sc["opacities"], bg, ranges, ids, cam)
     assert (img - ref).abs().max().item() < 5e-3  # GPU projection vs oracle projection feed
     assert (img != bg).any()
+
+
+def test_alpha_threshold_sits_where_the_reference_puts_it(device):
+    """The blend loop selects alpha >= 1/255 without a compare: alpha * (255 * 2^-126) underflows to zero in a
+    kernel that flushes fp32 denormals exactly when alpha < fl(1/255) (scripts/ubench/flush_select.hip checks the
+    arithmetic for every float around the threshold).  Here the whole rasteriser is walked across the threshold:
+    4 096 Gaussians, each alone on its own pixel centre (so sigma = 0 and alpha = opacity, rasterization.mojo:138-145)
+    with opacities stepping ulp by ulp through 1/255.  The oracle blends iff opacity >= fl(1/255); the GPU's alpha is
+    exp2(log2(opacity)), two approximate instructions, so it may disagree within a few ulps of the threshold and
+    nowhere else -- and every pixel must be either exactly the background or blended with alpha >= 1/255."""
+    W = H = 64
+    n = W * H
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    m2 = np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], -1).astype(np.float32)
+    con = np.tile(np.array([400.0, 0.0, 400.0], np.float32), (n, 1))   # alpha falls below 1e-80 one pixel away
+    thr = np.float32(1.0) / np.float32(255.0)
+    bits = thr.view(np.uint32).astype(np.int64) + (np.arange(n) - n // 2)   # -2048 .. +2047 ulps around the threshold
+    op = bits.astype(np.uint32).view(np.float32)
+    col = np.tile(np.array([1.0, 0.5, 0.25], np.float32), (n, 1))
+    bg = np.array([0.0, 0.0, 0.0], np.float32)
+    dep = np.linspace(1.0, 2.0, n).astype(np.float32)
+    rad = np.ones((n, 2), np.int32)
+    ids, ranges = oracle.bin_tiles(m2, rad, dep, H, W, 16)
+    ref, _, _ = oracle.rasterize_fwd(m2, con, col, op, bg, ranges, ids, H, W, 16)
+    to = lambda a: torch.from_numpy(a).to(device)
+    img = np_(rasterize_gaussians_hip(to(m2), to(con), to(col), to(op), to(bg), to(ranges), to(ids),
+                                      simple_camera(device, H=H, W=W), 16))
+    red, ref_red = img[..., 0].ravel(), ref[..., 0].ravel()
+    hit, ref_hit = red != 0.0, ref_red != 0.0
+    assert np.array_equal(ref_hit, op >= thr)                      # the oracle's rule, restated
+    ulps = np.arange(n) - n // 2
+    disagree = hit != ref_hit
+    assert np.abs(ulps[disagree]).max(initial=0) <= 4, ulps[disagree]
+    assert (red[hit] >= float(thr) * (1 - 1e-6)).all()            # a blended pixel carries alpha >= 1/255
+    np.testing.assert_allclose(red[hit & ref_hit], ref_red[hit & ref_hit], rtol=2e-6)
+    print("alpha threshold: GPU / oracle disagree on", int(disagree.sum()), "of", n, "opacities, all within",
+          int(np.abs(ulps[disagree]).max(initial=0)), "ulps of 1/255")
