@@ -92,6 +92,14 @@ __device__ __forceinline__ float finish_channel(float pix255, float S, float bg)
     return __builtin_fmaf(pix255, ms::kInv255, tb);
 }
 
+// The blend loop's select needs fp32 denormals FLUSHED (ms::kFlushK).  build.py compiles this file with
+// -fgpu-flush-denormals-to-zero, which puts that into the kernel descriptor; the forward kernels also set the mode
+// field themselves (MODE[5:4] = 0: one scalar instruction per wave), so a build that lost the flag still selects
+// correctly, and tests/test_hip_parity.py::test_alpha_threshold_sits_where_the_reference_puts_it walks the threshold.
+__device__ __forceinline__ void flush_fp32_denormals() {
+    __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 0);   // hwreg(HW_REG_MODE, offset 4, size 2) = 0
+}
+
 __device__ __forceinline__ float load_color(const float *p) { return *p; }
 __device__ __forceinline__ float load_color(const __half *p) { return __half2float(*p); }
 
@@ -152,6 +160,7 @@ constexpr int kUnroll = MS_RASTER_UNROLL; // trips unrolled
 template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
 __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasterize_fwd(RasterArgs A) {
     static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
+    flush_fp32_denormals();
     // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
     // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
     // ...: dealt round-robin over the 8 XCDs, they land on ONE XCD back to back and share its L2 for the list they
@@ -549,6 +558,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     __shared__ float4 s_pa[256], s_pb[256];  // staged entries: mean.x mean.y a' b' | c' log2(o) - -
     __shared__ float s_pc[256 * CP];
     __shared__ int s_alive[4];
+    flush_fp32_denormals();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lx = lane & 7, ly = lane >> 3;
     const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
