@@ -107,8 +107,14 @@ def _band_learn(key, mode, m, info, camera, band):
     from . import render as R
     # (a frame at mode 16 is a split frame -- 32-px bins, flag bit 3 -- unless the band is too thin for that)
     grid = (32 if info["flags"] & 8 else 16) if mode == 16 else mode
-    R._settle(key, mode, R.bin_rule(mode, m, info["on_grid"], camera.W, max(16, (band[1] - band[0]) * 16),
-                                    band=True, grid_px=grid))
+    band_px = max(16, (band[1] - band[0]) * 16)
+    nxt = R.bin_rule(mode, m, info["on_grid"], camera.W, band_px, band=True, grid_px=grid)
+    if nxt == 64 and band_px < 256:
+        # a band under four rows of 64-px bins: the coarse grid's saving in pairs does not make up for the bin rows
+        # that stick out of the band (config 3 cut 8 ways, 144-px bands: 98 / 102 / 113 us at 16 / 32 / 64 px on the
+        # edge bands whose large near-camera footprints the rule sends to 64)
+        nxt = 32
+    R._settle(key, mode, nxt)
 
 
 def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size, band, out):

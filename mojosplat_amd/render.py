@@ -66,10 +66,10 @@ _bin_left = {}            # same key -> (the grid last switched away from, frame
 _bin_lock = threading.Lock()
 
 
-def _rule(d, e, k=1.0):
+def _rule(d, e, k=1.0, coarse=1.0):
     if d < _D_SPLIT * k:
         return 16
-    return 32 if d < _D_COARSE * k else 64
+    return 32 if d < _D_COARSE * k * coarse else 64
 
 
 def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int, band: bool = False, grid_px: Optional[int] = None) -> int:
@@ -97,8 +97,16 @@ def bin_rule(mode: int, m: int, on_grid: int, W: int, H: int, band: bool = False
             d = g * (math.sqrt(p * (H + d + g) / H) - 1.0)
         inside = H / (H + d + 16.0)
     e = on_grid * inside * (d / 16.0 + 1.0) ** 2 / (math.ceil(W / 16) * math.ceil(H / 16))
-    lo, hi = _rule(d, e, 1.0 - _DEAD_BAND), _rule(d, e, 1.0 + _DEAD_BAND)
-    return lo if lo == hi else mode     # inside a dead band: stay
+    # a rank's band pays the fixed costs of a frame for a fraction of its pixels: 64-px bins only win from ~26 px there
+    # (config 3 cut 4 ways, edge bands of 21-22 px footprints: 115 us at 32 px, 138 at 64; config 5 cut 4 or 8 ways,
+    # 29 px and up: 64 px wins on every band, by up to 12 %: scripts/band_bench.py)
+    coarse = 1.5 if band else 1.0
+    lo, hi = _rule(d, e, 1.0 - _DEAD_BAND, coarse), _rule(d, e, 1.0 + _DEAD_BAND, coarse)
+    if lo == hi:
+        return lo
+    # inside a dead band: stay -- unless the current grid is neither of the two the band lies between (a first frame
+    # on the default grid): then the coarser of them
+    return mode if mode in (lo, hi) else lo
 
 
 def _settle(key, mode, nxt):
