@@ -167,14 +167,19 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
     // all stage (speed only, never correctness)
     constexpr int WPB = 1;
     constexpr int kParts = 4 / NQ;
-    constexpr int CS = (CP == 3) ? 4 : CP;       // CP == 3: r, g ride in the second word; blue heads a third 16-byte word
+    // CP == 3: r, g ride in the second word; blue is a float of its own per slot (with the index in the batch beside
+    // it for a frame that keeps per-pixel records): a pair's two blues are ONE ds_read_b64, and staging writes 36 B
+    // per record, not 48 (the LDS array is 73 % busy in this kernel, SQ_LDS_IDX_ACTIVE)
+    // (measured against the 16-byte colour slot of before: 94.4 / 94.5 us against 94.2 / 94.8 -- no difference in time,
+    // 25 % less LDS per wave)
+    constexpr int CS = (CP == 3) ? (AUX ? 2 : 1) : CP;
     constexpr int kSlots = kBatch + kGroup;      // room for the neutral records that pad a list to a multiple of kGroup
     // One LDS block per (wave, quad): the records of the entries that REACH the quad, compacted in list order.
     // The three arrays sit at fixed offsets, so a record's words share one index * 16 B and the blend loop
     // reaches kGroup consecutive records from ONE address register through the instructions' offset fields.
     // (colours first: a pair's two blues are then within ds_read2_b32's 1 KB offset reach of the same address)
     struct Stage {
-        float col[kSlots * CS];  // CP == 3: (blue, index in batch, -, -)
+        __attribute__((aligned(16))) float col[(kSlots * CS + 3) & ~3];  // CP == 3: blue (, index in batch)
         float4 a[kSlots];        // mean.x, mean.y, a', b'
         float4 b[kSlots];        // c', log2(opacity), (r, g | index in batch, -)
     };
@@ -351,7 +356,10 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
                 S.a[pos] = r_a;
                 S.b[pos] = r_b;
-                if constexpr (CP == 3) reinterpret_cast<float4 *>(S.col)[pos] = r_c;
+                if constexpr (CP == 3) {
+                    if constexpr (AUX) reinterpret_cast<float2 *>(S.col)[pos] = make_float2(r_c.x, r_c.y);
+                    else S.col[pos] = r_c.x;
+                }
                 else {
 #pragma unroll
                     for (int k = 0; k < CP; ++k) S.col[pos * CS + k] = r_col[k];
@@ -360,7 +368,10 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
             if (lane < kGroup) {
                 S.a[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
                 S.b[n + lane] = make_float4(0.f, -kInf, 0.f, 0.f);   // log2(alpha) = -inf: alpha = 0, never a hit
-                if constexpr (CP == 3) reinterpret_cast<float4 *>(S.col)[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (CP == 3) {
+                    if constexpr (AUX) reinterpret_cast<float2 *>(S.col)[n + lane] = make_float2(0.f, 0.f);
+                    else S.col[n + lane] = 0.f;
+                }
                 else {
 #pragma unroll
                     for (int k = 0; k < CP; ++k) S.col[(n + lane) * CS + k] = 0.f;
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
                         rb[j] = S.b[k0 + j];
                         if constexpr (CP == 3) {
                             if constexpr (AUX) {
-                                const float2 c2 = reinterpret_cast<const float2 *>(S.col)[2 * (k0 + j)];
+                                const float2 c2 = reinterpret_cast<const float2 *>(S.col)[k0 + j];
                                 rc[j][0] = c2.x; rt[j] = __float_as_int(c2.y);
                             } else rc[j][0] = S.col[(k0 + j) * CS];
                         } else {
