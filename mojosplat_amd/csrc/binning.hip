@@ -16,15 +16,20 @@
 //
 //   k_isect_hist      G workgroups, each histograms a contiguous chunk of Gaussians into LDS
 //   k_project_hist    the same fused with the projection itself (what ms_render_fwd runs)
-//   k_tile_scan_wg    per tile: exclusive prefix over the G partial counts (16 waves split G)
-//   k_tile_scan_total one workgroup: exclusive scan over tiles -> tile_ranges, M, work lists
+//   k_tile_scan_wg    per tile: exclusive prefix over the G partial counts; on grids up to 4 096 tiles its last
+//                     workgroup to arrive also runs the total pass (tile_scan_total) in the same launch
+//   k_tile_scan_total one workgroup: exclusive scan over tiles -> tile_ranges, M, work lists, launch order, size
+//                     record (a launch of its own on larger grids and for empty bands)
 //   k_isect_scatter   same chunks; LDS cursors hand out slots inside each tile segment
 //   k_tile_sort_small one 256-thread workgroup per tile with <= 1024 entries (16 KB LDS)
 //   k_tile_sort_list  work lists of tiles with <= 8192 (74 KB LDS, two per CU) and <= 16384
 //                     entries (136 KB); fixed-size persistent grids on sync-free frames
 //   k_xl_*            tiles beyond that: LDS-sorted 16384-runs + binary-search merge rounds
 //   k_tile_front      lazily sorted frames (ms_render_fwd): only the nearest ~1024 entries of a heavy tile
-//                     are selected and sorted; the rasteriser flags tiles whose pixels outlive them
+//                     are selected and sorted; the rasteriser flags tiles whose pixels outlive them.
+//                     <false, true> (plain bins): ONE launch over the band's tiles, heaviest first, that also
+//                     sorts the short lists whole (instead of k_tile_front + k_tile_sort_small)
+//   chunk_of_block    workgroup -> chunk of the count / scatter kernels: XCD-contiguous (partial-write merging)
 //   <PACK> / <SPLIT>  kernel variants of split frames: 32-px bins whose keys carry the 4 block bits of
 //                     their entry and whose sorted lists leave the sort kernels as four 16x16-block
 //                     lists (emit_block_lists)
