@@ -151,6 +151,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef MS_RASTER_UNROLL
 #define MS_RASTER_UNROLL 2
 #endif
+#ifndef MS_RASTER_MINW_AUX
+#define MS_RASTER_MINW_AUX 7   // variants that keep per-pixel records: 8 waves per SIMD made them spill (two quads per wave: 5)
+#endif
 #ifndef MS_RASTER_MINW
 #define MS_RASTER_MINW 8
 #endif
@@ -158,9 +161,8 @@ constexpr int kGroup = MS_RASTER_GROUP;   // records evaluated per trip of the b
 constexpr int kUnroll = MS_RASTER_UNROLL; // trips unrolled
 
 template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
-__global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasterize_fwd(RasterArgs A) {
+__global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
     static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
-    flush_fp32_denormals();
     // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
     // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
     // ...: dealt round-robin over the 8 XCDs, they land on ONE XCD back to back and share its L2 for the list they
@@ -259,6 +261,9 @@ __global__ __launch_bounds__(64, (CP <= 4 ? MS_RASTER_MINW : 1)) void k_rasteriz
     if (A.lazy.front_count && end_all - start > A.lazy.front_threshold) end = start + min(A.lazy.front_count[tile], end_all - start);
     const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
     const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
+    // (here rather than at the kernel's first line: s_setreg is a scheduling barrier, and up there it cost the
+    // headline variant a spilled VGPR -- 8 MB of scratch writes per frame, WRITE_SIZE 25.7 -> 33.6 MB)
+    flush_fp32_denormals();
 
     // what the staging lane holds of its entry: the record's three words (PACKED), or the per-stage fields
     float4 r_a = make_float4(0.f, 0.f, 0.f, 0.f), r_b = r_a, r_c = r_a;

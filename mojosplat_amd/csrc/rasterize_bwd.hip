@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256) void k_rasterize_bwd(RasterBwdArgs A) {
 //     flush adds 4 whole rows per wave-instruction -- contiguous float atomics run ~17x faster
 //     than one-dword-per-row ones on MI355X (MI355X_MICROARCH.md, Global float atomics);
 //     k_unpack_grads then adds the rows into the caller's four gradient tensors.
+#ifndef MS_BWD_WAVES
+#define MS_BWD_WAVES 4
+#endif
 constexpr int kRow = 16;  // floats per packed gradient row: mx my ca cb cc op c0 c1 c2 c3 - - - - - -
 
 struct RasterBwd2Args {
@@ -279,7 +282,7 @@ __device__ __forceinline__ float wave_allreduce8(const float (&v)[8], int lane) 
 // NQ = quads per wave: 4 = one wave per 16x16 block; 2 = two waves per block (upper / lower strip; each stages the
 // list but blends only its quads): the longest wave's work halves and twice as many waves fill the slots.
 template <int CP, int NQ>
-__global__ __launch_bounds__(64, 4) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
+__global__ __launch_bounds__(64, MS_BWD_WAVES) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
     const RasterBwdArgs &A = B2.a;
     constexpr int NG = 6 + CP;
     constexpr int kParts = 4 / NQ;
