@@ -373,6 +373,30 @@ def main():
             extras["multi_view_batch16_views_per_s"] = round(64 / (time.perf_counter() - tb), 1)
         del sc5, g5
         torch.cuda.empty_cache()
+        if world > 1:
+            # not the headline either: the OTHER sharding axis -- whole views split over the ranks, one in-place
+            # all-gather per call (render_gaussians_batch_sharded).  No per-frame fixed cost grows with the rank count
+            # here; the exchange moves the same bytes per view as the band gather.
+            try:
+                from mojosplat_amd.distributed import render_gaussians_batch_sharded
+                sc, cam, g = load(args.workload)
+                cams = [cam] * (2 * world)
+                for _ in range(3):
+                    v = render_gaussians_batch_sharded(*g, cams, background_color=bg)
+                same = bool(torch.equal(v[rank], ms.render_gaussians(*g, cam, background_color=bg, backend="hip")))
+                barrier()
+                tb = time.perf_counter()
+                for _ in range(10):
+                    render_gaussians_batch_sharded(*g, cams, background_color=bg)
+                barrier()
+                tv = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=dev)
+                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+                extras["view_sharded"] = {"workload": f"{args.workload}, {2 * world} views per call split by view over {world} ranks",
+                                          "views_per_s": round(10 * 2 * world / float(tv.item()), 1),
+                                          "view_equals_single_gpu_frame": same}
+                del sc, g, v
+            except Exception as e:  # noqa: BLE001  (same inputs, same code on every rank: they fail alike)
+                extras["view_sharded"] = {"error": repr(e)}
 
     rc = 0
     if rank == 0:

@@ -264,7 +264,7 @@ def render_begin_hip(means3d, scales, quats, opacities, colors, camera, backgrou
 
 
 @torch.no_grad()
-def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, background, tile_size):
+def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, background, tile_size, out=None):
     """Render the same Gaussians from several cameras -> (C, H, W, channels) f32: ONE library call,
     ms_render_fwd_batch (the camera dimension the reference's kernels carry and its wrappers pin to 1).
 
@@ -288,7 +288,10 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
         cdt, colors = 0, _hip.f32c(colors)
     CD = colors.shape[1]
     bg = None if background is None else _hip.f32c(background.reshape(-1))
-    out = torch.empty((C, H, W, CD), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((C, H, W, CD), dtype=torch.float32, device=dev)
+    else:   # a caller-owned slab (the view-sharded multi-GPU path renders straight into its gather buffer)
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev and tuple(out.shape) == (C, H, W, CD)
     if C == 0:
         return out, [], None
     vms = torch.stack([c._viewmat_f32().to(dev) for c in cameras]).contiguous()       # (C, 4, 4) on the device

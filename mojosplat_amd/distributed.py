@@ -306,3 +306,39 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         img, work = gather(full, info["on_grid"])   # RCCL's stream waits for `now`
         return resolve(img, work)                   # ... and `now` for the gather
     return PendingFrame(finalize=finalize)
+
+
+@torch.no_grad()
+def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, cameras,
+                                   background_color: Optional[torch.Tensor] = None, tile_size: int = 16, group=None):
+    """Multi-view rendering sharded by VIEW instead of by tile row -- the second sharding axis SURVEY.md section 8(f)
+    row 4 names: the same Gaussians from C cameras, every rank returns all C views, (C, H, W, channels) f32.
+
+    Rank r renders the contiguous run of views [r * per, (r + 1) * per), per = ceil(C / world), with the multi-view
+    entry point (render_gaussians_batch: one library call, two views in flight) straight into its slab of a
+    (world * per, H, W, channels) buffer, and ONE in-place all_gather_into_tensor over RCCL completes it on every
+    rank.  Whole frames shard without any per-frame fixed cost growing with the rank count, which is what bounds the
+    tile-row bands of a small frame: the price is that the views must be known together, and the
+    exchange moves the same bytes per view as the band gather does.  The zeros-image rule is per view and local
+    (every rank renders whole frames).  Inputs must be identical on all ranks."""
+    from .render import render_gaussians_batch
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    cams = list(cameras)
+    C = len(cams)
+    dev = means3d.device
+    ch = features.shape[-1]
+    if C == 0:
+        return torch.empty((0, 0, 0, ch), dtype=torch.float32, device=dev)
+    H, W = cams[0].H, cams[0].W
+    if world == 1:
+        return render_gaussians_batch(means3d, scales, quats, opacities, features, cams,
+                                      background_color=background_color, tile_size=tile_size)
+    per = -(-C // world)
+    full = torch.empty((world * per, H, W, ch), dtype=torch.float32, device=dev)
+    mine = cams[rank * per:(rank + 1) * per]
+    if mine:
+        render_gaussians_batch(means3d, scales, quats, opacities, features, mine, background_color=background_color,
+                               tile_size=tile_size, out=full[rank * per:rank * per + len(mine)])
+    dist.all_gather_into_tensor(full, full[rank * per:(rank + 1) * per], group=group)   # in place, as the band gather
+    return full[:C]

@@ -261,7 +261,7 @@ def render_gaussians(
 
 @torch.no_grad()
 def render_gaussians_batch(means3d, scales, quats, opacities, features, cameras, background_color=None,
-                           tile_size: int = TILE_SIZE, backend: str = "hip") -> torch.Tensor:
+                           tile_size: int = TILE_SIZE, backend: str = "hip", out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Multi-view rendering: the same Gaussians from C cameras -> (C, H, W, channels).
 
     The reference's kernels carry a camera batch dimension but every wrapper pins C = 1
@@ -269,9 +269,13 @@ def render_gaussians_batch(means3d, scales, quats, opacities, features, cameras,
     section 8(f) row 4 asks for.  Image i equals ``render_gaussians(..., cameras[i])`` bit for
     bit (including the zeros image for a view with no intersections)."""
     if backend != "hip":
-        return torch.stack([render_gaussians(means3d, scales, quats, opacities, features, c,
+        imgs = torch.stack([render_gaussians(means3d, scales, quats, opacities, features, c,
                                              background_color=background_color, tile_size=tile_size,
                                              backend=backend) for c in cameras])
+        if out is not None:
+            out.copy_(imgs)
+            return out
+        return imgs
     required = [means3d, scales, quats, opacities, features]
     if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in required):
         raise ValueError("All input gaussian tensors must be CUDA tensors.")
@@ -297,7 +301,7 @@ def render_gaussians_batch(means3d, scales, quats, opacities, features, cameras,
             key = _bin_key(means3d, cameras[0])
             with _bin_lock:
                 mode = _bin_mode.get(key, TILE_SIZE)
-    out, _, rec = render_batch_hip(means3d, scales, quats, opacities, features, cameras, bg, mode)
+    out, _, rec = render_batch_hip(means3d, scales, quats, opacities, features, cameras, bg, mode, out=out)
     if key is not None and rec is not None:
         grid = (32 if rec["flags"] & 8 else 16) if mode == TILE_SIZE else mode
         _settle(key, mode, bin_rule(mode, rec["m"], rec["on_grid"], cameras[0].W, cameras[0].H, grid_px=grid))

@@ -39,6 +39,22 @@ try:
             assert torch.equal(cur.wait(), ref2), f"pipelined marshalled frame {k - 1} differs"
         cur = nxt
     assert torch.equal(cur.wait(), ref2)
+    # the other sharding axis: C views split over the ranks by view, one all-gather (render_gaussians_batch_sharded);
+    # C = 5 is not a multiple of 2 or 3 ranks, and one view looks away from the scene (the zeros-image rule is per view)
+    from mojosplat_amd.distributed import render_gaussians_batch_sharded
+    from mojosplat_amd.utils import Camera, look_at
+    eyes = [(0.0, 1.5, 5.0), (2.0, 1.0, 4.5), (-2.5, 2.0, 4.0), (0.5, -1.0, 6.0), (0.0, 1.5, 40.0)]
+    targets = [(0, 0, 0)] * 4 + [(0.0, 1.5, 80.0)]
+    cams = []
+    for e, t in zip(eyes, targets):
+        vm = look_at(torch.tensor(e), torch.tensor(t, dtype=torch.float32), torch.tensor([0.0, 1.0, 0.0]))
+        cams.append(Camera(R=vm[:3, :3].contiguous().to(dev), T=vm[:3, 3].contiguous().to(dev), H=cam.H, W=cam.W,
+                           fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, near=cam.near, far=cam.far))
+    views = render_gaussians_batch_sharded(*g, cams, background_color=bg)
+    assert views.shape == (5, cam.H, cam.W, 3)
+    for v, c in enumerate(cams):
+        assert torch.equal(views[v], ms.render_gaussians(*g, c, background_color=bg)), f"view {v} differs"
+    assert (views[4] == 0).all(), "a view that sees nothing is the zeros image"
     print(f"rank {rank}/{world}: sharded frames (blocking + pipelined) equal the single-GPU frame", flush=True)
 except Exception as e:
     print(f"rank {rank}: {type(e).__name__}: {e}", flush=True)
