@@ -386,8 +386,13 @@ def main():
                 same = bool(torch.equal(v[rank], ms.render_gaussians(*g, cam, background_color=bg, backend="hip")))
                 barrier()
                 tb = time.perf_counter()
-                for _ in range(10):
-                    render_gaussians_batch_sharded(*g, cams, background_color=bg)
+                pend = None
+                for _ in range(10):   # one call ahead: call k + 1 renders while call k's views are exchanged
+                    nxt = render_gaussians_batch_sharded(*g, cams, background_color=bg, async_op=True)
+                    if pend is not None:
+                        pend.wait()
+                    pend = nxt
+                pend.wait()
                 barrier()
                 tv = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=dev)
                 dist.all_reduce(tv, op=dist.ReduceOp.MAX)

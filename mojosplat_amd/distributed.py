@@ -310,7 +310,8 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
 
 @torch.no_grad()
 def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, cameras,
-                                   background_color: Optional[torch.Tensor] = None, tile_size: int = 16, group=None):
+                                   background_color: Optional[torch.Tensor] = None, tile_size: int = 16, group=None,
+                                   async_op: bool = False):
     """Multi-view rendering sharded by VIEW instead of by tile row -- the second sharding axis SURVEY.md section 8(f)
     row 4 names: the same Gaussians from C cameras, every rank returns all C views, (C, H, W, channels) f32.
 
@@ -320,7 +321,10 @@ def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, 
     rank.  Whole frames shard without any per-frame fixed cost growing with the rank count, which is what bounds the
     tile-row bands of a small frame: the price is that the views must be known together, and the
     exchange moves the same bytes per view as the band gather does.  The zeros-image rule is per view and local
-    (every rank renders whole frames).  Inputs must be identical on all ranks."""
+    (every rank renders whole frames).  Inputs must be identical on all ranks.
+    async_op=True returns a PendingFrame right after the gather is enqueued on the collective's stream: `.wait()`
+    makes the current stream wait for it and hands out the views, so the next call's rendering overlaps this call's
+    exchange (use it one call ahead, as with render_gaussians_sharded)."""
     from .render import render_gaussians_batch
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -332,13 +336,19 @@ def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, 
         return torch.empty((0, 0, 0, ch), dtype=torch.float32, device=dev)
     H, W = cams[0].H, cams[0].W
     if world == 1:
-        return render_gaussians_batch(means3d, scales, quats, opacities, features, cams,
-                                      background_color=background_color, tile_size=tile_size)
+        out = render_gaussians_batch(means3d, scales, quats, opacities, features, cams,
+                                     background_color=background_color, tile_size=tile_size)
+        return PendingFrame(image=out) if async_op else out
     per = -(-C // world)
     full = torch.empty((world * per, H, W, ch), dtype=torch.float32, device=dev)
     mine = cams[rank * per:(rank + 1) * per]
     if mine:
         render_gaussians_batch(means3d, scales, quats, opacities, features, mine, background_color=background_color,
                                tile_size=tile_size, out=full[rank * per:rank * per + len(mine)])
-    dist.all_gather_into_tensor(full, full[rank * per:(rank + 1) * per], group=group)   # in place, as the band gather
-    return full[:C]
+    # in place, as the band gather
+    work = dist.all_gather_into_tensor(full, full[rank * per:(rank + 1) * per], group=group, async_op=True)
+
+    def done():
+        work.wait()
+        return full[:C]
+    return PendingFrame(finalize=done) if async_op else done()

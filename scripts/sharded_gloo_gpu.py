@@ -55,6 +55,13 @@ try:
     for v, c in enumerate(cams):
         assert torch.equal(views[v], ms.render_gaussians(*g, c, background_color=bg)), f"view {v} differs"
     assert (views[4] == 0).all(), "a view that sees nothing is the zeros image"
+    pend = None
+    for k in range(3):   # one call ahead
+        nxt = render_gaussians_batch_sharded(*g, cams, background_color=bg, async_op=True)
+        if pend is not None:
+            assert torch.equal(pend.wait(), views), f"pipelined view batch {k - 1} differs"
+        pend = nxt
+    assert torch.equal(pend.wait(), views)
     print(f"rank {rank}/{world}: sharded frames (blocking + pipelined) equal the single-GPU frame", flush=True)
 except Exception as e:
     print(f"rank {rank}: {type(e).__name__}: {e}", flush=True)
