@@ -27,6 +27,20 @@ intersection count M is that of the lists the timed kernel is GIVEN (tight binni
 cannot blend; `algorithmic_bytes_gsplat_M` keeps round 1's figure on gsplat's M for comparison).
 `cpu_baseline` times the scalar C oracle (1 core) on frames of the same workload on this box's host
 and, beside it, the package's backend="torch" projection on CPU tensors (the reference's CPU path).
+
+`value` is K steps over the barrier-bracketed wall time of exactly those K steps (the contract);
+`ms_per_step` is the MEDIAN of the per-step periods (host time stamps taken as each call returns -- the
+host is paced by every frame's size record, so in steady state a period is a frame) when K >= 16, and
+`ms_per_step_mean` the plain wall time / K beside it (SURVEY 8(d) asks for a median).
+
+N = 1 also runs, after the timed region and unless --no-extras (what the rocprofv3 summaries under profiles/
+are taken with, so that their kernel averages are those of the headline frame alone):
+  extras.orbit          256 frames of the same scene from a camera on an orbit (a new view matrix every frame):
+                        frames/s, the miss counters of the sync-free path, four sampled frames verified bit for
+                        bit against the per-stage path;
+  extras.cfg3_fwd_bwd   BASELINE config 3 as it is named (forward + backward, grads for means / scales / quats /
+                        opacities / colours): ms per step, stage times from HIP events, rooflines of the two
+                        backward kernels on SURVEY 8(d)'s bytes.
 """
 import argparse
 import json
@@ -64,7 +78,8 @@ def parse_args(argv=None):
                     help="N=1: also time the multi-view batch entry point and config 5 (kept out of the default "
                          "run, whose rocprof kernel averages must match the timed workload); N>1 runs always "
                          "report config 5 (the config BASELINE names for 8 GPUs) under `extras`")
-    ap.add_argument("--no-extras", action="store_true", help="N>1: skip the config-5 leg")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N>1: skip the config-5 leg; N=1: skip the moving-camera and forward+backward legs")
     return ap.parse_args(argv)
 
 
@@ -271,12 +286,15 @@ def main():
         step()
     render_mod._STAGE_HOOK = hook   # (N > 1: the sharded entry point consults the same hook)
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    stamps = [0.0] * (args.steps + 1)
+    t0 = stamps[0] = time.perf_counter()
+    for k in range(args.steps):
         step()
+        stamps[k + 1] = time.perf_counter()   # (the call returns once the frame's size record is in: one frame behind the GPU)
     barrier()
     dt = time.perf_counter() - t0
     render_mod._STAGE_HOOK = None
+    periods = sorted(b - a for a, b in zip(stamps[1:-1], stamps[2:]))   # (the first period holds the pipeline's fill)
 
     # ---- verification of the timed path (untimed) -------------------------------------------------
     if world == 1:
@@ -316,8 +334,13 @@ def main():
         dist.all_reduce(vflag, op=dist.ReduceOp.MIN)
     dt = float(t.item())
     verified = bool(vflag.item())
-    ms_per_step = dt / args.steps * 1e3
+    ms_mean = dt / args.steps * 1e3
     fps = args.steps / dt
+    # the median per-step period (K >= 16, one GPU: the ranks of a sharded run are paced by their collectives, and
+    # the contract's max-over-ranks wall time is the figure there)
+    ms_per_step = ms_mean
+    if args.steps >= 16 and world == 1 and periods:
+        ms_per_step = periods[len(periods) // 2] * 1e3
 
     stage_us = {}
     if stage_events:
@@ -327,6 +350,15 @@ def main():
             for i, n in enumerate(("project", "bin", "raster_untimed_pass")):
                 v = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for evs in breakdown]
                 stage_us[n] = sum(v) / len(v)
+
+    # ---- N = 1, after the timed region: a moving camera, and config 3 as BASELINE names it (forward + backward) ----
+    legs = {}
+    if world == 1 and not args.no_extras:
+        legs["orbit"] = orbit_leg(ms, _fused, render_mod, g, cam, bg, stagewise, ms_mean)
+        if not fp16:
+            legs["cfg3_fwd_bwd" if args.workload == "cfg3" else args.workload + "_fwd_bwd"] = \
+                fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev)
+        verified = verified and legs["orbit"]["sampled_frames_bit_identical_to_stagewise"]
 
     # ---- extras: config 5 (the config BASELINE names for 8 GPUs) ----------------------------------
     extras = None
@@ -415,36 +447,48 @@ def main():
         roofline = None
         if "raster" in stage_us:
             ach = b_raster / (stage_us["raster"] * 1e-6) / 1e9
-            traffic = None
+            # HBM bytes of the kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, scripts/collect_profiles.sh): a stored
+            # measurement, tied to the kernel sources it was taken on -- sources that have changed since void it
+            traffic, traffic_note = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and world == 1:   # measured on the whole frame
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("rasterize_fwd_bytes")
+                rec = json.load(open(tpath)).get(args.workload, {})
+                have = csrc_sha16()
+                if rec.get("csrc_sha16") == have:
+                    traffic = rec.get("rasterize_fwd_bytes")
+                    traffic_note = f"PMC passes on csrc {have} (commit {rec.get('commit', '?')}), profiles/{rec.get('source', 'traffic.json')}"
+                else:
+                    traffic_note = (f"null: profiles/traffic.json was measured on csrc {rec.get('csrc_sha16')}, "
+                                    f"this library is built from csrc {have}")
             roofline = {"bound": "hbm", "kernel": "k_rasterize_fwd" + ("" if world == 1 else " (rank 0's band)"),
                         "achieved": round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "algorithmic_bytes": b_raster,
+                        "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes": b_raster,
                         "intersections_in_kernel_lists": m_kernel,
                         "algorithmic_bytes_gsplat_M": b_raster_gsplat,
                         "frac_gsplat_M": round(b_raster_gsplat / (stage_us["raster"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "avg_kernel_us": round(stage_us["raster"], 1), "instrumented_launches": len(stage_events),
                         "alpha_evals": 256 * m_kernel,
-                        "frame": {"algorithmic_bytes": b_frame,
-                                  "achieved": round(b_frame / (ms_per_step * 1e-3) / 1e9, 1),
-                                  "frac": round(b_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "frame": {"algorithmic_bytes": b_frame, "on": "ms_per_step_mean (wall time of the K steps / K)",
+                                  "achieved": round(b_frame / (ms_mean * 1e-3) / 1e9, 1),
+                                  "frac": round(b_frame / (ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                         "stage_us": {k: round(v, 1) for k, v in stage_us.items()}}
         cpu = None
         verification = {"bit_identical_to_stagewise": verified, "max_abs_vs_stagewise": max_abs}
         if world == 1 and not (args.no_cpu_baseline and args.no_verify):
             sc, cam, g = load(args.workload)
-            cpu, oracle_check = cpu_baseline(sc, cam, W, H, BACKGROUND_V1, args.workload,
+            cpu, ocheck = cpu_baseline(sc, cam, W, H, BACKGROUND_V1, args.workload,
                                              img if not args.no_verify else None, not args.no_cpu_baseline)
-            if oracle_check is not None:
-                verification["oracle"] = oracle_check
-                verified = verified and oracle_check["unexplained_px"] == 0
+            if ocheck is not None:
+                verification["oracle"] = ocheck
+                verified = verified and ocheck["unexplained_px"] == 0 and ocheck["within_flip_cap"]
         out = {
             "metric": "frames/sec at 1M Gaussians 1920x1080 fwd; achieved HBM GB/s vs peak",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_step_mean": round(ms_mean, 4),
+            "timing": "value = steps / wall time of the timed region; ms_per_step = median per-step period"
+                      if ms_per_step != ms_mean else "value = steps / wall time of the timed region = 1000 / ms_per_step",
+            "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearse else ""),
             "config": {"workload": f"{args.workload}: randscene-v1 N={N} {W}x{H} ell={ell} seed=42 forward",
@@ -454,7 +498,8 @@ def main():
             "verified": verified, "max_abs_vs_stagewise": max_abs, "verification": verification,
             "rccl": None if world == 1 else {"world": dist.get_world_size(), "backend": dist.get_backend(),
                                              "devices": "all ranks on cuda:0 (rehearsal)" if rehearse else "one per rank"},
-            "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "extras": (dict(extras or {}, **legs) or None),
         }
         print(json.dumps(out), flush=True)
         if not verified:
@@ -468,6 +513,167 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(rc)
+
+
+def orbit_leg(ms, _fused, render_mod, g, cam, bg, stagewise, static_ms, frames=256):
+    """The same scene from a camera that moves every frame (the reference's callers render changing views:
+    render_sample.py:60-71, examples/benchmark_proj.py:124-145): one orbit around the scene at the static camera's
+    radius and height, `frames` poses, a new view matrix per frame.  Everything the sync-free path bets on from the
+    previous frame's size record (buffer capacity, "no heavy tile", front depth, the binning rule's grid) is now a
+    bet against a DIFFERENT frame: the counters say how often it was lost."""
+    import math
+
+    import torch
+
+    from mojosplat_amd.utils import Camera, look_at
+    dev = g[0].device
+    c = cam._campos()
+    radius, height = math.hypot(c[0], c[2]), c[1]
+    cams = []
+    for k in range(frames):
+        th = 2.0 * math.pi * k / frames
+        vm = look_at(torch.tensor([radius * math.sin(th), height, radius * math.cos(th)]), torch.zeros(3),
+                     torch.tensor([0.0, 1.0, 0.0]))
+        cams.append(Camera(R=vm[:3, :3].contiguous().to(dev), T=vm[:3, 3].contiguous().to(dev), H=cam.H, W=cam.W,
+                           fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, near=cam.near, far=cam.far))
+    for cm in cams:
+        cm._viewmat_f32()      # the 64-byte device copy of each pose exists before the clock starts
+    key = render_mod._bin_key(g[0], cam)
+    host = _fused._state[(dev, 0)]["host_np"]
+    for cm in cams[-8:]:       # approach the start of the orbit
+        ms.render_gaussians(*g, cm, background_color=bg, backend="hip")
+    torch.cuda.synchronize()
+    sample = {0, frames // 3, 2 * frames // 3, frames - 1}
+    kept, ms_pairs, modes, switches = {}, [], [], 0
+    stats = _fused.FRAME_STATS = {}
+    stamps = [time.perf_counter()]
+    for k, cm in enumerate(cams):
+        mode = render_mod._bin_mode.get(key, 16)
+        img = ms.render_gaussians(*g, cm, background_color=bg, backend="hip")
+        stamps.append(time.perf_counter())
+        ms_pairs.append(int(host[0]))
+        switches += bool(modes and modes[-1] != mode)
+        modes.append(mode)
+        if k in sample:
+            kept[k] = img      # (a reference to the frame as rendered here, no copy)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - stamps[0]
+    _fused.FRAME_STATS = None
+    periods = sorted(b - a for a, b in zip(stamps[1:-1], stamps[2:]))
+    same = True
+    for k, img in sorted(kept.items()):
+        ref, _, _ = stagewise(g, cams[k])
+        same = same and bool(torch.equal(img, ref))
+    fps = frames / dt
+    out = {"what": f"{frames} frames, camera on one orbit of the scene (radius {radius:.2f}, height {height:.2f}), a new "
+                   "view matrix every frame; render_gaussians(backend='hip') per frame, blocking API",
+           "frames": frames, "frames_per_s": round(fps, 1), "ms_per_frame_mean": round(dt / frames * 1e3, 4),
+           "ms_per_frame_median": round(periods[len(periods) // 2] * 1e3, 4),
+           "vs_static_camera": round((dt / frames * 1e3) / static_ms, 3),
+           "pairs_min_max": [min(ms_pairs), max(ms_pairs)], "bin_px_used": sorted(set(modes)),
+           "bin_rule_switches": int(switches),
+           "misses": {k: int(stats.get(k, 0)) for k in ("frames", "speculated", "redone_exact", "overflow", "light_bet_lost",
+                                                       "other_miss", "buffer_grown", "redo_tiles", "front_level_up",
+                                                       "full_sort_on")},
+           "sampled_frames": sorted(kept), "sampled_frames_bit_identical_to_stagewise": same}
+    return out
+
+
+def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=6):
+    """BASELINE config 3 as named: forward + backward, grads for means / scales / quats / opacities / colours
+    (dL/dimage = rand(H, W, 3), seed 43: SURVEY 8(d)).  ms per step over `steps` un-instrumented steps; stage times
+    from HIP events on the launch stream in a separate short pass (an event between two kernels costs a bubble)."""
+    import torch
+
+    from mojosplat_amd import autograd as ag
+    leaves = [t.float().clone().requires_grad_(True) for t in g]
+    v_img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(43)).to(dev)
+    host = _fused._state[(dev, 0)]["host_np"]
+
+    def step():
+        for l in leaves:
+            l.grad = None
+        img = ag.render_gaussians_trainable(*leaves, cam, background_color=bg)
+        (img * v_img).sum().backward()
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    stamps = [time.perf_counter()]
+    for _ in range(steps):
+        step()
+        torch.cuda.synchronize()      # a training step ends with its gradients
+        stamps.append(time.perf_counter())
+    dt = stamps[-1] - stamps[0]
+    periods = sorted(b - a for a, b in zip(stamps[:-1], stamps[1:]))
+    m_lists = int(host[0])            # pairs on the differentiable frame's lists (16-px tiles, tight binning)
+    finite = all(bool(torch.isfinite(l.grad).all()) for l in leaves)
+    # stage times
+    n_ev = 10
+    fev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
+    bev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
+    for evs in fev + bev:
+        for e in evs:
+            e.record()
+    torch.cuda.synchronize()
+    fi, bi = iter(fev), iter(bev)
+    render_mod._STAGE_HOOK = lambda: next(fi)
+    ag._BWD_HOOK = lambda: next(bi)
+    for _ in range(n_ev):
+        step()
+    torch.cuda.synchronize()
+    render_mod._STAGE_HOOK = None
+    ag._BWD_HOOK = None
+    mean = lambda v: sum(v) / len(v)
+    us = {"fwd_project_count": mean([e[0].elapsed_time(e[1]) for e in fev]) * 1e3,
+          "fwd_bin": mean([e[1].elapsed_time(e[2]) for e in fev]) * 1e3,
+          "fwd_raster": mean([e[2].elapsed_time(e[3]) for e in fev]) * 1e3,
+          "bwd_raster_call": mean([e[0].elapsed_time(e[1]) for e in bev]) * 1e3,
+          "bwd_project": mean([e[1].elapsed_time(e[2]) for e in bev]) * 1e3}
+    b_rbwd = 40 * m_lists + 24 * H * W + 36 * N
+    b_pbwd = 108 * N
+    return {"what": "render_gaussians_trainable forward + (img * v).sum().backward(), grads for means3d / scales / quats / "
+                    "opacities / colours; every step synchronised (a training step ends with its gradients)",
+            "steps": steps, "ms_per_step_mean": round(dt / steps * 1e3, 4),
+            "ms_per_step_median": round(periods[len(periods) // 2] * 1e3, 4), "grads_finite": finite,
+            "pairs_on_lists": m_lists,
+            "stage_us": {k: round(v, 1) for k, v in us.items()},
+            "stage_us_note": "HIP events on the launch stream, separate pass of 10 steps; bwd_raster_call = k_bwd_order + "
+                             "k_rasterize_bwd_v2 + k_unpack_grads (one library call)",
+            "roofline": {"bwd_raster": {"bound": "hbm", "algorithmic_bytes": b_rbwd, "formula": "40 M + 24 HW + 36 N",
+                                        "achieved": round(b_rbwd / (us["bwd_raster_call"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": round(b_rbwd / (us["bwd_raster_call"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "bwd_project": {"bound": "hbm", "algorithmic_bytes": b_pbwd, "formula": "108 N",
+                                         "achieved": round(b_pbwd / (us["bwd_project"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": round(b_pbwd / (us["bwd_project"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}}
+
+
+def csrc_sha16():
+    """sha256[:16] over the kernel sources the library is built from (csrc/*.hip, *.hpp, the C header)."""
+    import hashlib
+    d = os.path.join(ROOT, "mojosplat_amd", "csrc")
+    files = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".hpp")))
+    h = hashlib.sha256()
+    for f in files + [os.path.join("..", "..", "include", "mojosplat_hip.h")]:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def oracle_check(gpu_img, ref, margin, *, atol=1e-4, eps=2e-5, flip_cap=1e-2):
+    """The suite's end-to-end bar (tests/helpers.py check_image_strict with eps = 2e-5, as tests/test_hip_configs.py
+    and __graft_entry__.smoke use it): a pixel may differ from the oracle's by more than atol only where a branch of
+    the oracle's walk sits within eps of its threshold; even those are capped at flip_cap."""
+    import numpy as np
+    diff = np.abs(gpu_img.astype(np.float64) - ref.astype(np.float64)).max(-1)
+    bad = diff > atol
+    sens = margin < eps
+    return {"max_abs": float(diff.max()), "px_beyond_1e-4": int(bad.sum()),
+            "explained_by_branch_margin": int((bad & sens).sum()), "unexplained_px": int((bad & ~sens).sum()),
+            "max_abs_where_no_branch_is_close": float(diff[~sens].max()) if (~sens).any() else 0.0,
+            "margin_eps": eps, "flip_cap": flip_cap, "within_flip_cap": bool(diff.max() <= flip_cap),
+            "what": "GPU frame (its own projection) vs oracle.render_fwd end to end; tests/helpers.py "
+                    "check_image_strict's rule with the suite's end-to-end eps"}
 
 
 def cpu_baseline(sc, cam, W, H, bg, workload, gpu_img, timed):
@@ -492,13 +698,7 @@ def cpu_baseline(sc, cam, W, H, bg, workload, gpu_img, timed):
     if gpu_img is not None:
         # all host threads here: this is the checker, not the baseline
         ref, aux = oracle.render_fwd(*full, vm, cam.fx, cam.fy, cam.cx, cam.cy, W, H, background=bgn, margin=True)
-        diff = np.abs(gpu_img.float().cpu().numpy() - ref).max(-1)
-        bad = diff > 1e-4
-        sens = aux["margin"] < 1e-4          # a branch of the walk within 1e-4 of its threshold
-        check = {"max_abs": float(diff.max()), "px_beyond_1e-4": int(bad.sum()),
-                 "explained_by_branch_margin": int((bad & sens).sum()), "unexplained_px": int((bad & ~sens).sum()),
-                 "max_abs_where_no_branch_is_close": float(diff[~sens].max()), "margin_eps": 1e-4,
-                 "what": "GPU frame (its own projection) vs oracle.render_fwd end to end, tests/helpers.py rule"}
+        check = oracle_check(gpu_img.float().cpu().numpy(), ref, aux["margin"])
     rec = None
     if timed:
         args = tuple(a[:n] for a in full)

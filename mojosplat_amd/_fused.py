@@ -54,6 +54,43 @@ def _grow(st, key, nbytes, dev, slack=1.0):
     return buf
 
 
+# Optional frame statistics (bench.py's moving-camera leg): set to a dict and every finished frame adds to its
+# counters -- how often a sync-free frame's bets were lost and what that cost.  None (the default): nothing is counted.
+#   frames            frames finished
+#   speculated        ... whose emit + rasterise were enqueued before the size record was known
+#   redone_exact      ... of those, redone on the exact path (the speculation did not hold)
+#   overflow          ... because the frame held more pairs than the intersection buffer had room for
+#   light_bet_lost    ... because a frame that bet on "no heavy tile" (short sorts only) had one
+#   other_miss        ... any other reason (a tile class that was not launched, an empty frame)
+#   buffer_grown      frames that had to grow the intersection buffer (a subset of overflow / first frames)
+#   redo_tiles        tiles the clean-up pass redid (reported one frame late by the library; exact-path frames excluded)
+#   front_level_up / full_sort_on   the lane's lazy-sorting mode escalated
+FRAME_STATS = None
+
+
+def _count_frame(stats, frame, host, grew):
+    flags, heavy = int(host[7]), int(host[2]) + int(host[3]) + int(host[4])
+    stats["frames"] = stats.get("frames", 0) + 1
+    if grew:
+        stats["buffer_grown"] = stats.get("buffer_grown", 0) + 1
+    if flags & 1:
+        stats["speculated"] = stats.get("speculated", 0) + 1
+        if flags & 4:
+            stats["redone_exact"] = stats.get("redone_exact", 0) + 1
+            isect = frame.isect if frame.own else frame.st["isect"]
+            nbytes = 0 if isect is None else isect.numel()
+            cap = (nbytes - 768) // 28 if flags & 8 else (nbytes - 512) // 12
+            if grew or int(host[0]) > cap:
+                why = "overflow"
+            elif (flags & 32) and heavy > 0:
+                why = "light_bet_lost"
+            else:
+                why = "other_miss"
+            stats[why] = stats.get(why, 0) + 1
+    if not flags & 4:
+        stats["redo_tiles"] = stats.get("redo_tiles", 0) + int(host[5])
+
+
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
 FULL_SORT = 0x100
 FRONT_LEVEL = 0x200  # x level (0..3): deeper lazily sorted fronts
@@ -146,10 +183,12 @@ class _Frame:
         """-> (image, M) of the band.  Waits for the frame's size record, redoes the frame on the
         exact path if the speculation did not hold (growing the intersection buffer if needed)."""
         st, host = self.st, self.st["host_np"]
+        grew = False
         with _hip.on_device(self.dev):
             rc = self.run(phase)
             if rc == 2:  # MS_ERR_WORKSPACE: the intersection buffer is too small for this frame's M
                 need = int(host[5])
+                grew = need > 0
                 if self.own:
                     if need > 0:
                         # the speculative kernels may still be running on the old block
@@ -173,6 +212,8 @@ class _Frame:
         # full sorts.  (The count lives in the lane's workspace, whose layout follows the frame's shape: it
         # only means something when the previous frame had the same shape, and a new shape starts afresh.)
         heavy = int(host[2]) + int(host[3]) + int(host[4])
+        if FRAME_STATS is not None:
+            _count_frame(FRAME_STATS, self, host, grew)
         if not self.own:
             same_shape = st.get("shape") == self.shape
             memo = st.setdefault("learnt", {})   # shape -> (full_sort, front_level): a lane that alternates between
@@ -182,8 +223,12 @@ class _Frame:
                   and st.get("prev_level") == st.get("front_level", 0)):
                 if int(host[5]) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
                     st["full_sort"] = True
+                    if FRAME_STATS is not None:
+                        FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
                 else:
                     st["front_level"] = st.get("front_level", 0) + 1
+                    if FRAME_STATS is not None:
+                        FRAME_STATS["front_level_up"] = FRAME_STATS.get("front_level_up", 0) + 1
             st["shape"], st["prev_level"] = self.shape, (self.level if not self.mode & FULL_SORT else None)
             memo[self.shape] = (bool(st.get("full_sort")), int(st.get("front_level", 0)))
             if len(memo) > 64:
@@ -328,6 +373,10 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
                     continue
                 _hip.check(rc, "ms_render_fwd_batch")
                 break
+        # the batch ran on these lanes at the default sorting mode and on ITS grid: what the lanes had learnt about the
+        # frames of another caller (the asynchronous band path shares them) no longer describes their workspaces
+        for st in sts:
+            st["shape"] = None
     for s_ in streams[:n_lanes]:
         cur.wait_stream(s_)
     for t in (out, means3d, scales, quats, op, colors, vms) + (() if bg is None else (bg,)):

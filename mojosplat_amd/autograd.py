@@ -93,6 +93,12 @@ class _RasterizeHip(torch.autograd.Function):
         return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None
 
 
+# bench.py installs a callable here that returns 3 (already recorded once) torch.cuda.Event objects per backward:
+# they are re-recorded on the launch stream before the backward rasteriser, between it and the backward projection,
+# and after that.  None = no events.
+_BWD_HOOK = None
+
+
 class _RenderFusedHip(torch.autograd.Function):
     """The whole differentiable frame around ONE forward library call (ms_render_fwd with the
     backward's per-pixel records): fused projection + counting, tight binning, sync-free emit and
@@ -101,8 +107,10 @@ class _RenderFusedHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3d, scales, quats, opacities, colors, background, camera, tile_size):
         from ._fused import WHOLE, _Frame
+        from . import render as _render   # bench.py's in-situ stage timing hook (None otherwise)
+        evs = _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None
         frame = _Frame(means3d.detach(), scales.detach(), quats.detach(), opacities.detach(), colors.detach(),
-                       camera, background, tile_size, None, None, None, 0, own=True)
+                       camera, background, tile_size, evs, None, None, 0, own=True)
         info = {}
         img, M = frame.finish(WHOLE, info)
         ctx.empty = info["on_grid"] == 0
@@ -136,17 +144,24 @@ class _RenderFusedHip(torch.autograd.Function):
         v_scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
         v_quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
         vm = cam._viewmat_f32().to(dev)
+        bev = _BWD_HOOK() if _BWD_HOOK is not None else None
         with _hip.on_device(dev):
             st = _hip.stream(dev)
+            if bev:
+                bev[0].record()
             _hip.check(L.ms_rasterize_to_pixels_3dgs_bwd(
                 N, ids.numel(), _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(col), C, _hip.ptr(op), _hip.ptr(bg),
                 cam.W, cam.H, ts, _hip.ptr(ranges), _hip.ptr(ids), _hip.ptr(alphas), _hip.ptr(last),
                 _hip.ptr(v_img), None, _hip.ptr(v_means2d), _hip.ptr(v_conics), _hip.ptr(v_colors),
                 _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes, 1, st), "ms_rasterize_to_pixels_3dgs_bwd")
+            if bev:
+                bev[1].record()
             _hip.check(L.ms_project_gaussians_bwd(
                 N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(vm), cam.fx, cam.fy, cam.cx, cam.cy,
                 cam.W, cam.H, EPS2D, _hip.ptr(radii), _hip.ptr(v_means2d), _hip.ptr(v_conics), None,
                 _hip.ptr(v_means3d), _hip.ptr(v_scales), _hip.ptr(v_quats), st), "ms_project_gaussians_bwd")
+            if bev:
+                bev[2].record()
         v_bg = None
         if bg is not None and ctx.needs_input_grad[5]:
             v_bg = ((1.0 - alphas)[..., None] * v_img).sum(dim=(0, 1))

@@ -779,14 +779,17 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
         }
     }
     // The hand-off to the last workgroup is the tile counts alone (the prefixes are for the next KERNEL): agent-scope
-    // stores (write-through: the XCDs' L2s are not coherent with each other), drained (vmcnt(0), which the
-    // workgroup-scope release waits for) before the ticket; the total pass reads them with agent-scope loads.  A
-    // full agent-scope fence here would write back every dirty line of the 4 MB of prefixes first: measured 61 us.
+    // stores (write-through: the XCDs' L2s are not coherent with each other), DRAINED by the storing wave itself --
+    // an explicit s_waitcnt vmcnt(0): a workgroup-scope release fence only waits on lgkmcnt in this mode, so without
+    // it the ticket could become visible on another XCD before the counts have landed -- then the barrier, then the
+    // ticket; the total pass reads the counts with agent-scope loads.  A full agent-scope fence here would write back
+    // every dirty line of the 4 MB of prefixes first: measured 61 us.
     if (!A.ticket) {   // the total pass is a launch of its own
         if (sl == 0 && t < T_local) tile_count[t] = total;
         return;
     }
     if (sl == 0 && t < T_local) __hip_atomic_store(&tile_count[t], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have been acknowledged
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;

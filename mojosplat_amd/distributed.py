@@ -98,13 +98,14 @@ _learnt = {}   # band key -> the last size record the rule was applied to (a sta
 def _band_learn(key, mode, m, info, camera, band):
     if key is None:
         return
-    rec = (mode, m, info["on_grid"], info["flags"])
-    if _learnt.get(key) == rec:
-        return       # same record as the previous frame: the rule's answer stands
-    if len(_learnt) > 256:
-        _learnt.clear()
-    _learnt[key] = rec
     from . import render as R
+    rec = (mode, m, info["on_grid"], info["flags"])
+    with R._bin_lock:
+        if _learnt.get(key) == rec:
+            return       # same record as the previous frame: the rule's answer stands
+        if len(_learnt) > 256:
+            _learnt.clear()
+        _learnt[key] = rec
     # (a frame at mode 16 is a split frame -- 32-px bins, flag bit 3 -- unless the band is too thin for that)
     grid = (32 if info["flags"] & 8 else 16) if mode == 16 else mode
     band_px = max(16, (band[1] - band[0]) * 16)
@@ -127,8 +128,10 @@ def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg
         info = {}
         b = _band_of(band, th)
         key, mode = _band_bin(means3d, camera, b, tile_size)
+        # (rows16: the band stays in 16-px rows while the BINS follow the rule -- only when the caller's tiles are the
+        # 16-px ones; an explicit tile_size of 32 / 48 / 64 keeps band_plan's units, tile rows of that size)
         _, m = render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, mode,
-                              row_range=b, out=out, info=info, rows16=True)
+                              row_range=b, out=out, info=info, rows16=(tile_size == 16))
         _band_learn(key, mode, m, info, camera, b)
         return info["on_grid"]
     means2d, conics, depths, radii = stages.project(means3d, scales, quats, opacities, camera)
@@ -232,13 +235,20 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                                                group=group, async_op=True)
 
             def image():
-                # the OR over the ranks is at least this rank's own bit: only a rank whose band holds nothing has
-                # to WAIT for the reduced flag (a device-to-host read, i.e. a host stall per frame otherwise)
+                # every rank completes the flag's collective (RCCL: the current stream waits for it, no host stall;
+                # an error of the collective surfaces here on every rank) ...
+                fwork.wait()
+                # ... but the OR over the ranks is at least this rank's own bit: only a rank whose band holds nothing
+                # has to READ the reduced flag (a device-to-host read, i.e. a host stall per frame otherwise)
                 if on_grid > 0:
                     return full[:H]
-                fwork.wait()
                 return full[:H] if int(flag.item()) > 0 else torch.zeros(H, W, C, device=dev, dtype=torch.float32)
             return image, work
+        if rehearse is not None and stages is None and world > 1:
+            # a rehearsed rank of the HIP path: its on-grid count is the count AFTER the band pre-cull, so an empty
+            # band of a non-empty frame also reports 0 -- the frame-level zeros rule cannot be decided locally;
+            # the band (background where nothing reaches it) is what this rank contributes
+            return full[:H], None
         if on_grid == 0:
             # zeros, not background (render.py:73-76); identical inputs -> every rank takes this
             # branch, so skipping the collective is consistent across the group
@@ -282,7 +292,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     my_band = _band_of(bands[rank], th)
     bkey, bmode = _band_bin(means3d, camera, my_band, tile_size)
     frame = _Frame(means3d, scales, quats, opacities, features, camera, bg, bmode, evs,
-                   my_band, full, 1 + lane, s.cuda_stream, rows16=True)
+                   my_band, full, 1 + lane, s.cuda_stream, rows16=(tile_size == 16))
     # (persistent events per lane: Stream.wait_stream creates a fresh event per call, ~8 us of host time each)
     ev_in, ev_out = _lane_events(dev, lane)
     ev_in.record(cur)

@@ -115,8 +115,9 @@ def _settle(key, mode, nxt):
     _MIN_SETTLED frames it may."""
     with _bin_lock:
         if len(_bin_mode) >= 256 and key not in _bin_mode:
-            _bin_mode.pop(next(iter(_bin_mode)))
-            _bin_left.pop(next(iter(_bin_left)), None)
+            old = next(iter(_bin_mode))     # the same key leaves both tables
+            _bin_mode.pop(old)
+            _bin_left.pop(old, None)
         left, age = _bin_left.get(key, (None, 0))
         if nxt != mode and nxt == left and age < _MIN_SETTLED:
             nxt = mode

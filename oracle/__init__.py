@@ -151,7 +151,10 @@ def render_fwd(means3d, scales, quats, opacities, colors, viewmat, fx, fy, cx, c
     ids, ranges = bin_tiles(m2, rad, dep, H, W, tile_size)
     C = np.asarray(colors).shape[1]
     if ids.size == 0:
-        return np.zeros((H, W, C), np.float32), dict(M=0)
+        aux = dict(M=0)
+        if margin:   # no branch of any walk anywhere: nothing excuses a pixel
+            aux["margin"] = np.full((H, W), np.inf, np.float32)
+        return np.zeros((H, W, C), np.float32), aux
     bg = np.zeros((C,), np.float32) if background is None else background
     res = rasterize_fwd(m2, con, colors, opacities, bg, ranges, ids, H, W, tile_size, margin=margin,
                         threads=threads)

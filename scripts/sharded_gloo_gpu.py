@@ -28,6 +28,20 @@ try:
             assert torch.equal(cur.wait(), ref), f"pipelined frame {k - 1} differs"
         cur = nxt
     assert torch.equal(cur.wait(), ref)
+    # an explicit tile size other than 16: the band plan, the slabs and the band handed to the library are all in rows
+    # of THAT size (the library's 16-px-row mode is for bins that follow the rule under 16-px tiles only)
+    for ts in (32, 64):
+        ref_ts = ms.render_gaussians(*g, cam, background_color=bg, tile_size=ts)
+        assert torch.equal(ref_ts, ref), f"tile_size={ts}: the single-GPU frame depends on the tile size"
+        assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, tile_size=ts), ref), \
+            f"tile_size={ts}: blocking sharded frame differs"
+        cur = None
+        for k in range(3):
+            nxt = render_gaussians_sharded(*g, cam, background_color=bg, tile_size=ts, async_op=True)
+            if cur is not None:
+                assert torch.equal(cur.wait(), ref), f"tile_size={ts}: pipelined frame {k - 1} differs"
+            cur = nxt
+        assert torch.equal(cur.wait(), ref)
     # inputs the frame has to marshal (float64 / strided / fp16): their copies are made on the current stream
     # and read on a lane stream -- the ordering the pipelined path must get right
     g2 = (g[0].double(), torch.stack([g[1], g[1]], 1)[:, 0], g[2].double(), g[3], g[4].half())

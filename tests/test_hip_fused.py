@@ -79,6 +79,43 @@ def test_band_calls_assemble_the_full_frame(device):
     assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True).wait(), ref)
 
 
+def test_sharded_bands_with_an_explicit_tile_size_and_on_sparse_scenes(device):
+    """(1) render_gaussians_sharded(tile_size=32 / 64): band plan, slab and the band handed to the library are in
+    rows of THAT tile size (the 16-px-row mode belongs to rule-chosen bins under 16-px tiles only) -- every rehearsed
+    rank's slab equals the single-GPU frame's rows.  (2) A rehearsed rank whose band no Gaussian reaches returns
+    its band as background, not the frame-level zeros image (the pre-culled on-grid count cannot decide that rule)."""
+    from mojosplat_amd.distributed import band_plan, render_gaussians_sharded
+    sc, cam = randscene_v1(30_000, 640, 360, ell=-3.0, seed=9, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    ref = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    for ts in (32, 64):
+        th = -(-cam.H // ts)
+        for world in (2, 3):
+            rows, bands = band_plan(th, world)
+            for r, (r0, r1) in enumerate(bands):
+                y0, y1 = min(r0 * ts, cam.H), min(r1 * ts, cam.H)
+                a = render_gaussians_sharded(*g, cam, background_color=bg, tile_size=ts, rehearse=(r, world))
+                b = render_gaussians_sharded(*g, cam, background_color=bg, tile_size=ts, async_op=True,
+                                             rehearse=(r, world)).wait()
+                assert torch.equal(a[y0:y1], ref[y0:y1]) and torch.equal(b[y0:y1], ref[y0:y1]), (ts, world, r)
+    # a scene that only reaches the top of the image: the lower bands hold nothing
+    m2, _, _, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+    top = (rad[:, 1] > 0) & (m2[:, 1] + rad[:, 1].float() < 150.0)      # footprints that end above row 150
+    assert 1000 < int(top.sum()) < 30_000
+    g2 = tuple(t[top].contiguous() for t in g)
+    ref2 = ms.render_gaussians(*g2, cam, background_color=bg, backend="hip")
+    assert (ref2[-32:] == bg).all() and not (ref2 == bg).all()
+    world = 4
+    rows, bands = band_plan(-(-cam.H // 16), world)
+    out = torch.zeros_like(ref2)
+    for r, (r0, r1) in enumerate(bands):
+        img = render_gaussians_sharded(*g2, cam, background_color=bg, rehearse=(r, world))
+        y0, y1 = min(r0 * 16, cam.H), min(r1 * 16, cam.H)
+        out[y0:y1] = img[y0:y1]
+    assert torch.equal(out, ref2)
+
+
 def test_split_frames_on_bands_that_cut_through_bin_rows(device):
     """Bands of >= 16 tile rows are split frames (32-px bins cut into block lists) even when they start
     or end in the middle of a bin row: the bins of that row are binned whole, only the band's blocks are
