@@ -38,6 +38,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "project_device.hpp"
@@ -55,6 +56,9 @@ constexpr int kMaxG = 512;
 constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
 constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
 constexpr int kBandCull = 32;      // bit of the `tight` flags: the band's Gaussians were pre-culled (k_band_precull)
+constexpr int kLean = 64;          // ... the frame keeps LeanRecs instead of the projected arrays (internal: ms_render_fwd)
+constexpr int kDeferTotal = 128;   // ... the scans' total pass rides in the scatter launch (internal: sync-free frames)
+static_assert(kLean == ms::kTightLean && kDeferTotal == ms::kTightDeferTotal, "internal flag bits out of sync");
 constexpr size_t kMaxLds = 160 * 1024 - 4096;   // dynamic LDS of the binning kernels: the CU's 160 KB less their static blocks (segment prefix of a band's candidate list, wave totals)
 
 struct Grid {
@@ -64,6 +68,16 @@ struct Grid {
     // half-tile blocks next to the Gaussian index (id << 4 | blocks): the sorted lists of 32-px bins can
     // then be split into the per-16x16-block lists the rasteriser wants, without testing anything again
     int pack, cw, ch;   // cw x ch: the half-tile (block) grid of the image
+};
+
+// What k_project_hist leaves per position for a LEAN frame (ms_render_fwd's plain 3-channel forward frames, whose
+// rasteriser reads the ready-made records and whose projected arrays nobody reads): the Gaussian's tile box on
+// the binning grid, clamped to the band -- x0 | y0 << 16, x1 | y1 << 16 -- the bits of its depth, and the tile
+// count n of the box (0: culled, nothing to emit) with the block-mask mode's edge flags in bits 28-31.  16 bytes
+// instead of means2d + conics + depth + radii (32): the scatter kernel reads ONE dwordx4 per Gaussian and redoes
+// no box arithmetic.  (Grids beyond 65 535 tiles a side keep the full arrays.)
+struct LeanRec {
+    uint32_t xy0, xy1, depth_bits, n_edges;
 };
 
 // Tight binning: which tiles of a Gaussian's box can its alpha >= 1/255 ellipse reach at all?
@@ -217,9 +231,15 @@ __device__ __forceinline__ unsigned long long clip_cells(unsigned long long m, i
 // (index gi, n = 0 if it has none); F(local_tile, gaussian_index) is called for
 // every tile of every box.  Small boxes are walked by their own lane, big ones by the whole wave.
 // Must be reached by all lanes of the wave (ballot / shuffles inside).
-template <bool PACK, class F>
-__device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y1, int n, int edges,
-                                           const Grid &g, unsigned long long mask, F &&f) {
+// `payload`: a word of the box's OWNER that f receives as a fourth argument (the lean scatter's depth bits: a
+// big box is walked by the whole wave, whose other lanes know the owner's index but not its registers).
+template <bool PACK, bool PAYLOAD, class F>
+__device__ __forceinline__ void walk_boxes_impl(int gi, int x0, int x1, int y0, int y1, int n, int edges,
+                                                const Grid &g, unsigned long long mask, F &&f, uint32_t payload) {
+    auto call = [&](int t, int64_t i, int q, uint32_t pl) __attribute__((always_inline)) {
+        if constexpr (PAYLOAD) f(t, i, q, pl);
+        else f(t, i, q);
+    };
     const int lane = threadIdx.x & 63;
     const int64_t i = gi;   // this lane's Gaussian (its index in the arrays; a band's candidate list maps to it)
     const bool big = n > kCoopThreshold;
@@ -257,7 +277,7 @@ __device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y
             } else {
                 q = PACK ? edge_blocks(edges, c, r, w, y1 - y0) : 0xf;
             }
-            f((y0 + r - g.row_begin) * g.tw + x0 + c, i, q);
+            call((y0 + r - g.row_begin) * g.tw + x0 + c, i, q, payload);
         }
     }
     unsigned long long bigmask = __ballot(big);
@@ -270,13 +290,25 @@ __device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y
                                       (unsigned)__shfl((int)(mask & 0xffffffffu), src);
         const int be = PACK ? __shfl(edges, src) : 0;
         const int64_t bi = __shfl(gi, src);
+        const uint32_t bp = PAYLOAD ? (uint32_t)__shfl((int)payload, src) : 0u;
         const int w = bx1 - bx0, cnt = w * (by1 - by0);
         for (int k = lane; k < cnt; k += 64) {
             const int r = k / w, c = k % w;
             if (cnt > 64 || ((bm >> k) & 1ull))
-                f((by0 + r - g.row_begin) * g.tw + bx0 + c, bi, PACK ? edge_blocks(be, c, r, w, by1 - by0) : 0xf);
+                call((by0 + r - g.row_begin) * g.tw + bx0 + c, bi, PACK ? edge_blocks(be, c, r, w, by1 - by0) : 0xf, bp);
         }
     }
+}
+
+template <bool PACK, class F>
+__device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y1, int n, int edges,
+                                           const Grid &g, unsigned long long mask, F &&f) {
+    walk_boxes_impl<PACK, false>(gi, x0, x1, y0, y1, n, edges, g, mask, f, 0u);
+}
+template <bool PACK, class F>
+__device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y1, int n, int edges,
+                                           const Grid &g, unsigned long long mask, F &&f, uint32_t payload) {
+    walk_boxes_impl<PACK, true>(gi, x0, x1, y0, y1, n, edges, g, mask, f, payload);
 }
 
 // Walk every (Gaussian, tile) pair of one chunk; F(local_tile, gaussian_index).
@@ -328,15 +360,15 @@ template <bool PACK, class F>
 __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const float *means2d,
                                                const int32_t *radii, const unsigned long long *masks,
                                                const Grid &g,
-                                               int32_t *tiles_per_gauss, unsigned int *s_on_grid, Candidates cand, F &&f) {
+                                               int32_t *tiles_per_gauss, unsigned int *s_on_grid, Candidates cand, int G, F &&f) {
     __shared__ uint32_t s_pref[kMaxG + 1];
     CandMap map{s_pref};
     int64_t stride = kHistThreads;
     if (cand.ids) {   // positions of the candidate list, step s -> workgroup s mod G
         map.build(cand);
-        i0 = (int64_t)chunk_of_block(blockIdx.x, gridDim.x) * kHistThreads;
+        i0 = (int64_t)chunk_of_block(blockIdx.x, G) * kHistThreads;
         i1 = (int64_t)s_pref[cand.n_segs];
-        stride = (int64_t)gridDim.x * kHistThreads;
+        stride = (int64_t)G * kHistThreads;
     }
     for (int64_t base = i0; base < i1; base += stride) {
         const int64_t j = base + threadIdx.x;
@@ -451,14 +483,18 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
 // Fused projection + tile counting (the first two kernels of a frame in one): every lane projects
 // its Gaussian (project_device.hpp), stores the projected record, and counts the tiles of its box
 // in the workgroup's LDS histogram.  Same chunking as k_isect_hist / k_isect_scatter.
-template <bool PACK>
+// LEAN (ms_render_fwd's plain 3-channel forward frames): nobody reads the projected arrays of such a frame -- the
+// rasteriser stages from the ready-made records, the scatter kernel wants the tile box and the depth -- so the
+// kernel stores one 16-byte LeanRec per position instead of means2d / conics / depths / radii (32 bytes).
+template <bool PACK, bool LEAN>
 __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
     ms::ProjParams P, Grid g, int64_t chunk, float *__restrict__ means2d, float *__restrict__ conics,
     float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist,
     uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks,
-    const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand) {
+    const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
+    LeanRec *__restrict__ lean) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
@@ -486,47 +522,57 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             // projected arrays stay dense and their stores coalesced (scattered 4-48-byte stores by Gaussian
             // index cost 3.5x the projection itself).  Positions grow with the Gaussian index, so the
             // (depth bits, id) order of the sorted lists is the same either way.
-            const int64_t src = cand.ids ? map.gaussian(cand, j) : j;
+            // (32-bit indices against uniform base pointers -- the step's own slice of the inputs, or the whole arrays
+            // for a candidate's gather: one address register per load instead of 64-bit arithmetic per lane)
+            const bool gather = cand.ids != nullptr;
+            const uint32_t src = gather ? (uint32_t)map.gaussian(cand, j) : (uint32_t)threadIdx.x;
+            const int64_t b0 = gather ? 0 : base;
+            const float *opac_b = opacities ? opacities + b0 : nullptr;
             const int64_t i = j;
             gi = (int)i;
-            const ms::ProjOut o = ms::project_one(src, means3d, scales, quats, opacities, viewmat, P);
-            reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
-            // (leaving the conics out -- a plain forward frame's rasteriser reads the records -- was measured: 32.0 ->
-            // 31.8 us, the kernel is VALU bound)
-            conics[3 * i] = o.c0;
-            conics[3 * i + 1] = o.c1;
-            conics[3 * i + 2] = o.c2;
-            depths[i] = o.d;
-            reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
+            const ms::ProjOut o = ms::project_one<uint32_t>(src, means3d + 3 * b0, scales + 3 * b0, quats + 4 * b0, opac_b, viewmat, P);
+            if constexpr (!LEAN) {
+                reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
+                conics[3 * i] = o.c0;
+                conics[3 * i + 1] = o.c1;
+                conics[3 * i + 2] = o.c2;
+                depths[i] = o.d;
+                reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
+            }
             if (rec && o.r0 > 0 && o.r1 > 0) {
                 // the rasteriser's staged record, ready made (ms::RasterRecord, ms_common.hpp): three 16-byte
                 // words per visible Gaussian instead of seven scattered 4-12-byte gathers + arithmetic per
                 // (tile, Gaussian) pair.  Same expressions as the rasteriser's own staging: same bits.
                 float col[3];
                 if (color_f16) {
-                    const __half *c = reinterpret_cast<const __half *>(colors) + 3 * src;
-                    col[0] = __half2float(c[0]); col[1] = __half2float(c[1]); col[2] = __half2float(c[2]);
+                    const __half *c = reinterpret_cast<const __half *>(colors) + 3 * b0;
+                    col[0] = __half2float(c[3 * src]); col[1] = __half2float(c[3 * src + 1]); col[2] = __half2float(c[3 * src + 2]);
                 } else {
-                    const float *c = reinterpret_cast<const float *>(colors) + 3 * src;
-                    col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
+                    const float *c = reinterpret_cast<const float *>(colors) + 3 * b0;
+                    col[0] = ms::ld_f32(c, src, 3, 0); col[1] = ms::ld_f32(c, src, 3, 1); col[2] = ms::ld_f32(c, src, 3, 2);
                 }
-                const ms::RasterRecord r = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[src], col[0], col[1], col[2]);
-                rec[3 * i] = r.a;
-                rec[3 * i + 1] = r.b;
-                rec[3 * i + 2] = r.c;
+                const ms::RasterRecord r = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), col[0], col[1], col[2]);
+                // (stores likewise: the step's slice of the output + a 32-bit byte offset)
+                char *rb = reinterpret_cast<char *>(rec + 3 * base) + 48u * (uint32_t)threadIdx.x;
+                *reinterpret_cast<float4 *>(rb) = r.a;
+                *reinterpret_cast<float4 *>(rb + 16) = r.b;
+                *reinterpret_cast<float4 *>(rb + 32) = r.c;
             }
             if (o.r0 > 0 && o.r1 > 0) {
                 on_grid = bin_box<PACK>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
                 if (masks) {
                     if (PACK && n <= 16 && n > 0)   // per half-tile cell (the 16x16 blocks of a 32-px bin)
-                        mask = clip_cells(reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[src], 2 * x0, 2 * x1,
+                        mask = clip_cells(reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), 2 * x0, 2 * x1,
                                                      2 * y0, 2 * y1, g.ts >> 1), edges, x1 - x0, y1 - y0);
                     else
-                        mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, opacities[src], x0, x1, y0, y1, g.ts);
-                    masks[i] = mask;
+                        mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), x0, x1, y0, y1, g.ts);
+                    *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(masks + base) + 8u * (uint32_t)threadIdx.x) = mask;
                 }
             }
+            if constexpr (LEAN)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lean + base) + 16u * (uint32_t)threadIdx.x) = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16),
+                                                                __float_as_uint(o.d), (uint32_t)n | ((uint32_t)edges << 28));
         }
         count_on_grid(on_grid, &s_on_grid);
         walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
@@ -551,7 +597,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     const int wg = chunk_of_block(blockIdx.x, gridDim.x);
     const int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk);
     for_each_isect<false>(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid, Candidates{nullptr, nullptr, 0, 0},
-                   [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
+                   (int)gridDim.x, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)wg * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
@@ -801,34 +847,236 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
 // The total pass alone (an empty band has no per-tile prefix to take)
 __global__ __launch_bounds__(1024) void k_tile_scan_total(ScanTotalArgs A) { tile_scan_total<false>(A); }
 
-template <bool PACK>
+// Exclusive prefix over the T tile counts in LDS: s[t] = sum of count[0 .. t), every thread of the (1024-thread)
+// workgroup; -> the grand total (64-bit; offsets saturate at INT32_MAX: the host rejects M > INT32_MAX before it
+// trusts any of them).  Three barriers whatever T is: counts -> LDS (coalesced), each thread sums a run of
+// ceil(T / 1024) consecutive entries, wave scans + the 16 wave totals, each thread writes its run back.
+__device__ __forceinline__ unsigned long long tile_prefix_lds(const uint32_t *__restrict__ count, int T, uint32_t *s) {
+    __shared__ unsigned long long s_wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int t = tid; t < T; t += kHistThreads) s[t] = count[t];
+    __syncthreads();
+    const int per = (T + kHistThreads - 1) / kHistThreads;
+    const int j0 = min(T, tid * per), j1 = min(T, j0 + per);
+    unsigned long long sum = 0;
+    for (int j = j0; j < j1; ++j) sum += s[j];
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wtot[w] = incl;
+    __syncthreads();
+    unsigned long long run = incl - sum, grand = 0;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) {
+        if (ww < w) run += s_wtot[ww];
+        grand += s_wtot[ww];
+    }
+    for (int j = j0; j < j1; ++j) {
+        const uint32_t v = s[j];
+        s[j] = (uint32_t)min(run, 0x7fffffffull);
+        run += v;
+    }
+    __syncthreads();
+    return grand;
+}
+
+// The total pass of the scans, DEFERRED into the scatter launch (sync-free frames of ms_render_fwd): as a pass of
+// its own -- one workgroup, a chain of dependent round trips -- it cost 9 of the scan kernel's 12.9 us on the
+// frame's critical path.  Here every scatter workgroup takes the exclusive prefix over the tile counts itself
+// (tile_prefix_lds: 8 KB of L2-resident counts, three barriers), and two EXTRA workgroups of the same launch
+// write what the later kernels and the host want while the others scatter:
+//   which == 0   tile_ranges, the zeroed redo flags, the work lists of over-sized tiles, the size record (+ mirror)
+//   which == 1   the heaviest-first order of the band's tiles (counting sort over 128 length buckets)
+// Same results as tile_scan_total (whose comments apply), bit for bit.
+__device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A, uint32_t *s, int T_local) {
+    const Grid &g = A.g;
+    const int band0 = g.row_begin * g.tw, band1 = g.row_end * g.tw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (which == 1) {
+        if (!A.order) return;
+        __shared__ unsigned int s_bkt[128], s_base[128];
+        auto bucket_of = [](unsigned int c) -> int {
+            if (c == 0) return 0;
+            const int l = 31 - __clz((int)c);
+            const int frac = l >= 2 ? (int)((c >> (l - 2)) & 3u) : (int)((c << (2 - l)) & 3u);
+            return 1 + 4 * l + frac;
+        };
+        if (tid < 128) s_bkt[tid] = 0;
+        __syncthreads();
+        for (int t = tid; t < T_local; t += kHistThreads) atomicAdd(&s_bkt[bucket_of(A.tile_count[t])], 1u);
+        __syncthreads();
+        if (tid < 64) {   // s_base[b] = tiles in heavier buckets: suffix sums, lane 0 owns the heaviest two
+            const unsigned int c0 = s_bkt[127 - 2 * lane], c1 = s_bkt[126 - 2 * lane];
+            unsigned int incl = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned int o = (unsigned int)__shfl_up((int)incl, d);
+                if (lane >= d) incl += o;
+            }
+            const unsigned int excl = incl - (c0 + c1);
+            s_base[127 - 2 * lane] = excl;
+            s_base[126 - 2 * lane] = excl + c0;
+        }
+        __syncthreads();
+        for (int t = tid; t < T_local; t += kHistThreads)
+            A.order[atomicAdd(&s_base[bucket_of(A.tile_count[t])], 1u)] = band0 + t;
+        return;
+    }
+    __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
+    if (tid == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; }
+    const int prev_redo = tid == 0 ? *A.redo_count : 0;
+    unsigned int on_grid_part = tid < A.G ? A.wg_on_grid[tid] : 0u;   // G <= kMaxG <= blockDim
+    const unsigned long long grand = tile_prefix_lds(A.tile_count, T_local, s);   // (its barriers also publish the zeros above)
+    if (tid == 0) s[T_local] = (uint32_t)min(grand, 0x7fffffffull);    // the end of the last tile (the LDS block's spare words)
+    __syncthreads();
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) on_grid_part += (unsigned int)__shfl_xor((int)on_grid_part, d);
+    if (lane == 0 && on_grid_part) atomicAdd(&s_on_grid, on_grid_part);
+    unsigned int lmax = 0;
+    for (int t = tid; t < T_local; t += kHistThreads) {
+        const uint32_t b = s[t], e = s[t + 1], c = e - b;
+        const int at = band0 + t;
+        reinterpret_cast<int2 *>(A.tile_ranges)[at] = make_int2((int32_t)b, (int32_t)e);
+        A.redo_flag[at] = 0;
+        lmax = max(lmax, c);
+        // (a saturated prefix makes c meaningless; such a frame is rejected by the host on info[0])
+        if (c > (unsigned)kLargeCapDecl) A.xl_list[atomicAdd(&s_nxl, 1u)] = at;
+        else if (c > (unsigned)kMediumCapDecl) A.large_list[atomicAdd(&s_nlarge, 1u)] = at;
+        else if (c > (unsigned)kSmallCapDecl) A.medium_list[atomicAdd(&s_nmedium, 1u)] = at;
+    }
+    if (!A.band_only) {   // the rest of the grid: empty ranges at 0 before the band, at M behind it
+        const int32_t m = (int32_t)min(grand, 0x7fffffffull);
+        for (int t = tid; t < g.tw * g.th; t += kHistThreads)
+            if (t < band0 || t >= band1) {
+                reinterpret_cast<int2 *>(A.tile_ranges)[t] = t < band0 ? make_int2(0, 0) : make_int2(m, m);
+                A.redo_flag[t] = 0;
+            }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (unsigned int)__shfl_xor((int)lmax, d));
+    if (lane == 0) atomicMax(&s_max, lmax);
+    __syncthreads();
+    if (tid == 0) {
+        int64_t rec[7] = {(int64_t)grand, (int64_t)s_max, (int64_t)s_nmedium, (int64_t)s_nlarge, (int64_t)s_nxl,
+                          (int64_t)prev_redo, (int64_t)s_on_grid};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) A.info[k] = rec[k];
+        A.info[7] = 0;
+        *A.redo_count = 0;
+        if (A.info_mirror) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) A.info_mirror[k] = rec[k];
+            __threadfence_system();
+        }
+    }
+}
+
+// LEAN: per-position LeanRecs (+ reach masks) instead of means2d / radii / depths.  DEFER: the launch carries the
+// scans' total pass (deferred_total; gridDim = G + 2), and the tile starts come from the workgroup's own prefix
+// over the tile counts instead of tile_ranges.
+template <bool PACK, bool LEAN, bool DEFER>
 __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
-    Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
+    const LeanRec *__restrict__ lean, Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
     const int32_t *__restrict__ tile_ranges, int64_t M, uint64_t *__restrict__ keys,
-    uint32_t *__restrict__ wg_depth, Candidates cand) {
+    uint32_t *__restrict__ wg_depth, Candidates cand, int G, ScanTotalArgs A) {
     extern __shared__ uint32_t s_cur[];
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     const int band0 = g.row_begin * g.tw;
-    const int wg = chunk_of_block(blockIdx.x, gridDim.x);   // the chunk (and histogram row) the count kernel gave this index
+    if constexpr (DEFER) {
+        if ((int)blockIdx.x >= G) {   // (uniform per workgroup)
+            deferred_total((int)blockIdx.x - G, A, s_cur, T_local);
+            return;
+        }
+    }
+    const int wg = chunk_of_block(blockIdx.x, G);   // the chunk (and histogram row) the count kernel gave this index
     const uint32_t *row = hist + (size_t)wg * T_local;
-    for (int t = threadIdx.x; t < T_local; t += kHistThreads)
-        s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
+    int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk), stride = kHistThreads;
+    if constexpr (LEAN) {
+        if (cand.ids) {   // positions of the band's candidate list, step s -> workgroup s mod G (as the count kernel)
+            __shared__ uint32_t s_pref[kMaxG + 1];
+            CandMap map{s_pref};
+            map.build(cand);
+            i0 = (int64_t)wg * kHistThreads;
+            i1 = (int64_t)s_pref[cand.n_segs];
+            stride = (int64_t)G * kHistThreads;
+        }
+    }
+    // the first step's record is on its way while the cursors are set up (the kernel is a chain of round trips:
+    // waves sat in s_waitcnt 71 % of their life)
+    LeanRec r_next = {0u, 0u, 0u, 0u};
+    if constexpr (LEAN) {
+        if (i0 + threadIdx.x < i1) r_next = lean[i0 + threadIdx.x];
+    }
+    if constexpr (DEFER) {
+        // (the histogram row's loads go out before the prefix's barriers)
+        constexpr int kPre = 4;
+        uint32_t rpre[kPre];
+        const bool pre = T_local <= kPre * kHistThreads;
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) {
+                const int t = k * kHistThreads + threadIdx.x;
+                rpre[k] = t < T_local ? row[t] : 0u;
+            }
+        }
+        (void)tile_prefix_lds(A.tile_count, T_local, s_cur);
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) {
+                const int t = k * kHistThreads + threadIdx.x;
+                if (t < T_local) s_cur[t] += rpre[k];
+            }
+        } else {
+            for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cur[t] += row[t];
+        }
+    } else {
+        for (int t = threadIdx.x; t < T_local; t += kHistThreads)
+            s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
+    }
     __syncthreads();
-    const int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk);
     // depth bits (order preserving for the positive depths that survive) of everything this workgroup
     // emits: k_tile_front spreads its buckets over the frame's range
     uint32_t dmin = 0xffffffffu, dmax = 0u;
-    for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, cand, [&](int t, int64_t i, int q) {
-        const uint32_t slot = atomicAdd(&s_cur[t], 1u);
-        const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
-        const uint32_t dbits = __float_as_uint(depths[i]);
-        dmin = min(dmin, dbits);
-        dmax = max(dmax, dbits);
-        const uint64_t key = ((uint64_t)dbits << 32) | low;
-        if ((int64_t)slot < M) keys[slot] = key;
-    });
+    if constexpr (LEAN) {
+        for (int64_t base = i0; base < i1; base += stride) {
+            const LeanRec r = r_next;
+            const int64_t jn = base + stride + threadIdx.x;
+            if (jn < i1) r_next = lean[jn];
+            const int64_t j = base + threadIdx.x;
+            int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
+            unsigned long long mask = ~0ull;
+            if (j < i1) {
+                n = (int)(r.n_edges & 0x0fffffffu);
+                edges = (int)(r.n_edges >> 28);
+                x0 = (int)(r.xy0 & 0xffffu); y0 = (int)(r.xy0 >> 16);
+                x1 = (int)(r.xy1 & 0xffffu); y1 = (int)(r.xy1 >> 16);
+                if (masks && (n > 1 || (PACK && n > 0))) mask = masks[j];
+            }
+            const uint32_t dbits = r.depth_bits;
+            if (n > 0) { dmin = min(dmin, dbits); dmax = max(dmax, dbits); }
+            walk_boxes<PACK>((int)j, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t i, int q, uint32_t db) {
+                const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+                const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
+                const uint64_t key = ((uint64_t)db << 32) | low;
+                if ((int64_t)slot < M) keys[slot] = key;
+            }, dbits);
+        }
+    } else {
+        for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, cand, G, [&](int t, int64_t i, int q) {
+            const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+            const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
+            const uint32_t dbits = __float_as_uint(depths[i]);
+            dmin = min(dmin, dbits);
+            dmax = max(dmax, dbits);
+            const uint64_t key = ((uint64_t)dbits << 32) | low;
+            if ((int64_t)slot < M) keys[slot] = key;
+        });
+    }
     if (wg_depth) {
         uint32_t *s_depth = s_cur + T_local + 1;   // (the 16 spare bytes every binning kernel's LDS block ends with)
         __syncthreads();                           // (the cursors are done with)
@@ -1453,7 +1701,7 @@ struct Plan {
     int T, T_local;
     size_t lds_bytes;
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
-        off_redo_list, off_redo_count, off_depth_wg, off_order, off_cand_count, off_cand, total;
+        off_redo_list, off_redo_count, off_depth_wg, off_order, off_cand_count, off_cand, off_lean, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -1487,6 +1735,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_cand_count = o; o += ms::align_up((size_t)kMaxG * 4, 256);   // band pre-cull: survivors per segment
     p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
     p.off_cand = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 4, 256);  // band pre-cull: candidate list
+    p.off_lean = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * sizeof(LeanRec), 256);  // lean frames: box + depth per position
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -1524,10 +1773,22 @@ namespace {
 // per-tile prefix over the partial histograms -> tile_ranges, M, work lists
 int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t *count, int32_t *medium,
                int32_t *large, int32_t *xl, const uint32_t *wg_on_grid, int n_wg, int32_t *tile_ranges,
-               int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream) {
+               int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream, bool defer_total = false) {
     ScanTotalArgs A{g, count, tile_ranges, medium, large, xl, wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag),
                     (int32_t *)(ws + p.off_redo_count), band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order),
                     (uint32_t *)wg_on_grid + kMaxG};
+    if (defer_total && p.T_local > 0) {
+        // the per-tile prefix over the partial rows alone: the total pass rides in the scatter launch (deferred_total)
+        A.ticket = nullptr;
+        if (p.T_local <= 4096)
+            hipLaunchKernelGGL(k_tile_scan_wg<16>, dim3((unsigned)ms::ceil_div(p.T_local, 16)), dim3(1024), 0, stream,
+                               p.G, p.T_local, hist, count, A);
+        else
+            hipLaunchKernelGGL(k_tile_scan_wg<64>, dim3((unsigned)ms::ceil_div(p.T_local, 64)), dim3(1024), 0, stream,
+                               p.G, p.T_local, hist, count, A);
+        MS_LAUNCH_CHECK();
+        return MS_OK;
+    }
     if (p.T_local > 0) {
         // (the last workgroup to arrive runs the total pass)
         if (p.T_local <= 4096)
@@ -1638,7 +1899,7 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
                                       int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
                                       void *stream_) {
     return ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy, cx, cy, W, H,
-                                   eps2d, near_plane, far_plane, radius_clip, tile_size, row_begin, row_end, tight,
+                                   eps2d, near_plane, far_plane, radius_clip, tile_size, row_begin, row_end, tight & 63,
                                    means2d, conics, depths, radii, workspace, workspace_bytes, tile_ranges, isect_info,
                                    isect_info_mirror, nullptr, 0, nullptr, stream_);
 }
@@ -1686,6 +1947,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                                                   scales_are_log, opacities != nullptr);
     // bit 5 of `tight`: the band is a rank's share of a frame -- pre-cull the Gaussians that cannot reach it
     Candidates cand{nullptr, nullptr, 0, 0};
+    if ((tight & kBandCull) && N >= (1ll << 28)) tight &= ~kBandCull;   // (the candidates' gather indexes with 32-bit byte offsets)
     if ((tight & kBandCull) && N > 0) {
         int32_t *seg_count = (int32_t *)(ws + p.off_cand_count);
         hipLaunchKernelGGL(k_band_precull, dim3(p.G), dim3(kHistThreads), 0, stream, N, means3d, scales, viewmat, P,
@@ -1696,16 +1958,20 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
     }
     {   // also for N == 0 (one workgroup that walks nothing): the histogram row and the on-grid slot the
         // scans read must exist
-        auto kernel = pack ? k_project_hist<true> : k_project_hist<false>;
+        // lean frame: LeanRecs instead of the projected arrays (the caller vouches that nobody reads those)
+        const bool lean = (tight & kLean) && raster_records && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
+        auto kernel = pack ? (lean ? k_project_hist<true, true> : k_project_hist<true, false>)
+                           : (lean ? k_project_hist<false, true> : k_project_hist<false, false>);
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
                            quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks,
-                           colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand);
+                           colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand,
+                           (LeanRec *)(ws + p.off_lean));
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
-                      (tight & 2) ? 1 : 0, isect_info_mirror, stream);
+                      (tight & 2) ? 1 : 0, isect_info_mirror, stream, (tight & kDeferTotal) != 0);
 }
 
 namespace {
@@ -1716,7 +1982,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
               int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
               const int32_t *tile_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
               uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
-              hipStream_t stream, const ms::BlockLists *blocks = nullptr) {
+              hipStream_t stream, const ms::BlockLists *blocks = nullptr, const ms::DeferredTotal *defer = nullptr) {
     const ms::BlockLists bl = blocks ? *blocks : ms::BlockLists{nullptr, nullptr, nullptr, 0, 0};
     Plan p;
     const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
@@ -1736,14 +2002,31 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                   n_large = spec ? 0 : host_info[3], n_xl = spec ? 0 : host_info[4];
 
     {
-        auto kernel = pack ? k_isect_scatter<true> : k_isect_scatter<false>;
+        const bool lean = (tight & kLean) && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
+        const bool deferred = defer && p.T_local > 0;
+        ScanTotalArgs A{};
+        if (deferred) {
+            A = ScanTotalArgs{g, (const uint32_t *)(ws + p.off_count), const_cast<int32_t *>(tile_ranges), (int32_t *)(ws + p.off_medium),
+                              (int32_t *)(ws + p.off_large), (int32_t *)(ws + p.off_xl), (const uint32_t *)(ws + p.off_on_grid), p.G,
+                              (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count), defer->band_only,
+                              defer->info, defer->info_mirror, (int32_t *)(ws + p.off_order), nullptr};
+        }
+        auto pick = [&](auto packc) {
+            constexpr bool PK = decltype(packc)::value;
+            return lean ? (deferred ? k_isect_scatter<PK, true, true> : k_isect_scatter<PK, true, false>)
+                        : (deferred ? k_isect_scatter<PK, false, true> : k_isect_scatter<PK, false, false>);
+        };
+        auto kernel = pack ? pick(std::true_type{}) : pick(std::false_type{});
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
-        hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
-                           g, p.chunk, hist, tile_ranges, cap, sort_keys, lazy ? (uint32_t *)(ws + p.off_depth_wg) : nullptr,
+        hipLaunchKernelGGL(kernel, dim3(p.G + (deferred ? 2 : 0)), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
+                           (const LeanRec *)(ws + p.off_lean), g, p.chunk, hist, tile_ranges, cap, sort_keys,
+                           lazy ? (uint32_t *)(ws + p.off_depth_wg) : nullptr,
                            (tight & kBandCull) ? Candidates{(const int32_t *)(ws + p.off_cand), (const int32_t *)(ws + p.off_cand_count), p.G, p.chunk}
-                                               : Candidates{nullptr, nullptr, 0, 0});
+                                               : Candidates{nullptr, nullptr, 0, 0}, p.G, A);
         MS_LAUNCH_CHECK();
+        // the size record is complete once the scatter launch is: the caller's hand-off event goes here
+        if (deferred && defer->sync_event) MS_HIP(hipEventRecord((hipEvent_t)defer->sync_event, stream));
     }
 
     static_assert(kSmallCap == kSmallCapDecl && kMediumCap == kMediumCapDecl && kLargeCap == kLargeCapDecl,
@@ -1888,7 +2171,7 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
                MS_ERR_INVALID_ARG, "isect_emit: null pointer");
     MS_REQUIRE(n_xl == 0 || sort_tmp || lazy, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
     MS_REQUIRE(!lazy || !isect_ids, MS_ERR_INVALID_ARG, "isect_emit: lazy lists carry no isect_ids");
-    return emit_impl(N, means2d, radii, depths, tight, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+    return emit_impl(N, means2d, radii, depths, tight & 63, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
                      row_begin, row_end, workspace, workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp,
                      flatten_ids, isect_ids, (hipStream_t)stream_);
 }
@@ -1906,16 +2189,50 @@ extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, 
     if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
     MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
                MS_ERR_INVALID_ARG, "isect_emit_speculative: null pointer");
-    return emit_impl(N, means2d, radii, depths, tight, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+    return emit_impl(N, means2d, radii, depths, tight & 63, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
                      row_begin, row_end, workspace, workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity,
                      sort_keys, nullptr, flatten_ids, nullptr, (hipStream_t)stream_);
+}
+
+int ms::isect_emit_speculative(int64_t N, const float *means2d, const int32_t *radii, const float *depths,
+                               int tile_size, int tile_w, int tile_h, int row_begin, int row_end, void *workspace,
+                               size_t workspace_bytes, const int32_t *tile_ranges, const int64_t *isect_info_dev,
+                               int64_t capacity, const int64_t *prev_info_host, int tight, int lazy, float depth_near,
+                               float depth_far, uint64_t *sort_keys, int32_t *flatten_ids,
+                               const ms::DeferredTotal *defer, void *stream_) {
+    MS_REQUIRE(N >= 0 && isect_info_dev && capacity > 0 && capacity <= 0x7fffffffll, MS_ERR_INVALID_ARG,
+               "isect_emit_speculative: bad N / info / capacity");
+    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
+    MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
+               MS_ERR_INVALID_ARG, "isect_emit_speculative: null pointer");
+    return emit_impl(N, means2d, radii, depths, tight, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+                     row_begin, row_end, workspace, workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity,
+                     sort_keys, nullptr, flatten_ids, nullptr, (hipStream_t)stream_, nullptr, defer);
+}
+
+int ms::isect_emit_exact(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
+                         int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
+                         const int32_t *tile_ranges, const int64_t *host_info, int tight, int lazy, float depth_near,
+                         float depth_far, uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, void *stream_) {
+    MS_REQUIRE(N >= 0 && host_info, MS_ERR_INVALID_ARG, "isect_emit: bad N / host_info");
+    if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
+    const int64_t M = host_info[0], n_xl = host_info[4];
+    MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE,
+               "isect_emit: %lld intersections do not fit int32 indices", (long long)M);
+    if (M == 0) return MS_OK;
+    MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
+               MS_ERR_INVALID_ARG, "isect_emit: null pointer");
+    MS_REQUIRE(n_xl == 0 || sort_tmp || lazy, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
+    return emit_impl(N, means2d, radii, depths, tight, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+                     row_begin, row_end, workspace, workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp,
+                     flatten_ids, nullptr, (hipStream_t)stream_);
 }
 
 int ms::isect_emit_bins(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int bin_w,
                         int bin_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
                         const int32_t *bin_ranges, const int64_t *host_info, const int64_t *info_dev, int64_t cap,
                         int flags, int lazy, float depth_near, float depth_far, uint64_t *sort_keys,
-                        const ms::BlockLists *out, void *stream_) {
+                        const ms::BlockLists *out, const ms::DeferredTotal *defer, void *stream_) {
     MS_REQUIRE(N > 0 && cap > 0 && cap <= 0x1fffffffll && (info_dev || host_info) && (lazy & 1), MS_ERR_INVALID_ARG,
                "isect_emit_bins: bad N / capacity / info (block lists come from lazily sorted bins only)");
     if (int rc = check_grid(32, bin_w, bin_h, row_begin, row_end)) return rc;
@@ -1924,7 +2241,7 @@ int ms::isect_emit_bins(int64_t N, const float *means2d, const int32_t *radii, c
                MS_ERR_INVALID_ARG, "isect_emit_bins: null pointer");
     return emit_impl(N, means2d, radii, depths, flags, lazy | 1, depth_near, depth_far, 32, bin_w, bin_h, row_begin,
                      row_end, workspace, workspace_bytes, bin_ranges, host_info, info_dev, cap, sort_keys, nullptr,
-                     nullptr, nullptr, (hipStream_t)stream_, out);
+                     nullptr, nullptr, (hipStream_t)stream_, out, info_dev ? defer : nullptr);
 }
 
 extern "C" int ms_isect_offset_encode(int64_t M, const int64_t *isect_ids_sorted, int tile_w,

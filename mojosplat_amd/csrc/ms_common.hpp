@@ -125,12 +125,33 @@ struct BlockLists {
     int32_t *block_ranges, *block_ids, *bin_more;
     int tw16, th16;
 };
+// Sync-free frames (ms_render_fwd): the scans' total pass -- tile_ranges, work lists, launch order, the size record --
+// rides in the scatter launch instead of being a serial pass of its own (binning.hip, deferred_total), and the
+// caller's hand-off event is recorded right behind that launch.
+struct DeferredTotal {
+    int band_only;
+    int64_t *info, *info_mirror;
+    void *sync_event;
+};
+// bits of the `tight` flags that only ms_render_fwd sets (the C entry points mask them off)
+constexpr int kTightLean = 64, kTightDeferTotal = 128;
+// binning.hip: ms_isect_tiles_emit_speculative / ms_isect_tiles_emit with the internal flag bits honoured
+int isect_emit_speculative(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
+                           int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
+                           const int32_t *tile_ranges, const int64_t *isect_info_dev, int64_t capacity,
+                           const int64_t *prev_info_host, int tight, int lazy, float depth_near, float depth_far,
+                           uint64_t *sort_keys, int32_t *flatten_ids, const DeferredTotal *defer, void *stream);
+int isect_emit_exact(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
+                     int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,
+                     const int32_t *tile_ranges, const int64_t *host_info, int tight, int lazy, float depth_near,
+                     float depth_far, uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, void *stream);
+
 // binning.hip: scatter + sorts on the bin grid, writing block lists (info_dev != null: sync-free frame
 // against `cap` entries, host_info = the previous frame's record or null)
 int isect_emit_bins(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int bin_w, int bin_h,
                     int row_begin, int row_end, void *workspace, size_t workspace_bytes, const int32_t *bin_ranges,
                     const int64_t *host_info, const int64_t *info_dev, int64_t cap, int flags, int lazy, float depth_near,
-                    float depth_far, uint64_t *sort_keys, const BlockLists *out, void *stream);
+                    float depth_far, uint64_t *sort_keys, const BlockLists *out, const DeferredTotal *defer, void *stream);
 
 // Split frame: the block lists cut from 32-px bins are rasterised per 16x16 block and cleaned up per
 // bin.  Rows are BLOCK rows.

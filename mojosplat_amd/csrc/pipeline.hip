@@ -62,6 +62,24 @@ static int ms_order_enabled() {
     return v;
 }
 
+// MOJOSPLAT_LEAN=0: keep writing the projected arrays on frames whose rasteriser reads the ready-made records
+static int ms_lean_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_LEAN");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+
+// MOJOSPLAT_DEFER_TOTAL=0: the scans' total pass as a pass of its own on sync-free frames too
+static int ms_defer_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_DEFER_TOTAL");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+
 // MOJOSPLAT_SPLIT=0: bin on the rasteriser's own 16-px tiles instead of 32-px bins cut into block lists
 static int ms_split_enabled() {
     static const int v = [] {
@@ -180,7 +198,10 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     // MOJOSPLAT_BAND_CULL=0 switches that off.
     // (only frames whose rasteriser reads the ready-made records: the lists of a culled band hold POSITIONS in the
     // band's candidate list, which index the workspace's dense projected arrays and records, not the caller's)
-    const int cull = (use_records && !aux_frame && N >= 32768 && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0;
+    // lean frame: nobody reads the projected arrays (the rasteriser and the clean-up pass stage from the records,
+    // the scatter kernel from the 16-byte box + depth records the count kernel leaves instead)
+    const int lean = (use_records && !aux_frame && ((uintptr_t)records & 15) == 0 && ms_lean_enabled()) ? ms::kTightLean : 0;
+    const int cull = ((use_records && !aux_frame && N >= 32768 && N < (1ll << 28) && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0) | lean;
     const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0) | cull;
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
     ms::LazyLists lazy_lists;
@@ -201,10 +222,18 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             (void)hipGetLastError();
             mirror = nullptr;
         }
+        // Sync-free frame (see below) -- decided here because such a frame also DEFERS the scans' total pass into
+        // its scatter launch (binning.hip, deferred_total): the size record then reaches the host behind that launch
+        const int64_t cap = split ? (isect_bytes > 768 ? (int64_t)((isect_bytes - 768) / 28) : 0)
+                                  : (isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0);
+        const bool speculate = sync_event && isect_buf && cap > 0 && N > 0;   // (an empty set has null inputs: exact path, M = 0)
+        const bool deferred = speculate && mirror && (split ? b1 > b0 : r1 > r0) && ms_defer_enabled();
+        const ms::DeferredTotal defer{1, info, (int64_t *)mirror, sync_event};
+        const int defer_bit = deferred ? ms::kTightDeferTotal : 0;
         if (int rc = ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
                                              cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,
                                              split ? 32 : tile_size, split ? b0 : r0, split ? b1 : r1,
-                                             /*tight | ranges for the band only (| block masks)=*/split ? bin_flags : 1 | 2 | cull,
+                                             /*tight | ranges for the band only (| block masks)=*/(split ? bin_flags : 1 | 2 | cull) | defer_bit,
                                              means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
                                              split ? bin_ranges : ranges, info, (int64_t *)mirror,
                                              use_records ? colors : nullptr, color_dtype, records, stream))
@@ -212,15 +241,13 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
         mark(1);
         host_info[7] = no_split ? 16 : 0;
         if (!mirror) MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-        if (sync_event) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));
+        if (sync_event && !deferred) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));   // (deferred: behind the scatter launch)
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
         // sized by an earlier frame), enqueue emit + rasterise against that capacity NOW and only
         // then wait for the size record -- the GPU never idles on the hand-off.  Every kernel
         // clamps to `cap`, so an overflowing frame writes nothing out of bounds; it is detected
         // in the finishing half and redone on the exact path.
-        const int64_t cap = split ? (isect_bytes > 768 ? (int64_t)((isect_bytes - 768) / 28) : 0)
-                                  : (isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0);
-        if (sync_event && isect_buf && cap > 0 && N > 0) {   // (an empty set has null inputs: exact path, M = 0)
+        if (speculate) {
             const int64_t cmax = split ? ms_split_max_entries() : 0x7fffffffll;
             const int64_t c = cap > cmax ? cmax : cap;
             uint64_t *keys = (uint64_t *)isect_buf;
@@ -229,7 +256,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                 const ms::BlockLists lists{ranges, (int32_t *)((char *)ids + ms::align_up((size_t)c * 4, 256)), bin_more, tw, th};
                 if (int rc = ms::isect_emit_bins(N, means2d, radii, depths, bw, bh, b0, b1, ws + L.off_isect,
                                                  L.isect_bytes, bin_ranges, prev, info, c, bin_flags, lazy,
-                                                 near_plane, far_plane, keys, &lists, stream))
+                                                 near_plane, far_plane, keys, &lists, deferred ? &defer : nullptr, stream))
                     return rc;
                 mark(2);
                 lazy_lists.keys = keys;
@@ -245,10 +272,10 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
             // the previous frame on this record (same scratch, same grid) had no tile beyond the small sort class:
             // bet that this one has none either (bit 5 of host_info[7]; checked against the size record below)
             const bool bet_light = lazy && prev[0] > 0 && prev[2] + prev[3] + prev[4] == 0 && !(prev[7] & 4);
-            if (int rc = ms_isect_tiles_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
-                                                         ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
-                                                         /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy | (bet_light ? 8 : 0),
-                                                         near_plane, far_plane, keys, ids, stream))
+            if (int rc = ms::isect_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
+                                                    ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
+                                                    /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy | (bet_light ? 8 : 0),
+                                                    near_plane, far_plane, keys, ids, deferred ? &defer : nullptr, stream))
                 return rc;
             mark(2);
             lazy_lists.keys = keys;
@@ -319,7 +346,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
         const ms::BlockLists lists{ranges, (int32_t *)((char *)ids + ms::align_up((size_t)M * 4, 256)), bin_more, tw, th};
         if (int rc = ms::isect_emit_bins(N, means2d, radii, depths, bw, bh, b0, b1, ws + L.off_isect, L.isect_bytes,
                                          bin_ranges, host_info, nullptr, c, bin_flags, lazy, near_plane, far_plane,
-                                         keys, &lists, stream))
+                                         keys, &lists, nullptr, stream))
             return rc;
         if (!speculated) mark(2);
         lazy_lists.keys = keys;
@@ -328,9 +355,9 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                                        records, order,
                                        (!speculated && stage_events) ? stage_events[3] : nullptr, stream);
     }
-    if (int rc = ms_isect_tiles_emit(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
-                                     L.isect_bytes, ranges, host_info, /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy, near_plane, far_plane,
-                                     keys, tmp, ids, nullptr, stream))
+    if (int rc = ms::isect_emit_exact(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
+                                      L.isect_bytes, ranges, host_info, /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy, near_plane, far_plane,
+                                      keys, tmp, ids, stream))
         return rc;
     if (!speculated) mark(2);
     lazy_lists.keys = keys;

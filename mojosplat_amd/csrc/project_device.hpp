@@ -37,13 +37,50 @@ static inline ProjParams make_proj_params(float fx, float fy, float cx, float cy
     return P;
 }
 
-// Strict fp32 evaluation order (no FMA contraction) so that the only differences against the CPU
-// oracle come from expf/logf; radii are integers and flip on 1-ulp changes.
-__device__ __forceinline__ ProjOut project_one(int64_t i, const float *__restrict__ means3d,
+// The projection of one Gaussian.
+// -DMS_PROJ_FAST (NOT the shipped build; kept as a measured negative result): the chain written for the
+// instruction count -- the fused projection + count kernel was VALU bound in round 2 (1 200 instructions per
+// Gaussian, a third of them this chain):
+//   * cov2d = (J W M)(J W M)^T with M = R diag(s): the 2x3 matrix T = J W costs 12 operations, B = T R 18,
+//     A = B diag(s) 6 and the three entries of A A^T 9 -- 45 multiply-adds where the reference's order
+//     (cov3d = M M^T, W cov3d W^T, J . J^T; projection.mojo:129-198) takes ~160; same quantity, rounded differently
+//     at the 1e-7 level;
+//   * FMA contraction on; v_rsq_f32 / v_rcp_f32 (+ one Newton step for 1/z and 1/det) / v_sqrt_f32 / v_log_f32
+//     instead of the IEEE division and square-root sequences (~10 instructions each).
+// 507 -> 273 VALU instructions for the stand-alone kernel, k_project_hist 31.8 -> 28.3 us at config 3 -- and 27
+// pixels of the config-3 frame beyond 1e-4 of the oracle's with no branch of its walk within 2e-5 of a threshold
+// (round 2's chain: 0): cov2d's determinant cancels for elongated footprints (condition number a c / det up to
+// ~1e3), so two fp32 evaluations of a, b, c that are each good to 1e-7 but rounded in a different ORDER give conics
+// that differ by 1e-4 relative, i.e. alphas by 5e-4 at the 1/255 threshold.  The shipped chain therefore keeps the
+// reference's operation order for cov2d, uncontracted (bit for bit the oracle's a, b, c up to the ulp of expf), and
+// is fast only where an error is not amplified: the conics' common factor 1 / det.
+template <class Idx>
+__device__ __forceinline__ float ld_f32(const float *base, Idx i, int stride, int k) {
+    if constexpr (sizeof(Idx) == 4)
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (uint32_t)(4u * ((uint32_t)stride * (uint32_t)i + (uint32_t)k)));
+    else
+        return base[(int64_t)stride * i + k];
+}
+template <class Idx>
+__device__ __forceinline__ float4 ld_f32x4(const float *base, Idx i) {
+    if constexpr (sizeof(Idx) == 4)
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + (uint32_t)(16u * (uint32_t)i));
+    else
+        return reinterpret_cast<const float4 *>(base)[i];
+}
+
+__device__ __forceinline__ float rcp_nr(float x) {   // 1 / x to ~0.5 ulp: v_rcp_f32 + one Newton step
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+
+#ifdef MS_PROJ_FAST
+template <class Idx>
+__device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ means3d,
                                                const float *__restrict__ scales, const float *__restrict__ quats,
                                                const float *__restrict__ opacities,
                                                const float *__restrict__ viewmat, const ProjParams &P) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(fast)
     float V[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> s_load
@@ -60,7 +97,7 @@ __device__ __forceinline__ ProjOut project_one(int64_t i, const float *__restric
     if (alive) {
         const float4 q4 = reinterpret_cast<const float4 *>(quats)[i];
         float w = q4.x, x = q4.y, y = q4.z, zq = q4.w;
-        const float inv_norm = 1.0f / sqrtf(x * x + y * y + zq * zq + w * w);
+        const float inv_norm = __builtin_amdgcn_rsqf(x * x + y * y + zq * zq + w * w);
         w *= inv_norm; x *= inv_norm; y *= inv_norm; zq *= inv_norm;
         const float x2 = x * x, y2 = y * y, z2 = zq * zq;
         const float xy = x * y, xz = x * zq, yz = y * zq, wx = w * x, wy = w * y, wz = w * zq;
@@ -69,6 +106,93 @@ __device__ __forceinline__ ProjOut project_one(int64_t i, const float *__restric
         const float R20 = 2.f * (xz - wy), R21 = 2.f * (yz + wx), R22 = 1.f - 2.f * (x2 + y2);
 
         float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+        if (P.scales_are_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
+
+        // pinhole Jacobian with the 1.3x FOV clamp; T = J Wv (2x3)
+        const float rz = rcp_nr(z);
+        const float tx = z * fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz));
+        const float ty = z * fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
+        const float J00 = P.fx * rz, J02 = -(J00 * tx) * rz;
+        const float J11 = P.fy * rz, J12 = -(J11 * ty) * rz;
+        const float T00 = J00 * V[0] + J02 * V[8], T01 = J00 * V[1] + J02 * V[9], T02 = J00 * V[2] + J02 * V[10];
+        const float T10 = J11 * V[4] + J12 * V[8], T11 = J11 * V[5] + J12 * V[9], T12 = J11 * V[6] + J12 * V[10];
+        // A = T R diag(s)
+        const float A00 = (T00 * R00 + T01 * R10 + T02 * R20) * s0, A01 = (T00 * R01 + T01 * R11 + T02 * R21) * s1,
+                    A02 = (T00 * R02 + T01 * R12 + T02 * R22) * s2;
+        const float A10 = (T10 * R00 + T11 * R10 + T12 * R20) * s0, A11 = (T10 * R01 + T11 * R11 + T12 * R21) * s1,
+                    A12 = (T10 * R02 + T11 * R12 + T12 * R22) * s2;
+        const float a = A00 * A00 + A01 * A01 + A02 * A02 + P.eps2d;
+        const float b = A00 * A10 + A01 * A11 + A02 * A12;
+        const float c = A10 * A10 + A11 * A11 + A12 * A12 + P.eps2d;
+        const float m2x = (P.fx * mx) * rz + P.cx, m2y = (P.fy * my) * rz + P.cy;
+
+        const float det = a * c - b * b;
+        alive = det > 0.f;
+
+        float extend = 3.33f;
+        if (alive && P.has_opacity) {
+            const float op = opacities[i];
+            if (op < kAlphaThreshold) {
+                alive = false;
+            } else {
+                extend = fminf(extend, __builtin_amdgcn_sqrtf(2.0f * __logf(op * 255.0f)));
+            }
+        }
+        if (alive) {
+            const float rx = ceilf(extend * __builtin_amdgcn_sqrtf(a)), ry = ceilf(extend * __builtin_amdgcn_sqrtf(c));
+            if (rx <= P.radius_clip && ry <= P.radius_clip) alive = false;
+            if (m2x + rx <= 0.f || m2x - rx >= P.W || m2y + ry <= 0.f || m2y - ry >= P.H) alive = false;
+            if (alive) {
+                const float inv_det = rcp_nr(det);
+                o_c0 = c * inv_det;
+                o_c1 = -b * inv_det;
+                o_c2 = a * inv_det;
+                o_r0 = (int)rx;
+                o_r1 = (int)ry;
+                o_m0 = m2x;
+                o_m1 = m2y;
+                o_d = z;
+            }
+        }
+    }
+    return ProjOut{o_m0, o_m1, o_c0, o_c1, o_c2, o_d, o_r0, o_r1};
+}
+#else
+// The shipped chain: strict fp32 evaluation order (no FMA contraction), the reference's operation order
+// (projection.mojo:89-211), so that the only differences against the CPU oracle come from expf / logf and the
+// conics' common factor; radii are integers and flip on 1-ulp changes.
+template <class Idx>
+__device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ means3d,
+                                               const float *__restrict__ scales, const float *__restrict__ quats,
+                                               const float *__restrict__ opacities,
+                                               const float *__restrict__ viewmat, const ProjParams &P) {
+#pragma clang fp contract(off)
+    float V[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> s_load
+
+    // Idx = uint32_t: byte offsets formed in 32 bits against uniform base pointers (saddr + voffset addressing)
+    const float p0 = ld_f32(means3d, i, 3, 0), p1 = ld_f32(means3d, i, 3, 1), p2 = ld_f32(means3d, i, 3, 2);
+    const float mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
+    const float my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
+    const float z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
+
+    float o_m0 = 0.f, o_m1 = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_d = 0.f;
+    int o_r0 = 0, o_r1 = 0;
+
+    bool alive = !(z < P.near_plane || z > P.far_plane);
+    if (alive) {
+        const float4 q4 = ld_f32x4(quats, i);
+        float w = q4.x, x = q4.y, y = q4.z, zq = q4.w;
+        const float inv_norm = 1.0f / sqrtf(x * x + y * y + zq * zq + w * w);
+        w *= inv_norm; x *= inv_norm; y *= inv_norm; zq *= inv_norm;
+        const float x2 = x * x, y2 = y * y, z2 = zq * zq;
+        const float xy = x * y, xz = x * zq, yz = y * zq, wx = w * x, wy = w * y, wz = w * zq;
+        const float R00 = 1.f - 2.f * (y2 + z2), R01 = 2.f * (xy - wz), R02 = 2.f * (xz + wy);
+        const float R10 = 2.f * (xy + wz), R11 = 1.f - 2.f * (x2 + z2), R12 = 2.f * (yz - wx);
+        const float R20 = 2.f * (xz - wy), R21 = 2.f * (yz + wx), R22 = 1.f - 2.f * (x2 + y2);
+
+        float s0 = ld_f32(scales, i, 3, 0), s1 = ld_f32(scales, i, 3, 1), s2 = ld_f32(scales, i, 3, 2);
         if (P.scales_are_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
 
         // M = R diag(s); cov = M M^T
@@ -125,7 +249,7 @@ __device__ __forceinline__ ProjOut project_one(int64_t i, const float *__restric
 
         float extend = 3.33f;
         if (alive && P.has_opacity) {
-            const float op = opacities[i];
+            const float op = ld_f32(opacities, i, 1, 0);
             if (op < kAlphaThreshold) {
                 alive = false;
             } else {
@@ -137,7 +261,9 @@ __device__ __forceinline__ ProjOut project_one(int64_t i, const float *__restric
             if (rx <= P.radius_clip && ry <= P.radius_clip) alive = false;
             if (m2x + rx <= 0.f || m2x - rx >= P.W || m2y + ry <= 0.f || m2y - ry >= P.H) alive = false;
             if (alive) {
-                const float inv_det = 1.0f / det;
+                // (the conics' common factor: v_rcp_f32 + one Newton step, within an ulp of the IEEE quotient --
+                // a relative error that sigma carries unamplified)
+                const float inv_det = rcp_nr(det);
                 o_c0 = c * inv_det;
                 o_c1 = -b01 * inv_det;
                 o_c2 = a * inv_det;
@@ -151,5 +277,6 @@ __device__ __forceinline__ ProjOut project_one(int64_t i, const float *__restric
     }
     return ProjOut{o_m0, o_m1, o_c0, o_c1, o_c2, o_d, o_r0, o_r1};
 }
+#endif
 
 }  // namespace ms
