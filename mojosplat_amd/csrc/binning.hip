@@ -43,6 +43,16 @@
 
 #include "project_device.hpp"
 
+#ifdef MS_DIAG
+// Diagnostic build only (python -m mojosplat_amd.csrc.build --diag; never the shipped library): per-workgroup phase
+// stamps of the binning kernels (100 MHz chip-wide clock) into a buffer of their own that no other code reads
+// (scripts/bin_phases.py).  Kernel k, workgroup b, stamp j -> g_diag_bin[(k * 1024 + b) * 8 + j].
+__device__ unsigned long long *g_diag_bin = nullptr;
+#define MS_BIN_STAMP(k, j) do { if (g_diag_bin && threadIdx.x == 0 && blockIdx.x < 1024) g_diag_bin[((k) * 1024 + blockIdx.x) * 8 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MS_BIN_STAMP(k, j) do { } while (0)
+#endif
+
 namespace {
 
 #ifndef MS_CHUNK
@@ -494,12 +504,16 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist,
     uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks,
     const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
-    LeanRec *__restrict__ lean) {
-    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter
+    LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth) {
+    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range)
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
+    MS_BIN_STAMP(0, 0);
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
-    if (threadIdx.x == 0) s_on_grid = 0;
+    if (threadIdx.x == 0) { s_on_grid = 0; s_cnt[T_local + 1] = 0xffffffffu; s_cnt[T_local + 2] = 0u; }
+    // lean frames: the range of the depth bits of everything this workgroup's Gaussians can emit, for k_tile_front's
+    // buckets (the scatter kernel -- a chain of round trips -- otherwise ends with this reduction and its barriers)
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
     __syncthreads();
     __shared__ uint32_t s_pref[kMaxG + 1];
     CandMap map{s_pref};
@@ -570,6 +584,9 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                     *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(masks + base) + 8u * (uint32_t)threadIdx.x) = mask;
                 }
             }
+            if constexpr (LEAN) {
+                if (n > 0) { dmin = min(dmin, __float_as_uint(o.d)); dmax = max(dmax, __float_as_uint(o.d)); }
+            }
             if constexpr (LEAN)
                 *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lean + base) + 16u * (uint32_t)threadIdx.x) = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16),
                                                                 __float_as_uint(o.d), (uint32_t)n | ((uint32_t)edges << 28));
@@ -577,11 +594,27 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
         count_on_grid(on_grid, &s_on_grid);
         walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     }
+    if constexpr (LEAN) {
+        if (wg_depth) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d));
+                dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d));
+            }
+            if ((threadIdx.x & 63) == 0) { atomicMin(&s_cnt[T_local + 1], dmin); atomicMax(&s_cnt[T_local + 2], dmax); }
+        }
+    }
+    MS_BIN_STAMP(0, 1);
     __syncthreads();
+    MS_BIN_STAMP(0, 2);
     uint32_t *row = hist + (size_t)wg * T_local;
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
     if (threadIdx.x == 0) wg_on_grid[wg] = s_on_grid;
     if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
+    if constexpr (LEAN) {
+        if (wg_depth && threadIdx.x == 0) { wg_depth[2 * blockIdx.x] = s_cnt[T_local + 1]; wg_depth[2 * blockIdx.x + 1] = s_cnt[T_local + 2]; }
+    }
+    MS_BIN_STAMP(0, 3);
 }
 
 __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
@@ -786,6 +819,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
     constexpr int kScanSlices = 1024 / kScanTiles;
     __shared__ uint32_t s_part[16][kScanTiles];
     __shared__ int s_last;
+    MS_BIN_STAMP(1, 0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int tl = threadIdx.x & (kScanTiles - 1), sl = threadIdx.x / kScanTiles;
     const int t = blockIdx.x * kScanTiles + tl;
@@ -808,7 +842,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
         if (lane >= d) incl += o;
     }
     if (lane >= 64 - kScanTiles) s_part[w][tl] = incl;   // the wave's total for tile tl
+    MS_BIN_STAMP(1, 1);
     __syncthreads();
+    MS_BIN_STAMP(1, 2);
     uint32_t run = incl - sum, total = 0;
 #pragma unroll
     for (int ww = 0; ww < 16; ++ww) {
@@ -832,6 +868,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_wg(int G, int T_local,
     // every dirty line of the 4 MB of prefixes first: measured 61 us.
     if (!A.ticket) {   // the total pass is a launch of its own
         if (sl == 0 && t < T_local) tile_count[t] = total;
+        MS_BIN_STAMP(1, 3);
         return;
     }
     if (sl == 0 && t < T_local) __hip_atomic_store(&tile_count[t], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -851,13 +888,23 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(ScanTotalArgs A) { til
 // workgroup; -> the grand total (64-bit; offsets saturate at INT32_MAX: the host rejects M > INT32_MAX before it
 // trusts any of them).  Three barriers whatever T is: counts -> LDS (coalesced), each thread sums a run of
 // ceil(T / 1024) consecutive entries, wave scans + the 16 wave totals, each thread writes its run back.
-__device__ __forceinline__ unsigned long long tile_prefix_lds(const uint32_t *__restrict__ count, int T, uint32_t *s) {
+// add: an optional row of T words added to the prefix as it is written back (the scatter kernel's histogram row:
+// its loads are issued before the first barrier when a thread's run is at most four entries).
+__device__ __forceinline__ unsigned long long tile_prefix_lds(const uint32_t *__restrict__ count, int T, uint32_t *s,
+                                                              const uint32_t *__restrict__ add = nullptr) {
     __shared__ unsigned long long s_wtot[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int t = tid; t < T; t += kHistThreads) s[t] = count[t];
-    __syncthreads();
     const int per = (T + kHistThreads - 1) / kHistThreads;
     const int j0 = min(T, tid * per), j1 = min(T, j0 + per);
+    uint32_t addv[4] = {0u, 0u, 0u, 0u};
+    const bool pre = add && per <= 4;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (j0 + k < j1) addv[k] = add[j0 + k];
+    }
+    for (int t = tid; t < T; t += kHistThreads) s[t] = count[t];
+    __syncthreads();
     unsigned long long sum = 0;
     for (int j = j0; j < j1; ++j) sum += s[j];
     unsigned long long incl = sum;
@@ -874,10 +921,20 @@ __device__ __forceinline__ unsigned long long tile_prefix_lds(const uint32_t *__
         if (ww < w) run += s_wtot[ww];
         grand += s_wtot[ww];
     }
-    for (int j = j0; j < j1; ++j) {
-        const uint32_t v = s[j];
-        s[j] = (uint32_t)min(run, 0x7fffffffull);
-        run += v;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (j0 + k < j1) {
+                const uint32_t v = s[j0 + k];
+                s[j0 + k] = (uint32_t)min(run, 0x7fffffffull) + addv[k];
+                run += v;
+            }
+    } else {
+        for (int j = j0; j < j1; ++j) {
+            const uint32_t v = s[j];
+            s[j] = (uint32_t)min(run, 0x7fffffffull) + (add ? add[j] : 0u);
+            run += v;
+        }
     }
     __syncthreads();
     return grand;
@@ -987,9 +1044,11 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     extern __shared__ uint32_t s_cur[];
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     const int band0 = g.row_begin * g.tw;
+    MS_BIN_STAMP(2, 0);
     if constexpr (DEFER) {
         if ((int)blockIdx.x >= G) {   // (uniform per workgroup)
             deferred_total((int)blockIdx.x - G, A, s_cur, T_local);
+            MS_BIN_STAMP(2, 4);
             return;
         }
     }
@@ -1006,47 +1065,45 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
             stride = (int64_t)G * kHistThreads;
         }
     }
-    // the first step's record is on its way while the cursors are set up (the kernel is a chain of round trips:
-    // waves sat in s_waitcnt 71 % of their life)
-    LeanRec r_next = {0u, 0u, 0u, 0u};
+    // The kernel is a chain of round trips (waves sat in s_waitcnt 71 % of their life), so everything the first TWO
+    // steps read -- all a workgroup has at 2 048 Gaussians per chunk -- is on its way before the cursors are set
+    // up: the records, and the reach masks (unconditionally: which boxes need theirs is only known from the record)
+    constexpr int kAhead = 2;
+    LeanRec r_q[kAhead] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    unsigned long long m_q[kAhead] = {~0ull, ~0ull};
     if constexpr (LEAN) {
-        if (i0 + threadIdx.x < i1) r_next = lean[i0 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const int64_t j = i0 + k * stride + threadIdx.x;
+            if (j < i1) {
+                r_q[k] = lean[j];
+                if (masks) m_q[k] = masks[j];
+            }
+        }
     }
+    MS_BIN_STAMP(2, 1);
     if constexpr (DEFER) {
-        // (the histogram row's loads go out before the prefix's barriers)
-        constexpr int kPre = 4;
-        uint32_t rpre[kPre];
-        const bool pre = T_local <= kPre * kHistThreads;
-        if (pre) {
-#pragma unroll
-            for (int k = 0; k < kPre; ++k) {
-                const int t = k * kHistThreads + threadIdx.x;
-                rpre[k] = t < T_local ? row[t] : 0u;
-            }
-        }
-        (void)tile_prefix_lds(A.tile_count, T_local, s_cur);
-        if (pre) {
-#pragma unroll
-            for (int k = 0; k < kPre; ++k) {
-                const int t = k * kHistThreads + threadIdx.x;
-                if (t < T_local) s_cur[t] += rpre[k];
-            }
-        } else {
-            for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cur[t] += row[t];
-        }
+        (void)tile_prefix_lds(A.tile_count, T_local, s_cur, row);   // (its last barrier publishes the cursors)
+        MS_BIN_STAMP(2, 2);
     } else {
         for (int t = threadIdx.x; t < T_local; t += kHistThreads)
             s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
+        __syncthreads();
     }
-    __syncthreads();
     // depth bits (order preserving for the positive depths that survive) of everything this workgroup
     // emits: k_tile_front spreads its buckets over the frame's range
     uint32_t dmin = 0xffffffffu, dmax = 0u;
     if constexpr (LEAN) {
         for (int64_t base = i0; base < i1; base += stride) {
-            const LeanRec r = r_next;
-            const int64_t jn = base + stride + threadIdx.x;
-            if (jn < i1) r_next = lean[jn];
+            const LeanRec r = r_q[0];
+            const unsigned long long mk = m_q[0];
+#pragma unroll
+            for (int k = 0; k + 1 < kAhead; ++k) { r_q[k] = r_q[k + 1]; m_q[k] = m_q[k + 1]; }
+            const int64_t jn = base + kAhead * stride + threadIdx.x;
+            if (jn < i1) {
+                r_q[kAhead - 1] = lean[jn];
+                if (masks) m_q[kAhead - 1] = masks[jn];
+            }
             const int64_t j = base + threadIdx.x;
             int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
             unsigned long long mask = ~0ull;
@@ -1055,7 +1112,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
                 edges = (int)(r.n_edges >> 28);
                 x0 = (int)(r.xy0 & 0xffffu); y0 = (int)(r.xy0 >> 16);
                 x1 = (int)(r.xy1 & 0xffffu); y1 = (int)(r.xy1 >> 16);
-                if (masks && (n > 1 || (PACK && n > 0))) mask = masks[j];
+                if (masks && (n > 1 || (PACK && n > 0))) mask = mk;
             }
             const uint32_t dbits = r.depth_bits;
             if (n > 0) { dmin = min(dmin, dbits); dmax = max(dmax, dbits); }
@@ -1077,6 +1134,10 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
             if ((int64_t)slot < M) keys[slot] = key;
         });
     }
+    MS_BIN_STAMP(2, 3);
+#ifdef MS_DIAG
+    if constexpr (LEAN) { __syncthreads(); MS_BIN_STAMP(2, 4); }   // (when the LAST wave is done)
+#endif
     if (wg_depth) {
         uint32_t *s_depth = s_cur + T_local + 1;   // (the 16 spare bytes every binning kernel's LDS block ends with)
         __syncthreads();                           // (the cursors are done with)
@@ -1837,6 +1898,13 @@ const int32_t *ms::isect_order_array(const void *workspace, int64_t N, int tile_
     return (const int32_t *)((const char *)workspace + p.off_order);
 }
 
+#ifdef MS_DIAG
+extern "C" int ms_diag_set_bin_stamps(void *device_buffer) {
+    MS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_bin), &device_buffer, sizeof(void *)));
+    return MS_OK;
+}
+#endif
+
 extern "C" size_t ms_isect_workspace_bytes(int64_t N, int tile_w, int tile_h) {
     Plan p;
     if (tile_w <= 0 || tile_h <= 0 || (int64_t)tile_w * tile_h >= (1ll << 30)) return 0;
@@ -1967,7 +2035,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
                            quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks,
                            colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand,
-                           (LeanRec *)(ws + p.off_lean));
+                           (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg));
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
@@ -2021,7 +2089,8 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G + (deferred ? 2 : 0)), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
                            (const LeanRec *)(ws + p.off_lean), g, p.chunk, hist, tile_ranges, cap, sort_keys,
-                           lazy ? (uint32_t *)(ws + p.off_depth_wg) : nullptr,
+                           // (a lean frame's count kernel has left the per-workgroup depth ranges already)
+                           lazy && !lean ? (uint32_t *)(ws + p.off_depth_wg) : nullptr,
                            (tight & kBandCull) ? Candidates{(const int32_t *)(ws + p.off_cand), (const int32_t *)(ws + p.off_cand_count), p.G, p.chunk}
                                                : Candidates{nullptr, nullptr, 0, 0}, p.G, A);
         MS_LAUNCH_CHECK();
