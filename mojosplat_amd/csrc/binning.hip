@@ -66,6 +66,11 @@ constexpr int kMaxG = 512;
 constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
 constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
 constexpr int kBandCull = 32;      // bit of the `tight` flags: the band's Gaussians were pre-culled (k_band_precull)
+#ifdef MS_NO_LEAN12
+constexpr bool kLean12Enabled = false;   // (variant builds: A/B against the 16 + 8 byte form)
+#else
+constexpr bool kLean12Enabled = true;
+#endif
 constexpr int kLean = 64;          // ... the frame keeps LeanRecs instead of the projected arrays (internal: ms_render_fwd)
 constexpr int kDeferTotal = 128;   // ... the scans' total pass rides in the scatter launch (internal: sync-free frames)
 static_assert(kLean == ms::kTightLean && kDeferTotal == ms::kTightDeferTotal, "internal flag bits out of sync");
@@ -88,6 +93,13 @@ struct Grid {
 // no box arithmetic.  (Grids beyond 65 535 tiles a side keep the full arrays.)
 struct LeanRec {
     uint32_t xy0, xy1, depth_bits, n_edges;
+};
+// ... and on plain bins of grids up to 255 tiles a side (LEAN == 2) ONE 12-byte record carries the reach mask as
+// well: box = x0 | y0 << 8 | w << 16 | h << 24, the depth bits, the low 32 bits of the reach mask (boxes of 33-64
+// tiles keep every tile: count and scatter kernel agree by construction, the image does not depend on it) -- 12
+// bytes written and 12 read per Gaussian instead of 16 + 8.
+struct Lean12 {
+    uint32_t box, depth_bits, mask32;
 };
 
 // Tight binning: which tiles of a Gaussian's box can its alpha >= 1/255 ellipse reach at all?
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
 // LEAN (ms_render_fwd's plain 3-channel forward frames): nobody reads the projected arrays of such a frame -- the
 // rasteriser stages from the ready-made records, the scatter kernel wants the tile box and the depth -- so the
 // kernel stores one 16-byte LeanRec per position instead of means2d / conics / depths / radii (32 bytes).
-template <bool PACK, bool LEAN>
+template <bool PACK, int LEAN>   // LEAN: 0 = the projected arrays, 1 = LeanRec + reach mask, 2 = Lean12 (plain bins)
 __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             const int64_t i = j;
             gi = (int)i;
             const ms::ProjOut o = ms::project_one<uint32_t>(src, means3d + 3 * b0, scales + 3 * b0, quats + 4 * b0, opac_b, viewmat, P);
-            if constexpr (!LEAN) {
+            if constexpr (LEAN == 0) {
                 reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
                 conics[3 * i] = o.c0;
                 conics[3 * i + 1] = o.c1;
@@ -576,25 +588,33 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 on_grid = bin_box<PACK>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
                 if (masks) {
+                    if (LEAN == 2 && n > 32) mask = ~0ull;   // (a 12-byte record has room for 32 tiles' worth)
+                    else
                     if (PACK && n <= 16 && n > 0)   // per half-tile cell (the 16x16 blocks of a 32-px bin)
                         mask = clip_cells(reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), 2 * x0, 2 * x1,
                                                      2 * y0, 2 * y1, g.ts >> 1), edges, x1 - x0, y1 - y0);
                     else
                         mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), x0, x1, y0, y1, g.ts);
-                    *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(masks + base) + 8u * (uint32_t)threadIdx.x) = mask;
+                    if constexpr (LEAN != 2)
+                        *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(masks + base) + 8u * (uint32_t)threadIdx.x) = mask;
                 }
             }
-            if constexpr (LEAN) {
+            if constexpr (LEAN != 0) {
                 if (n > 0) { dmin = min(dmin, __float_as_uint(o.d)); dmax = max(dmax, __float_as_uint(o.d)); }
             }
-            if constexpr (LEAN)
+            if constexpr (LEAN == 2) {
+                uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(reinterpret_cast<Lean12 *>(lean) + base) + 12u * (uint32_t)threadIdx.x);
+                const uint32_t box = n > 0 ? ((uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24)) : 0u;
+                q[0] = box; q[1] = __float_as_uint(o.d); q[2] = (uint32_t)mask;
+            }
+            if constexpr (LEAN == 1)
                 *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lean + base) + 16u * (uint32_t)threadIdx.x) = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16),
                                                                 __float_as_uint(o.d), (uint32_t)n | ((uint32_t)edges << 28));
         }
         count_on_grid(on_grid, &s_on_grid);
         walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     }
-    if constexpr (LEAN) {
+    if constexpr (LEAN != 0) {
         if (wg_depth) {
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
@@ -611,7 +631,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
     if (threadIdx.x == 0) wg_on_grid[wg] = s_on_grid;
     if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
-    if constexpr (LEAN) {
+    if constexpr (LEAN != 0) {
         if (wg_depth && threadIdx.x == 0) { wg_depth[2 * blockIdx.x] = s_cnt[T_local + 1]; wg_depth[2 * blockIdx.x + 1] = s_cnt[T_local + 2]; }
     }
     MS_BIN_STAMP(0, 3);
@@ -1034,7 +1054,7 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
 // LEAN: per-position LeanRecs (+ reach masks) instead of means2d / radii / depths.  DEFER: the launch carries the
 // scans' total pass (deferred_total; gridDim = G + 2), and the tile starts come from the workgroup's own prefix
 // over the tile counts instead of tile_ranges.
-template <bool PACK, bool LEAN, bool DEFER>
+template <bool PACK, int LEAN, bool DEFER>
 __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
@@ -1055,7 +1075,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     const int wg = chunk_of_block(blockIdx.x, G);   // the chunk (and histogram row) the count kernel gave this index
     const uint32_t *row = hist + (size_t)wg * T_local;
     int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk), stride = kHistThreads;
-    if constexpr (LEAN) {
+    if constexpr (LEAN != 0) {
         if (cand.ids) {   // positions of the band's candidate list, step s -> workgroup s mod G (as the count kernel)
             __shared__ uint32_t s_pref[kMaxG + 1];
             CandMap map{s_pref};
@@ -1071,14 +1091,27 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     constexpr int kAhead = 2;
     LeanRec r_q[kAhead] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     unsigned long long m_q[kAhead] = {~0ull, ~0ull};
-    if constexpr (LEAN) {
+    // (LEAN == 2: a 12-byte record, unpacked into the same registers)
+    auto load_rec = [&](int64_t j, LeanRec &r, unsigned long long &m) __attribute__((always_inline)) {
+        if constexpr (LEAN == 2) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const Lean12 *>(lean) + j);
+            const uint32_t box = q[0], db = q[1], mk = q[2];
+            const uint32_t x0 = box & 0xffu, y0 = (box >> 8) & 0xffu, w = (box >> 16) & 0xffu, h = box >> 24;
+            r.xy0 = x0 | (y0 << 16);
+            r.xy1 = (x0 + w) | ((y0 + h) << 16);
+            r.depth_bits = db;
+            r.n_edges = w * h;
+            m = w * h > 32u ? ~0ull : (unsigned long long)mk;
+        } else {
+            r = lean[j];
+            if (masks) m = masks[j];
+        }
+    };
+    if constexpr (LEAN != 0) {
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) {
             const int64_t j = i0 + k * stride + threadIdx.x;
-            if (j < i1) {
-                r_q[k] = lean[j];
-                if (masks) m_q[k] = masks[j];
-            }
+            if (j < i1) load_rec(j, r_q[k], m_q[k]);
         }
     }
     MS_BIN_STAMP(2, 1);
@@ -1093,17 +1126,14 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     // depth bits (order preserving for the positive depths that survive) of everything this workgroup
     // emits: k_tile_front spreads its buckets over the frame's range
     uint32_t dmin = 0xffffffffu, dmax = 0u;
-    if constexpr (LEAN) {
+    if constexpr (LEAN != 0) {
         for (int64_t base = i0; base < i1; base += stride) {
             const LeanRec r = r_q[0];
             const unsigned long long mk = m_q[0];
 #pragma unroll
             for (int k = 0; k + 1 < kAhead; ++k) { r_q[k] = r_q[k + 1]; m_q[k] = m_q[k + 1]; }
             const int64_t jn = base + kAhead * stride + threadIdx.x;
-            if (jn < i1) {
-                r_q[kAhead - 1] = lean[jn];
-                if (masks) m_q[kAhead - 1] = masks[jn];
-            }
+            if (jn < i1) load_rec(jn, r_q[kAhead - 1], m_q[kAhead - 1]);
             const int64_t j = base + threadIdx.x;
             int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
             unsigned long long mask = ~0ull;
@@ -1136,7 +1166,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     }
     MS_BIN_STAMP(2, 3);
 #ifdef MS_DIAG
-    if constexpr (LEAN) { __syncthreads(); MS_BIN_STAMP(2, 4); }   // (when the LAST wave is done)
+    if constexpr (LEAN != 0) { __syncthreads(); MS_BIN_STAMP(2, 4); }   // (when the LAST wave is done)
 #endif
     if (wg_depth) {
         uint32_t *s_depth = s_cur + T_local + 1;   // (the 16 spare bytes every binning kernel's LDS block ends with)
@@ -1154,241 +1184,9 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     }
 }
 
-// ---- per-tile sort in LDS -------------------------------------------------------------
-// Keys are (depth_bits << 32 | gaussian); inside a tile they are distinct.
-//
-// Main path: ONE counting pass on the depth bits.  (depth_bits - min) >> shift maps the tile's
-// depth span order-preservingly onto B ~ n buckets (float bits are monotone in depth for the
-// positive depths that survive projection); an LDS histogram + scan + scatter puts every key
-// into its bucket, and inside a bucket -- 0..3 keys typically -- every key counts the keys
-// smaller than itself (full 64-bit compare) and moves to that rank.  ~6 barriers per tile instead of the O(log^2 n) of a
-// bitonic network.  If some bucket is crowded (many identical depths) the tile falls back to
-// the bitonic network below, which is oblivious to the key distribution.
-template <int THREADS>
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t *s, int P) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < (P >> 1); i += THREADS) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                const int hi = lo + j;
-                const bool up = (lo & k) == 0;
-                const uint64_t a = s[lo], b = s[hi];
-                if ((a > b) == up) { s[lo] = b; s[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__device__ __forceinline__ int next_pow2(int n) {
-    int p = 1;
-    while (p < n) p <<= 1;
-    return p;
-}
-
-constexpr int kMaxBuckets = 2048;  // bucket-array cap (8 KB of counters: two 8192-key workgroups fit a CU)
-constexpr int kBucketFallback = 512;  // a bucket this crowded (identical depths en masse) sends the tile to the bitonic path
-
-// Split frames: a bin's sorted list, still in LDS (low word of s_out[i] = id << 4 | block bits), leaves
-// as the four lists of its 16x16 blocks (ms::BlockLists).  Thread t holds entries e * THREADS + t: ballot
-// + prefix count per (round, wave, block), one wave-wide scan per block over the E * THREADS / 64 counts,
-// then every entry drops into its place.  Order is kept; nothing is tested again.
-// s_w: 260 words of scratch.  Called by every thread of the workgroup (two barriers inside).
-template <int THREADS, int E>
-__device__ __forceinline__ void emit_block_lists(const uint64_t *s_out, int F, int n, int start, int bin, int bin_w,
-                                                 const ms::BlockLists &out, uint32_t *s_w) {
-    constexpr int NW = THREADS / 64, NI = E * NW;
-    static_assert(NI <= 64 && NW >= 4, "one wave scans the counts of one block");
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int base = 4 * start;
-    uint32_t ranks[E];   // 4 x 8 bits: the entry's rank among its wave's entries of each block
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * THREADS + tid;
-        const uint32_t word = i < F ? (uint32_t)s_out[i] : 0u;
-        ranks[e] = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const unsigned long long m = __ballot((word >> b) & 1u);
-            ranks[e] |= __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << (8 * b);
-            if (lane == 0) s_w[b * 64 + e * NW + w] = (uint32_t)__popcll(m);
-        }
-    }
-    __syncthreads();
-    if (w < 4) {
-        const uint32_t v = lane < NI ? s_w[w * 64 + lane] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane < NI) s_w[w * 64 + lane] = incl - v;
-        if (lane == 63) s_w[256 + w] = incl;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * THREADS + tid;
-        if (i >= F) break;
-        const uint32_t word = (uint32_t)s_out[i];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if ((word >> b) & 1u)
-                out.block_ids[base + b * n + (int)s_w[b * 64 + e * NW + w] + (int)((ranks[e] >> (8 * b)) & 0xffu)] =
-                    (int32_t)(word >> 4);
-    }
-    if (tid < 4) {
-        const int by = bin / bin_w, bx = bin - by * bin_w;
-        const int x = 2 * bx + (tid & 1), y = 2 * by + (tid >> 1);
-        if (x < out.tw16 && y < out.th16)
-            reinterpret_cast<int2 *>(out.block_ranges)[y * out.tw16 + x] =
-                make_int2(base + tid * n, base + tid * n + (int)s_w[256 + tid]);
-    }
-    if (tid == 0) out.bin_more[bin] = F < n ? 1 : 0;
-}
-
-template <int THREADS, int E>
-struct SortCfg {
-    static constexpr int CAP = THREADS * E;
-    static constexpr int NB = 2 * CAP <= kMaxBuckets ? 2 * CAP : kMaxBuckets;  // ~2 buckets per key while LDS allows
-    static constexpr size_t LDS = (size_t)CAP * 8 + (size_t)NB * 4 + 64 * 4;
-};
-
-template <int THREADS, int E>
-__device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint64_t *__restrict__ keys_in,
-                                                 int start, int n, int tile,
-                                                 int32_t *__restrict__ flatten_ids,
-                                                 int64_t *__restrict__ isect_ids,
-                                                 uint64_t *__restrict__ keys_out,
-                                                 const ms::BlockLists *blocks = nullptr, int bin_w = 0) {
-    using Cfg = SortCfg<THREADS, E>;
-    constexpr int NW = THREADS / 64;
-    uint64_t *s_out = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + Cfg::CAP);
-    uint32_t *s_red = s_cnt + Cfg::NB;  // 64 words of reduction scratch
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-
-    // 1. keys -> registers; min / max of the depth bits
-    uint64_t k[E];
-    uint32_t kmin = 0xffffffffu, kmax = 0u;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * THREADS + tid;
-        k[e] = i < n ? keys_in[start + i] : ~0ull;
-        if (i < n) {
-            const uint32_t hi = (uint32_t)(k[e] >> 32);
-            kmin = min(kmin, hi);
-            kmax = max(kmax, hi);
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
-    }
-    if (lane == 0) { s_red[w] = kmin; s_red[16 + w] = kmax; }
-    const int B = min(Cfg::NB, max(64, 2 * next_pow2(n)));
-    for (int b = tid; b < B; b += THREADS) s_cnt[b] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) { kmin = min(kmin, s_red[ww]); kmax = max(kmax, s_red[16 + ww]); }
-    const uint32_t span = kmax - kmin;
-    const int bits = span ? 32 - __clz(span) : 0;
-    const int shift = max(0, bits - (31 - __clz(B)));
-
-    // 2. histogram
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (e * THREADS + tid < n) atomicAdd(&s_cnt[((uint32_t)(k[e] >> 32) - kmin) >> shift], 1u);
-    __syncthreads();
-
-    // 3. exclusive scan of the B counters (each lane owns `per` consecutive ones)
-    const int per = (B + THREADS - 1) / THREADS;   // <= NB / THREADS, a power of two or 1
-    uint32_t local[Cfg::NB / THREADS > 0 ? Cfg::NB / THREADS : 1];
-    uint32_t sum = 0, cmax = 0;
-#pragma unroll
-    for (int q = 0; q < (int)(sizeof(local) / 4); ++q) {
-        const int b = tid * per + q;
-        local[q] = (q < per && b < B) ? s_cnt[b] : 0u;
-        sum += local[q];
-        cmax = max(cmax, local[q]);
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += o;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d));
-    __syncthreads();  // s_red reuse
-    if (lane == 63) s_red[w] = incl;
-    if (lane == 0) s_red[16 + w] = cmax;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    cmax = 0;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) {
-        if (ww < w) run += s_red[ww];
-        cmax = max(cmax, s_red[16 + ww]);
-    }
-#pragma unroll
-    for (int q = 0; q < (int)(sizeof(local) / 4); ++q) {
-        const int b = tid * per + q;
-        if (q < per && b < B) { s_cnt[b] = run; run += local[q]; }
-    }
-    __syncthreads();
-
-    // 4. scatter into buckets (s_cnt[b] becomes the END of bucket b)
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (e * THREADS + tid < n) {
-            const uint32_t pos = atomicAdd(&s_cnt[((uint32_t)(k[e] >> 32) - kmin) >> shift], 1u);
-            s_out[pos] = k[e];
-        }
-    __syncthreads();
-
-    // 5. finish.  Every key ranks itself inside its bucket (reads only: k independent LDS loads
-    //    for a bucket of k keys, no divergent dependent chains), barrier, then drops into place.
-    //    Keys are distinct, so ranks are a permutation.  A crowded bucket (many identical depths)
-    //    sends the tile to the oblivious network instead.
-    if (cmax <= (uint32_t)kBucketFallback) {
-        int dest[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            dest[e] = -1;
-            if (e * THREADS + tid < n) {
-                const uint32_t b = ((uint32_t)(k[e] >> 32) - kmin) >> shift;
-                const int beg = b ? (int)s_cnt[b - 1] : 0, end = (int)s_cnt[b];
-                int r = 0;
-                for (int j = beg; j < end; ++j) r += s_out[j] < k[e] ? 1 : 0;
-                dest[e] = beg + r;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (dest[e] >= 0) s_out[dest[e]] = k[e];
-    } else {
-        const int P = max(2, next_pow2(n));
-        for (int i = n + tid; i < P; i += THREADS) s_out[i] = ~0ull;
-        __syncthreads();
-        bitonic_sort_lds<THREADS>(s_out, P);
-    }
-    __syncthreads();
-    if (blocks) {   // split frame: block lists instead of the bin's own list
-        if constexpr (E * (THREADS / 64) <= 64)   // (only the small class sorts bins)
-            emit_block_lists<THREADS, E>(s_out, n, n, start, tile, bin_w, *blocks, s_cnt);
-        return;
-    }
-    for (int i = tid; i < n; i += THREADS) {
-        const uint64_t v = s_out[i];
-        if (flatten_ids) flatten_ids[start + i] = (int32_t)(uint32_t)v;
-        if (isect_ids) isect_ids[start + i] = ((int64_t)tile << 32) | (int64_t)(v >> 32);
-        if (keys_out) keys_out[start + i] = v;
-    }
-}
+}  // namespace
+#include "sort_device.hpp"
+namespace {
 
 constexpr int kSmallCap = SortCfg<256, 4>::CAP;     // 1024: one 256-thread workgroup, 12 KB LDS
 constexpr int kMediumCap = SortCfg<1024, 8>::CAP;   // 8192: 1024 threads, 80 KB LDS
@@ -1457,12 +1255,8 @@ __global__ __launch_bounds__(1024, (E <= 8 ? 8 : 4)) void k_tile_sort_list(const
 #ifndef MS_MERGED_WAVES
 #define MS_MERGED_WAVES 6   // waves per SIMD the merged sort kernel is compiled for (8: spills; 6 measured best, profiles/r02_merged_sort.md)
 #endif
-constexpr int kFrontK = 1024;
-constexpr int kFrontCap = 4096;   // LDS room for selected keys (32 KB)
 constexpr int kFrontThreads = 512;           // more workgroups in flight than with 1024 (heavy tiles are latency bound)
-constexpr int kFrontNB = 4 * kFrontThreads;  // four buckets per thread in the scan
-constexpr int kFrontLogNB = 11;
-static_assert((1 << kFrontLogNB) == kFrontNB, "bucket count");
+static_assert(kFrontNB == 4 * kFrontThreads, "four buckets per thread in the scan");
 constexpr size_t kFrontLds = (size_t)kFrontCap * 8 + (size_t)kFrontNB * 4 + 64 * 4 + 16;
 
 // MERGED (plain bins of a lazily sorted frame): ONE launch sorts every list of the band -- block b takes tile
@@ -1552,131 +1346,8 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
             }
             continue;
         }
-        const uint64_t *kin = keys + start;
-        // A. depth-bit range: the camera's [near, far] when the caller knows it (every surviving
-        //    depth lies inside, so the pass over the keys is saved), else the tile's own min / max
-        uint32_t kmin = fixed_min;
-        int shift = fixed_shift;
-        for (int b = tid; b < kFrontNB; b += THREADS) s_cnt[b] = 0;
-        if (fixed_shift < 0) {
-            uint32_t kmax = 0u;
-            kmin = 0xffffffffu;
-            for (int i = tid; i < n; i += THREADS) {
-                const uint32_t d = (uint32_t)(kin[i] >> 32);
-                kmin = min(kmin, d);
-                kmax = max(kmax, d);
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d));
-                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
-            }
-            if (lane == 0) { s_red[w] = kmin; s_red[16 + w] = kmax; }
-            __syncthreads();
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) { kmin = min(kmin, s_red[ww]); kmax = max(kmax, s_red[16 + ww]); }
-            const uint32_t span = kmax - kmin;
-            const int bits = span ? 32 - __clz(span) : 0;
-            shift = max(0, bits - kFrontLogNB);
-        } else {
-            __syncthreads();
-        }
-        // B. histogram
-        auto bucket_of = [&](uint64_t k) -> int {
-            const uint32_t d = (uint32_t)(k >> 32);
-            const uint32_t b = (d > kmin ? d - kmin : 0u) >> shift;
-            return (int)min(b, (uint32_t)(kFrontNB - 1));
-        };
-        // (both passes over the keys fetch kLoads keys per thread before touching them: one memory round trip
-        // per kLoads * THREADS keys instead of one per THREADS -- the kernel lasts as long as its largest
-        // list takes, and that was 2 x n / THREADS dependent round trips)
-        constexpr int kLoads = SPLIT ? 8 : 4;   // (4: the plain variant stays within 64 VGPRs, 8 waves/SIMD)
-        for (int i0 = 0; i0 < n; i0 += kLoads * THREADS) {
-            uint32_t d[kLoads];
-#pragma unroll
-            for (int u = 0; u < kLoads; ++u) {
-                const int i = i0 + u * THREADS + tid;
-                d[u] = (uint32_t)(kin[min(i, n - 1)] >> 32);   // (unconditional: the loads of a batch issue together)
-            }
-#pragma unroll
-            for (int u = 0; u < kLoads; ++u)
-                if (i0 + u * THREADS + tid < n) atomicAdd(&s_cnt[bucket_of((uint64_t)d[u] << 32)], 1u);
-        }
-        __syncthreads();
-        // scan: thread t owns kBpt consecutive buckets
-        constexpr int kBpt = kFrontNB / THREADS;
-        uint32_t c[kBpt], sum = 0;
-#pragma unroll
-        for (int j = 0; j < kBpt; ++j) { c[j] = s_cnt[kBpt * tid + j]; sum += c[j]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += o;
-        }
-        __syncthreads();   // s_red reuse
-        if (lane == 63) s_red[w] = incl;
-        if (tid == 0) { s_sel[0] = -1; s_sel[1] = 0; }
-        __syncthreads();
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww)
-            if (ww < w) run += s_red[ww];
-        // b* = the bucket whose inclusive prefix first reaches kFrontK (n > kFrontK, so it exists);
-        // if that would overflow the LDS room, stop one bucket earlier (possibly with nothing:
-        // >= kFrontCap entries at one depth -- the clean-up kernel takes such a tile)
-        // (front_k: kFrontK per 16x16 block of the tile; a tile shorter than that is selected whole)
-        const uint32_t want = min((uint32_t)front_k, (uint32_t)n);
-#pragma unroll
-        for (int j = 0; j < kBpt; ++j) {
-            const uint32_t e = run, i = run + c[j];   // exclusive / inclusive prefix of bucket kBpt * tid + j
-            if (c[j] && e < want && i >= want) {
-                if (i <= (uint32_t)front_cap) { s_sel[0] = kBpt * tid + j; s_sel[1] = (int)i; }
-                else { s_sel[0] = kBpt * tid + j - 1; s_sel[1] = (int)e; }
-            }
-            s_cnt[kBpt * tid + j] = e;
-            run = i;
-        }
-        __syncthreads();
-        const int bstar = s_sel[0], F = s_sel[1];
-        // C. select
-        for (int i0 = 0; i0 < n; i0 += kLoads * THREADS) {
-            uint64_t k[kLoads];
-#pragma unroll
-            for (int u = 0; u < kLoads; ++u) {
-                const int i = i0 + u * THREADS + tid;
-                k[u] = kin[min(i, n - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < kLoads; ++u) {
-                const int b = bucket_of(k[u]);
-                if (i0 + u * THREADS + tid < n && b <= bstar)
-                    s_out[atomicAdd(&s_cnt[b], 1u)] = k[u];   // s_cnt[b] becomes the END of bucket b
-            }
-        }
-        __syncthreads();
-        // rank inside the bucket; keys are distinct, so ranks are a permutation
-        uint64_t kk[kFrontCap / THREADS];
-        int dest[kFrontCap / THREADS];
-#pragma unroll
-        for (int e = 0; e < kFrontCap / THREADS; ++e) {
-            const int i = e * THREADS + tid;
-            dest[e] = -1;
-            if (i < F) {
-                kk[e] = s_out[i];
-                const int b = bucket_of(kk[e]);
-                const int beg = b ? (int)s_cnt[b - 1] : 0, end = (int)s_cnt[b];
-                // buckets > b* kept their exclusive prefix in s_cnt, so s_cnt[b-1] is the end of b-1 for every b <= b*
-                int r = 0;
-                for (int j = beg; j < end; ++j) r += s_out[j] < kk[e] ? 1 : 0;
-                dest[e] = beg + r;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < kFrontCap / THREADS; ++e)
-            if (dest[e] >= 0) s_out[dest[e]] = kk[e];
-        __syncthreads();
+        const int F = front_select_lds<THREADS, (SPLIT ? 8 : 4)>(keys + start, n, s_out, s_cnt, s_red, s_sel, fixed_min, fixed_shift,
+                                                                 front_k, front_cap);
         if constexpr (SPLIT) emit_block_lists<THREADS, kFrontCap / THREADS>(s_out, F, n, start, tile, bin_w, blocks, s_cnt);
         else
             for (int i = tid; i < F; i += THREADS) flatten_ids[start + i] = (int32_t)(uint32_t)s_out[i];
@@ -1872,6 +1543,38 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
 }
 }  // namespace
 
+// How deep the lazily sorted fronts of a frame are and how their depth buckets are laid out (k_tile_front).  `lazy`: bits 1-2 = the front level the caller asked for.
+ms::FrontParams ms::front_params(int tile_size, int lazy, float depth_near, float depth_far, bool merged, bool split) {
+    ms::FrontParams fp;
+    // all surviving depths lie in the camera's (near, far): fixed order-preserving buckets
+    fp.fixed_min = 0;
+    fp.fixed_shift = -1;
+    if (depth_near > 0.f && depth_far > depth_near) {
+        uint32_t lo, hi;
+        memcpy(&lo, &depth_near, 4);
+        memcpy(&hi, &depth_far, 4);
+        const uint32_t span = hi - lo;
+        int bits = 0;
+        while (bits < 32 && (span >> bits)) ++bits;
+        fp.fixed_min = lo;
+        fp.fixed_shift = bits > kFrontLogNB ? bits - kFrontLogNB : 0;
+    }
+    // a tile of (tile_size/16)^2 blocks needs that many times the front of one block (up to the LDS room)
+    const int blocks_per_tile = ((tile_size + 15) / 16) * ((tile_size + 15) / 16);
+    // split frames: 1280 of a 32-px bin's nearest entries saturate its four blocks on the BASELINE
+    // scenes (1024: one bin of config 3 falls short; 2048: +9 us).  A caller that saw the clean-up pass
+    // run asks for deeper fronts (lazy bits 1-2: front level, x2 each, up to the LDS room).
+    static const int front_env = [] { const char *e = getenv("MOJOSPLAT_FRONT_K"); return e ? atoi(e) : 0; }();
+    // plain 32-px bins: 1536 (config 3: 2048 costs +5 us per frame, 1024 sends one bin to the clean-up pass)
+    int front_k = split ? 1280 : blocks_per_tile == 4 ? 1536 : min(kFrontK * blocks_per_tile, 2048);
+    if (front_env >= 256 && front_env <= kFrontCap && blocks_per_tile > 1) front_k = front_env;   // (measurements)
+    fp.front_k = min(front_k << ((lazy >> 1) & 3), kFrontCap);   // (3072: 1-3 % slower, no fewer clean-ups on the BASELINE scenes)
+    // LDS room for the selected keys: the front plus the bucket that completes it; the merged launch
+    // keeps it small (2048 keys: 25 KB per workgroup, four 512-thread workgroups per CU)
+    fp.front_cap = merged ? min(kFrontCap, max(2048, (fp.front_k * 4 / 3 + 511) & ~511)) : kFrontCap;
+    return fp;
+}
+
 // Where the lazy-sorting bookkeeping lives inside an isect workspace (for ms_render_fwd's rasteriser).
 void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, ms::LazyLists *out) {
     Plan p;
@@ -2027,9 +1730,10 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
     {   // also for N == 0 (one workgroup that walks nothing): the histogram row and the on-grid slot the
         // scans read must exist
         // lean frame: LeanRecs instead of the projected arrays (the caller vouches that nobody reads those)
-        const bool lean = (tight & kLean) && raster_records && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
-        auto kernel = pack ? (lean ? k_project_hist<true, true> : k_project_hist<true, false>)
-                           : (lean ? k_project_hist<false, true> : k_project_hist<false, false>);
+        const bool lean = (tight & kLean) && raster_records && masks && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
+        const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255 && kLean12Enabled;
+        auto kernel = pack ? (lean ? k_project_hist<true, 1> : k_project_hist<true, 0>)
+                           : (lean12 ? k_project_hist<false, 2> : lean ? k_project_hist<false, 1> : k_project_hist<false, 0>);
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
@@ -2070,7 +1774,8 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                   n_large = spec ? 0 : host_info[3], n_xl = spec ? 0 : host_info[4];
 
     {
-        const bool lean = (tight & kLean) && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
+        const bool lean = (tight & kLean) && masks && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
+        const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255 && kLean12Enabled;
         const bool deferred = defer && p.T_local > 0;
         ScanTotalArgs A{};
         if (deferred) {
@@ -2079,12 +1784,14 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                               (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count), defer->band_only,
                               defer->info, defer->info_mirror, (int32_t *)(ws + p.off_order), nullptr};
         }
-        auto pick = [&](auto packc) {
+        auto pick = [&](auto packc, auto leanc) {
             constexpr bool PK = decltype(packc)::value;
-            return lean ? (deferred ? k_isect_scatter<PK, true, true> : k_isect_scatter<PK, true, false>)
-                        : (deferred ? k_isect_scatter<PK, false, true> : k_isect_scatter<PK, false, false>);
+            constexpr int LN = decltype(leanc)::value;
+            return deferred ? k_isect_scatter<PK, LN, true> : k_isect_scatter<PK, LN, false>;
         };
-        auto kernel = pack ? pick(std::true_type{}) : pick(std::false_type{});
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        auto kernel = pack ? (lean ? pick(std::true_type{}, I1{}) : pick(std::true_type{}, I0{}))
+                           : (lean12 ? pick(std::false_type{}, I2{}) : lean ? pick(std::false_type{}, I1{}) : pick(std::false_type{}, I0{}));
         if (p.lds_bytes > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G + (deferred ? 2 : 0)), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
@@ -2132,32 +1839,9 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             }
             const unsigned grid = spec ? (unsigned)min((int64_t)min(p.T, 1024), guess)
                                        : (unsigned)(heavy < 1024 ? heavy : 1024);
-            // all surviving depths lie in the camera's (near, far): fixed order-preserving buckets
-            uint32_t fixed_min = 0;
-            int fixed_shift = -1;
-            if (depth_near > 0.f && depth_far > depth_near) {
-                uint32_t lo, hi;
-                memcpy(&lo, &depth_near, 4);
-                memcpy(&hi, &depth_far, 4);
-                const uint32_t span = hi - lo;
-                int bits = 0;
-                while (bits < 32 && (span >> bits)) ++bits;
-                fixed_min = lo;
-                fixed_shift = bits > kFrontLogNB ? bits - kFrontLogNB : 0;
-            }
-            // a tile of (tile_size/16)^2 blocks needs that many times the front of one block (up to the LDS room)
-            const int blocks_per_tile = ((tile_size + 15) / 16) * ((tile_size + 15) / 16);
-            // split frames (bl): 1280 of a 32-px bin's nearest entries saturate its four blocks on the BASELINE
-            // scenes (1024: one bin of config 3 falls short; 2048: +9 us).  A caller that saw the clean-up pass
-            // run asks for deeper fronts (lazy bits 1-2: front level, x2 each, up to the LDS room).
-            static const int front_env = [] { const char *e = getenv("MOJOSPLAT_FRONT_K"); return e ? atoi(e) : 0; }();
-            // plain 32-px bins: 1536 (config 3: 2048 costs +5 us per frame, 1024 sends one bin to the clean-up pass)
-            int front_k = bl.block_ids ? 1280 : blocks_per_tile == 4 ? 1536 : min(kFrontK * blocks_per_tile, 2048);
-            if (front_env >= 256 && front_env <= kFrontCap && blocks_per_tile > 1) front_k = front_env;   // (measurements)
-            front_k = min(front_k << ((lazy >> 1) & 3), kFrontCap);   // (3072: 1-3 % slower, no fewer clean-ups on the BASELINE scenes)
-            // LDS room for the selected keys: the front plus the bucket that completes it; the merged launch
-            // keeps it small (2048 keys: 25 KB per workgroup, four 512-thread workgroups per CU)
-            const int front_cap = merged ? min(kFrontCap, max(2048, (front_k * 4 / 3 + 511) & ~511)) : kFrontCap;
+            const ms::FrontParams fp = ms::front_params(tile_size, lazy, depth_near, depth_far, merged, bl.block_ids != nullptr);
+            const uint32_t fixed_min = fp.fixed_min;
+            const int fixed_shift = fp.fixed_shift, front_k = fp.front_k, front_cap = fp.front_cap;
             const size_t front_lds = kFrontLds - (size_t)(kFrontCap - front_cap) * 8;
             hipLaunchKernelGGL(front, dim3(merged ? (unsigned)p.T_local : grid), dim3(kFrontThreads), front_lds, stream,
                                medium, large, xl,

@@ -103,6 +103,12 @@ struct LazyLists {
                             // 64-workgroup launch costs 4.5 us, a one-workgroup one 2), 64 after a frame that did
 };
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
+// lazily sorted fronts: depth (entries) of a front, LDS room for it, depth buckets from the camera planes
+struct FrontParams {
+    uint32_t fixed_min;
+    int fixed_shift, front_k, front_cap;
+};
+FrontParams front_params(int tile_size, int lazy, float depth_near, float depth_far, bool merged, bool split);
 const int32_t *isect_order_array(const void *workspace, int64_t N, int tile_w, int tile_h);
 
 // rasterize.hip: ms_rasterize_to_pixels_3dgs_fwd with a separate density hint (ms_render_fwd's

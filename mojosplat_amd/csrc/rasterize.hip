@@ -160,70 +160,34 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int kGroup = MS_RASTER_GROUP;   // records evaluated per trip of the blend loop
 constexpr int kUnroll = MS_RASTER_UNROLL; // trips unrolled
 
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
-__global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
-    static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
-    // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
-    // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
-    // ...: dealt round-robin over the 8 XCDs, they land on ONE XCD back to back and share its L2 for the list they
-    // all stage (speed only, never correctness)
-    constexpr int WPB = 1;
-    constexpr int kParts = 4 / NQ;
-    // CP == 3: r, g ride in the second word; blue is a float of its own per slot (with the index in the batch beside
-    // it for a frame that keeps per-pixel records): a pair's two blues are ONE ds_read_b64, and staging writes 36 B
-    // per record, not 48 (the LDS array is 73 % busy in this kernel, SQ_LDS_IDX_ACTIVE)
-    // (measured against the 16-byte colour slot of before: 94.4 / 94.5 us against 94.2 / 94.8 -- no difference in time,
-    // 25 % less LDS per wave)
-    constexpr int CS = (CP == 3) ? (AUX ? 2 : 1) : CP;
-    constexpr int kSlots = kBatch + kGroup;      // room for the neutral records that pad a list to a multiple of kGroup
-    // One LDS block per (wave, quad): the records of the entries that REACH the quad, compacted in list order.
-    // The three arrays sit at fixed offsets, so a record's words share one index * 16 B and the blend loop
-    // reaches kGroup consecutive records from ONE address register through the instructions' offset fields.
-    // (colours first: a pair's two blues are then within ds_read2_b32's 1 KB offset reach of the same address)
-    struct Stage {
-        __attribute__((aligned(16))) float col[(kSlots * CS + 3) & ~3];  // CP == 3: blue (, index in batch)
-        float4 a[kSlots];        // mean.x, mean.y, a', b'
-        float4 b[kSlots];        // c', log2(opacity), (r, g | index in batch, -)
-    };
-    __shared__ Stage s_stage[WPB][NQ];
-    const int wib = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int wg = blockIdx.x, part = wib;   // workgroup index in units of blocks, and which of the block's waves this is
-    if constexpr (kParts > 1) {
-        const int j = blockIdx.x >> 3;
-        part = j % kParts;
-        wg = ((j / kParts) << 3) | (blockIdx.x & 7);
-        if (wg >= A.ngrid) return;
-    }
+// One LDS block per (wave, quad): the records of the entries that REACH the quad, compacted in list order.
+// The three arrays sit at fixed offsets, so a record's words share one index * 16 B and the blend loop
+// reaches kGroup consecutive records from ONE address register through the instructions' offset fields.
+// (colours first: a pair's two blues are then within ds_read2_b32's 1 KB offset reach of the same address)
+// CP == 3: r, g ride in the second word; blue is a float of its own per slot (with the index in the batch beside
+// it for a frame that keeps per-pixel records): a pair's two blues are ONE ds_read_b64, and staging writes 36 B
+// per record, not 48 (the LDS array is 73 % busy in this kernel, SQ_LDS_IDX_ACTIVE)
+// (measured against the 16-byte colour slot of before: 94.4 / 94.5 us against 94.2 / 94.8 -- no difference in time,
+// 25 % less LDS per wave)
+template <int CP, bool AUX>
+struct RasterStage {
+    static constexpr int CS = (CP == 3) ? (AUX ? 2 : 1) : CP;
+    static constexpr int kSlots = kBatch + kGroup;      // room for the neutral records that pad a list to a multiple of kGroup
+    __attribute__((aligned(16))) float col[(kSlots * CS + 3) & ~3];  // CP == 3: blue (, index in batch)
+    float4 a[kSlots];        // mean.x, mean.y, a', b'
+    float4 b[kSlots];        // c', log2(opacity), (r, g | index in batch, -)
+};
 
+// One wave's share of a 16x16 block: NQ quads of block `sub` of tile `tile`, starting at quad part * NQ.  s_q: the
+// wave's NQ staging blocks.
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
+__device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile, const int sub, const int part,
+                                            RasterStage<CP, AUX> *s_q, const int diag_slot) {
+    static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
+    using Stage = RasterStage<CP, AUX>;
+    constexpr int CS = Stage::CS;
     MS_DIAG_ONLY(const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime(), diag_c0 = __builtin_amdgcn_s_memtime(); unsigned diag_evals = 0, diag_batches = 0;)
-    // blockIdx -> 16x16 block: heaviest first when the binning stage has left an order, else image order
-    // interleaved over the XCDs
     const int qbase = NQ == 4 ? 0 : part * NQ;
-    int tile, sub;
-    if (A.order && A.order_bins) {   // split frame: the order lists 32-px bins, four workgroups (blocks) per bin
-        const int e = A.order[wg >> 2], sb = wg & 3;
-        const int by16 = 2 * (e / A.lazy.bin_w) + (sb >> 1), bx16 = 2 * (e % A.lazy.bin_w) + (sb & 1);
-        if (bx16 >= A.tw || by16 < A.row0 || by16 >= A.row1) return;   // (uniform per workgroup; no barrier anywhere)
-        tile = by16 * A.tw + bx16;
-        sub = 0;
-    } else if (A.order) {
-#ifdef MS_RASTER_SUBS_APART
-        tile = A.order[wg / A.nsub];
-        sub = wg % A.nsub;
-#else
-        // the nsub 16x16 blocks of a coarse tile on ONE XCD (wg & 7 labels it), back to back: they gather the
-        // same records, so the tile's list and records cross into that L2 once instead of nsub times
-        const int e = ((wg >> 3) / A.nsub) * 8 + (wg & 7);
-        if (e >= A.nblocks / A.nsub) return;   // (uniform per workgroup; the grid is padded to 8 tiles)
-        tile = A.order[e];
-        sub = (wg >> 3) % A.nsub;
-#endif
-    } else {
-        const int item = xcd_remap(wg, A.nblocks);
-        const int bt = item / A.nsub;
-        sub = item - bt * A.nsub;
-        tile = A.tile0 + bt;
-    }
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
     if (!A.order_bins) {   // a band cut at 16-px rows inside coarser tiles: blocks outside it are not this call's
@@ -354,7 +318,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_
         else r_b.z = __int_as_float(lane);
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
-            Stage &S = s_stage[wib][qi];
+            Stage &S = s_q[qi];
             const unsigned long long b = B[qi];
             const int n = __popcll(b);
             if ((mask >> qi) & 1) {
@@ -402,7 +366,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_
                 const int q = qbase + qi;
                 if (!__any(kq[qi] != 0.f)) continue;  // every pixel of this quad is finished (or outside)
                 const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
-                const Stage &S = s_stage[wib][qi];
+                const Stage &S = s_q[qi];
                 const int n = __popcll(B[qi]);
                 // kGroup records per trip: their LDS reads go out together, the kGroup log2(alpha) chains and
                 // exp2 are independent of each other (and of the T chain), then the blends run in list order
@@ -510,7 +474,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_
 
 #ifdef MS_DIAG
     if (g_diag_stamps && lane == 0) {
-        unsigned long long *d = g_diag_stamps + 8 * ((size_t)wg * kParts + part);
+        unsigned long long *d = g_diag_stamps + 8 * (size_t)diag_slot;
         d[0] = diag_t0;                               // 100 MHz, chip-wide
         d[1] = __builtin_amdgcn_s_memrealtime();
         d[4] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this wave's life
@@ -551,6 +515,51 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_
             if (A.last_ids) A.last_ids[p] = last[qi];
         }
     }
+}
+
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
+__global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
+    // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
+    // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
+    // ...: dealt round-robin over the 8 XCDs, they land on ONE XCD back to back and share its L2 for the list they
+    // all stage (speed only, never correctness)
+    constexpr int kParts = 4 / NQ;
+    __shared__ RasterStage<CP, AUX> s_stage[NQ];
+    int wg = blockIdx.x, part = 0;   // workgroup index in units of blocks, and which of the block's waves this is
+    if constexpr (kParts > 1) {
+        const int j = blockIdx.x >> 3;
+        part = j % kParts;
+        wg = ((j / kParts) << 3) | (blockIdx.x & 7);
+        if (wg >= A.ngrid) return;
+    }
+    // blockIdx -> 16x16 block: heaviest first when the binning stage has left an order, else image order
+    // interleaved over the XCDs
+    int tile, sub;
+    if (A.order && A.order_bins) {   // split frame: the order lists 32-px bins, four workgroups (blocks) per bin
+        const int e = A.order[wg >> 2], sb = wg & 3;
+        const int by16 = 2 * (e / A.lazy.bin_w) + (sb >> 1), bx16 = 2 * (e % A.lazy.bin_w) + (sb & 1);
+        if (bx16 >= A.tw || by16 < A.row0 || by16 >= A.row1) return;   // (uniform per workgroup; no barrier anywhere)
+        tile = by16 * A.tw + bx16;
+        sub = 0;
+    } else if (A.order) {
+#ifdef MS_RASTER_SUBS_APART
+        tile = A.order[wg / A.nsub];
+        sub = wg % A.nsub;
+#else
+        // the nsub 16x16 blocks of a coarse tile on ONE XCD (wg & 7 labels it), back to back: they gather the
+        // same records, so the tile's list and records cross into that L2 once instead of nsub times
+        const int e = ((wg >> 3) / A.nsub) * 8 + (wg & 7);
+        if (e >= A.nblocks / A.nsub) return;   // (uniform per workgroup; the grid is padded to 8 tiles)
+        tile = A.order[e];
+        sub = (wg >> 3) % A.nsub;
+#endif
+    } else {
+        const int item = xcd_remap(wg, A.nblocks);
+        const int bt = item / A.nsub;
+        sub = item - bt * A.nsub;
+        tile = A.tile0 + bt;
+    }
+    raster_tile<CP, ColorT, AUX, NQ, PACKED>(A, tile, sub, part, s_stage, wg * kParts + part);
 }
 
 // ---- clean-up pass of a lazily sorted frame -----------------------------------------------------
