@@ -606,6 +606,13 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
         stamps.append(time.perf_counter())
     dt = stamps[-1] - stamps[0]
     periods = sorted(b - a for a, b in zip(stamps[:-1], stamps[1:]))
+    # ... and streamed: the host runs ahead of the GPU (as it does when the optimiser step is enqueued behind the
+    # backward and nothing is read back), one synchronisation at the end
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt_streamed = time.perf_counter() - t0
     m_lists = int(host[0])            # pairs on the differentiable frame's lists (16-px tiles, tight binning)
     finite = all(bool(torch.isfinite(l.grad).all()) for l in leaves)
     # stage times
@@ -635,11 +642,12 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
     return {"what": "render_gaussians_trainable forward + (img * v).sum().backward(), grads for means3d / scales / quats / "
                     "opacities / colours; every step synchronised (a training step ends with its gradients)",
             "steps": steps, "ms_per_step_mean": round(dt / steps * 1e3, 4),
-            "ms_per_step_median": round(periods[len(periods) // 2] * 1e3, 4), "grads_finite": finite,
+            "ms_per_step_median": round(periods[len(periods) // 2] * 1e3, 4),
+            "ms_per_step_streamed": round(dt_streamed / steps * 1e3, 4), "grads_finite": finite,
             "pairs_on_lists": m_lists,
             "stage_us": {k: round(v, 1) for k, v in us.items()},
-            "stage_us_note": "HIP events on the launch stream, separate pass of 10 steps; bwd_raster_call = k_bwd_order + "
-                             "k_rasterize_bwd_v2 + k_unpack_grads (one library call)",
+            "stage_us_note": "HIP events on the launch stream, separate pass of 10 steps; bwd_raster_call = the packed rows' memset + "
+                             "k_bwd_order + k_rasterize_bwd_v2 + k_unpack_grads (the first stage of ms_render_bwd)",
             "roofline": {"bwd_raster": {"bound": "hbm", "algorithmic_bytes": b_rbwd, "formula": "40 M + 24 HW + 36 N",
                                         "achieved": round(b_rbwd / (us["bwd_raster_call"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": round(b_rbwd / (us["bwd_raster_call"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -18,6 +18,7 @@
  *   ms_project_gaussians_bwd          render.py:11); gsplat's backward semantics
  *   ms_render_fwd                     the whole of render_gaussians' device work
  *                                     (mojosplat/render.py:63-101) in one call
+ *   ms_render_bwd                     the backward of such a frame (no reference counterpart) in one call
  *   ms_render_fwd_batch               the same for C cameras: the camera dimension of the reference's
  *                                     kernels (kernels/projection.mojo:32-37) that its wrappers pin to 1
  *
@@ -223,6 +224,27 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
                              const int32_t *radii, const float *v_means2d,
                              const float *v_conics, const float *v_depths, float *v_means3d,
                              float *v_scales, float *v_quats, void *stream);
+
+/* Backward of a DIFFERENTIABLE ms_render_fwd frame (one that was asked for render_alphas and last_ids; declared
+ * below), from the scratch that frame left behind: `workspace` / `isect_buf` / `host_info` exactly as the forward
+ * call returned them (same N, image and tile size, untouched since), render_alphas / last_ids its per-pixel records.
+ * One call runs the backward rasteriser -- staging from the frame's ready-made records -- and the backward
+ * projection: what a training loop's backward() does between two Python statements (the reference has no backward:
+ * render.py:11, README.md:145).
+ *   in : the forward's inputs; v_render_colors f32[H,W,CDIM], v_render_alphas f32[H,W] or NULL.
+ *   out: v_means3d f32[N,3], v_scales f32[N,3] (w.r.t. the log-scales when scales_are_log), v_quats f32[N,4],
+ *        v_opacities f32[N], v_colors f32[N,CDIM] -- all OVERWRITTEN.
+ *   bwd_workspace: ms_render_bwd_workspace_bytes(N, CDIM) bytes of scratch.
+ *   mid_event: NULL, or a hipEvent_t recorded on `stream` between the two stages (in-situ timing). */
+size_t ms_render_bwd_workspace_bytes(int64_t N, int CDIM);
+int ms_render_bwd(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
+                  const float *opacities, const float *colors, int CDIM, const float *viewmat, float fx, float fy,
+                  float cx, float cy, int W, int H, float eps2d, int tile_size, const float *backgrounds,
+                  const void *workspace, size_t workspace_bytes, const void *isect_buf, size_t isect_bytes,
+                  const int64_t *host_info, const float *render_alphas, const int32_t *last_ids,
+                  const float *v_render_colors, const float *v_render_alphas, float *v_means3d, float *v_scales,
+                  float *v_quats, float *v_opacities, float *v_colors, void *bwd_workspace, size_t bwd_workspace_bytes,
+                  void *mid_event, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Spherical-harmonic colours (view dependent).  The reference leaves SH evaluation as a TODO

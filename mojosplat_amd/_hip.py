@@ -56,6 +56,11 @@ _SIGNATURES = {
                               c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                               c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ms_render_workspace_layout": (c_int, [c_int64, c_int, c_int, c_void_p]),
+    "ms_render_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "ms_render_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
+                              c_float, c_float, c_float, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t,
+                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "ms_isect_tiles_emit_speculative": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int64,
                                                 c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p,

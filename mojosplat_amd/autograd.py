@@ -10,6 +10,8 @@ expose the gfx950 backward kernels so the same three stages can sit inside a tra
 
 Binning is index work and carries no gradient.
 """
+import ctypes
+
 import torch
 
 from . import _hip
@@ -119,9 +121,11 @@ class _RenderFusedHip(torch.autograd.Function):
         if ctx.empty:
             ctx.save_for_backward(m3, sc, qu, op, col, bg)
             return img
-        means2d, conics, radii, ranges, ids = frame.intermediates(M, info["flags"], info["n_xl"])
-        ctx.scratch = (frame.ws, frame.isect)  # the views below alias these
-        ctx.save_for_backward(m3, sc, qu, op, col, bg, means2d, conics, radii, ranges, ids, frame.alphas, frame.last)
+        # the frame's scratch (projected arrays, records, sorted lists) and its size record stay alive for backward:
+        # ms_render_bwd reads them where the forward call left them
+        import numpy as np
+        ctx.scratch = (frame.ws, frame.isect, np.array(frame.st["host_np"], dtype=np.int64, copy=True))
+        ctx.save_for_backward(m3, sc, qu, op, col, bg, frame.alphas, frame.last)
         return img
 
     @staticmethod
@@ -131,35 +135,30 @@ class _RenderFusedHip(torch.autograd.Function):
             m3, sc, qu, op, col, bg = ctx.saved_tensors
             return (torch.zeros_like(m3), torch.zeros_like(sc), torch.zeros_like(qu), torch.zeros_like(op),
                     torch.zeros_like(col), None if bg is None else torch.zeros_like(bg), None, None)
-        m3, sc, qu, op, col, bg, means2d, conics, radii, ranges, ids, alphas, last = ctx.saved_tensors
+        m3, sc, qu, op, col, bg, alphas, last = ctx.saved_tensors
+        ws, isect, host = ctx.scratch
         L = _hip.lib()
         N, C = col.shape
         dev = m3.device
         v_img = _hip.f32c(v_img)
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # overwritten by the library
-        v_means2d, v_conics, v_colors, v_opac = z(N, 2), z(N, 3), z(N, C), z(N)
-        ws_bytes = L.ms_rasterize_bwd_workspace_bytes(N, C)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        v_means3d = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        v_scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        v_quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        v_means3d, v_scales, v_quats, v_opac, v_colors = z(N, 3), z(N, 3), z(N, 4), z(N), z(N, C)
+        bws_bytes = L.ms_render_bwd_workspace_bytes(N, C)
+        bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
         vm = cam._viewmat_f32().to(dev)
         bev = _BWD_HOOK() if _BWD_HOOK is not None else None
         with _hip.on_device(dev):
-            st = _hip.stream(dev)
             if bev:
                 bev[0].record()
-            _hip.check(L.ms_rasterize_to_pixels_3dgs_bwd(
-                N, ids.numel(), _hip.ptr(means2d), _hip.ptr(conics), _hip.ptr(col), C, _hip.ptr(op), _hip.ptr(bg),
-                cam.W, cam.H, ts, _hip.ptr(ranges), _hip.ptr(ids), _hip.ptr(alphas), _hip.ptr(last),
-                _hip.ptr(v_img), None, _hip.ptr(v_means2d), _hip.ptr(v_conics), _hip.ptr(v_colors),
-                _hip.ptr(v_opac), _hip.ptr(ws), ws_bytes, 1, st), "ms_rasterize_to_pixels_3dgs_bwd")
-            if bev:
-                bev[1].record()
-            _hip.check(L.ms_project_gaussians_bwd(
-                N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(vm), cam.fx, cam.fy, cam.cx, cam.cy,
-                cam.W, cam.H, EPS2D, _hip.ptr(radii), _hip.ptr(v_means2d), _hip.ptr(v_conics), None,
-                _hip.ptr(v_means3d), _hip.ptr(v_scales), _hip.ptr(v_quats), st), "ms_project_gaussians_bwd")
+            # one library call: the backward rasteriser (staging from the frame's ready-made records) and the backward
+            # projection, on the scratch the forward call left behind
+            _hip.check(L.ms_render_bwd(
+                N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(op), _hip.ptr(col), C, _hip.ptr(vm), cam.fx, cam.fy,
+                cam.cx, cam.cy, cam.W, cam.H, EPS2D, ts, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
+                0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(alphas), _hip.ptr(last), _hip.ptr(v_img),
+                None, _hip.ptr(v_means3d), _hip.ptr(v_scales), _hip.ptr(v_quats), _hip.ptr(v_opac), _hip.ptr(v_colors),
+                _hip.ptr(bws), bws_bytes, ctypes.c_void_p(bev[1].cuda_event) if bev else None, _hip.stream(dev)),
+                "ms_render_bwd")
             if bev:
                 bev[2].record()
         v_bg = None
@@ -209,4 +208,13 @@ def render_gaussians_trainable(means3d, scales, quats, opacities, features, came
             # same zeros image as the inference path (reference render.py:73-76), grad-connected
             return (means3d.sum() + features.sum()) * 0 + torch.zeros(camera.H, camera.W, C, device=dev)
         return rasterize_gaussians_autograd(means2d, conics, features, opacities, bg, ranges, ids, camera, tile_size)
-    return _RenderFusedHip.apply(means3d, scales, quats, opacities.reshape(-1), features, bg, camera, tile_size)
+    # The differentiable frame's binning grid is free, like the inference frame's (the image and the gradients are
+    # sums over the same (pixel, Gaussian) pairs whatever the bins): MOJOSPLAT_TRAIN_BIN_PX = 16 | 32 | 64 picks it for
+    # 16-px tiles (measurements; default: the tile size as given).
+    bin_px = tile_size
+    if tile_size == 16:
+        import os
+        v = os.environ.get("MOJOSPLAT_TRAIN_BIN_PX")
+        if v and int(v) in (16, 32, 64):
+            bin_px = int(v)
+    return _RenderFusedHip.apply(means3d, scales, quats, opacities.reshape(-1), features, bg, camera, bin_px)

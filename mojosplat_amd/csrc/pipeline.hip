@@ -386,6 +386,80 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
 }
 
 
+// ---- backward of a differentiable frame ---------------------------------------------------------------------------
+// ms_render_fwd with render_alphas / last_ids leaves everything the backward needs in the frame's own scratch: the
+// projected arrays and the ready-made records in `workspace`, the fully sorted lists in `isect_buf`.  One C call runs
+// the backward rasteriser (staging from the records) and the backward projection on it: no Python between the
+// kernels, and the layout of the scratch stays the library's own business.
+extern "C" size_t ms_render_bwd_workspace_bytes(int64_t N, int CDIM) {
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    return ms::align_up(ms_rasterize_bwd_workspace_bytes(N, CDIM), 256) + ms::align_up(n * 8, 256) + ms::align_up(n * 12, 256);
+}
+
+extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
+                             const float *opacities, const float *colors, int CDIM, const float *viewmat, float fx, float fy,
+                             float cx, float cy, int W, int H, float eps2d, int tile_size, const float *backgrounds,
+                             const void *workspace, size_t workspace_bytes, const void *isect_buf, size_t isect_bytes,
+                             const int64_t *host_info, const float *render_alphas, const int32_t *last_ids,
+                             const float *v_render_colors, const float *v_render_alphas, float *v_means3d, float *v_scales,
+                             float *v_quats, float *v_opacities, float *v_colors, void *bwd_workspace,
+                             size_t bwd_workspace_bytes, void *mid_event, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "render_bwd: bad sizes");
+    MS_REQUIRE(host_info && v_means3d && v_scales && v_quats && v_opacities && v_colors, MS_ERR_INVALID_ARG,
+               "render_bwd: null pointer");
+    if (N == 0) return MS_OK;
+    const int64_t M = host_info[0], n_xl = host_info[4];
+    if (host_info[6] == 0 || M == 0) {
+        // nothing on the grid / no intersections: the frame was the zeros image (or the background), and constant in
+        // every input
+        MS_HIP(hipMemsetAsync(v_means3d, 0, (size_t)N * 12, stream));
+        MS_HIP(hipMemsetAsync(v_scales, 0, (size_t)N * 12, stream));
+        MS_HIP(hipMemsetAsync(v_quats, 0, (size_t)N * 16, stream));
+        MS_HIP(hipMemsetAsync(v_opacities, 0, (size_t)N * 4, stream));
+        MS_HIP(hipMemsetAsync(v_colors, 0, (size_t)N * CDIM * 4, stream));
+        return MS_OK;
+    }
+    MS_REQUIRE(M > 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_bwd: bad intersection count %lld", (long long)M);
+    MS_REQUIRE(means3d && scales && quats && opacities && colors && viewmat && workspace && isect_buf && render_alphas &&
+                   last_ids && v_render_colors && bwd_workspace,
+               MS_ERR_INVALID_ARG, "render_bwd: null pointer");
+    MS_REQUIRE(!(host_info[7] & 8), MS_ERR_INVALID_ARG, "render_bwd: the frame's lists are block lists of a split frame");
+    const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+    const WsLayout L = ws_layout(N, tw, th);
+    MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_bwd: workspace %zu < %zu", workspace_bytes, L.total);
+    MS_REQUIRE(bwd_workspace_bytes >= ms_render_bwd_workspace_bytes(N, CDIM), MS_ERR_WORKSPACE,
+               "render_bwd: backward workspace %zu < %zu", bwd_workspace_bytes, ms_render_bwd_workspace_bytes(N, CDIM));
+    const char *ws = (const char *)workspace;
+    const float *means2d = (const float *)(ws + L.off_means2d), *conics = (const float *)(ws + L.off_conics);
+    const int32_t *radii = (const int32_t *)(ws + L.off_radii), *ranges = (const int32_t *)(ws + L.off_ranges);
+    // where the frame left its sorted ids (the layout rules of ms_render_fwd: exact, or sized by the buffer's capacity)
+    size_t ids_off;
+    if (host_info[7] & 4) {
+        ids_off = ms::align_up((size_t)M * 8, 256) * (n_xl > 0 ? 2 : 1);
+    } else {
+        MS_REQUIRE(isect_bytes > 512, MS_ERR_WORKSPACE, "render_bwd: intersection buffer too small");
+        int64_t cap = (int64_t)((isect_bytes - 512) / 12);
+        cap = cap > 0x7fffffffll ? 0x7fffffffll : cap;
+        ids_off = ms::align_up((size_t)cap * 8, 256);
+    }
+    MS_REQUIRE(ids_off + (size_t)M * 4 <= isect_bytes, MS_ERR_WORKSPACE, "render_bwd: intersection buffer %zu does not hold %lld ids",
+               isect_bytes, (long long)M);
+    const int32_t *ids = (const int32_t *)((const char *)isect_buf + ids_off);
+    const void *records = CDIM == 3 ? (const void *)(ws + L.off_records) : nullptr;
+    char *bw = (char *)bwd_workspace;
+    const size_t rb = ms::align_up(ms_rasterize_bwd_workspace_bytes(N, CDIM), 256);
+    float *v_means2d = (float *)(bw + rb), *v_conics = (float *)(bw + rb + ms::align_up((size_t)N * 8, 256));
+    if (int rc = ms::rasterize_bwd(N, M, means2d, conics, colors, CDIM, opacities, backgrounds, W, H, tile_size, ranges, ids,
+                                   render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors,
+                                   v_opacities, rb ? bw : nullptr, rb, /*overwrite=*/1, records, stream_))
+        return rc;
+    if (mid_event) MS_HIP(hipEventRecord((hipEvent_t)mid_event, stream));   // (in-situ timing: between the two stages)
+    return ms_project_gaussians_bwd(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, radii,
+                                    v_means2d, v_conics, nullptr, v_means3d, v_scales, v_quats, stream_);
+}
+
+
 // Camera batch: n_lanes views in flight (begin view v + 1 before finishing view v).  See the header.
 extern "C" int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *scales, int scales_are_log,
                                    const float *quats, const float *opacities, const void *colors, int color_dtype,

@@ -201,6 +201,7 @@ struct RasterBwd2Args {
     float *packed;  // f32[N][kRow], zeroed by the caller of the kernel
     const int32_t *order;   // blocks, heaviest list first (k_bwd_order), or null: image order
     int nblocks, n_gauss;
+    const float4 *records;  // the forward frame's ready-made ms::RasterRecords (3 channels), or null: the four arrays
 };
 
 // Launch order of the blocks: heaviest list first (counting sort of the tiles over 128 length buckets, 4 per
@@ -281,8 +282,14 @@ __device__ __forceinline__ float wave_allreduce8(const float (&v)[8], int lane) 
 
 // NQ = quads per wave: 4 = one wave per 16x16 block; 2 = two waves per block (upper / lower strip; each stages the
 // list but blends only its quads): the longest wave's work halves and twice as many waves fill the slots.
-template <int CP, int NQ>
+// REC: stage from the forward frame's ready-made 48-byte records (ms_render_bwd: three 16-byte gathers and no
+// arithmetic per entry instead of seven 4-12-byte gathers, the conic's scaling and the bound's logarithm -- the same
+// treatment the forward rasteriser got in round 2).  The records hold the conic pre-scaled exactly as s_a / s_b want
+// it, log2(opacity) (the opacity is taken back out with one exp2: an ulp beside the caller's value, far inside the
+// gradients' tolerance), and the three numbers of the ellipse-vs-quad test.
+template <int CP, int NQ, bool REC>
 __global__ __launch_bounds__(64, MS_BWD_WAVES) void k_rasterize_bwd_v2(RasterBwd2Args B2) {
+    static_assert(!REC || CP == 3, "ready-made records carry three channels");
     const RasterBwdArgs &A = B2.a;
     constexpr int NG = 6 + CP;
     constexpr int kParts = 4 / NQ;
@@ -346,6 +353,43 @@ __global__ __launch_bounds__(64, MS_BWD_WAVES) void k_rasterize_bwd_v2(RasterBwd
         const int idx = b0 + lane;
         int mask = 0, g = 0;
         float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f, col[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 st_a = make_float4(0.f, 0.f, 0.f, 0.f), st_b = st_a;   // what goes to s_a / s_b
+        if constexpr (REC) {
+            if (idx <= hi) {
+                constexpr float kInf = __builtin_huge_valf();
+                g = min(max(A.flatten_ids[idx], 0), B2.n_gauss - 1);
+                const float4 *rec = B2.records + 3 * (size_t)g;
+                const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                const float smax = rc.y, nb_c = rc.z, nb_a = rc.w;
+                st_a = ra;
+                st_b = make_float4(rb.x, __builtin_amdgcn_exp2f(rb.y), rb.z, rb.w);
+                col[2] = rc.x;
+                if (smax == kInf) {
+                    mask = 0xf;   // no bound (not positive definite, or the 0.999 clamp can bind): every quad
+                } else if (smax > -kInf) {
+                    // exact ellipse-vs-quad test in log2 units on the record, as in the forward kernel (rasterize.hip)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int qq = qbase + q;
+                        const float xl = fbx + (float)((qq & 1) * 8) - ra.x, xh = xl + 7.0f;
+                        const float yl = fby + (float)((qq >> 1) * 8) - ra.y, yh = yl + 7.0f;
+                        const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
+                        float best = (in_x && in_y) ? 0.f : 3.0e38f;
+                        if (!in_x) {
+                            const float dx = xl > 0.f ? xl : xh;
+                            const float dy = fminf(fmaxf(nb_c * dx, yl), yh);
+                            best = -(ra.z * dx * dx + rb.x * dy * dy + ra.w * dx * dy);
+                        }
+                        if (!in_y) {
+                            const float dy = yl > 0.f ? yl : yh;
+                            const float dx = fminf(fmaxf(nb_a * dy, xl), xh);
+                            best = fminf(best, -(ra.z * dx * dx + rb.x * dy * dy + ra.w * dx * dy));
+                        }
+                        mask |= (best <= smax) ? (1 << q) : 0;
+                    }
+                }
+            }
+        } else
         if (idx <= hi) {
             g = min(max(A.flatten_ids[idx], 0), B2.n_gauss - 1);
             const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
@@ -396,8 +440,13 @@ __global__ __launch_bounds__(64, MS_BWD_WAVES) void k_rasterize_bwd_v2(RasterBwd
         }
         wave_lds_sync_bwd();  // the previous batch's flush has read s_grad / s_c
         if (mask) {
-            s_a[lane] = make_float4(mx, my, -0.5f * kLog2e * ca, -kLog2e * cb);
-            s_b[lane] = make_float4(-0.5f * kLog2e * cc, op, col[0], col[1]);
+            if constexpr (REC) {
+                s_a[lane] = st_a;
+                s_b[lane] = st_b;
+            } else {
+                s_a[lane] = make_float4(mx, my, -0.5f * kLog2e * ca, -kLog2e * cb);
+                s_b[lane] = make_float4(-0.5f * kLog2e * cc, op, col[0], col[1]);
+            }
             s_c[lane] = make_float4(col[2], col[3], __int_as_float(g), 0.f);
         }
         wave_lds_sync_bwd();
@@ -516,6 +565,18 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *workspace,
     size_t workspace_bytes, int overwrite, void *stream) {
+    return ms::rasterize_bwd(N, M, means2d, conics, colors, CDIM, opacities, backgrounds, W, H, tile_size, tile_ranges,
+                             flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d, v_conics,
+                             v_colors, v_opacities, workspace, workspace_bytes, overwrite, nullptr, stream);
+}
+
+int ms::rasterize_bwd(
+    int64_t N, int64_t M, const float *means2d, const float *conics, const float *colors, int CDIM,
+    const float *opacities, const float *backgrounds, int W, int H, int tile_size,
+    const int32_t *tile_ranges, const int32_t *flatten_ids, const float *render_alphas,
+    const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+    float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *workspace,
+    size_t workspace_bytes, int overwrite, const void *records, void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_bwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_bwd: CDIM %d not in 1..32", CDIM);
@@ -560,6 +621,7 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
         B2.packed = (float *)workspace;
         B2.nblocks = (int)blocks;
         B2.n_gauss = (int)N;
+        B2.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
         MS_HIP(hipMemsetAsync(workspace, 0, packed_bytes, st));
         // heaviest blocks first when the workspace has room for the order (ms_rasterize_bwd_workspace_bytes
         // reserves it); two waves per block while the launch is a few rounds at most
@@ -578,14 +640,15 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
         static const int forced = [] { const char *e = getenv("MOJOSPLAT_BWD_PARTS"); const int n = e ? atoi(e) : 0; return (n == 1 || n == 2 || n == 4) ? n : 0; }();
         const int parts = forced ? forced : 1;
         const dim3 grid2((unsigned)(parts > 1 ? ((blocks + 7) / 8) * 8 * parts : blocks));
-#define MS_LAUNCH_BWD(CPV)                                                                              \
-    do {                                                                                                 \
-        if (parts == 4) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 1>), grid2, dim3(64), 0, st, B2);      \
-        else if (parts == 2) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 2>), grid2, dim3(64), 0, st, B2); \
-        else hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 4>), grid2, dim3(64), 0, st, B2);                 \
+#define MS_LAUNCH_BWD(CPV, RECV)                                                                              \
+    do {                                                                                                       \
+        if (parts == 4) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 1, RECV>), grid2, dim3(64), 0, st, B2);      \
+        else if (parts == 2) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 2, RECV>), grid2, dim3(64), 0, st, B2); \
+        else hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 4, RECV>), grid2, dim3(64), 0, st, B2);                 \
     } while (0)
-        if (CDIM <= 3) MS_LAUNCH_BWD(3);
-        else MS_LAUNCH_BWD(4);
+        if (CDIM == 3 && B2.records) MS_LAUNCH_BWD(3, true);
+        else if (CDIM <= 3) MS_LAUNCH_BWD(3, false);
+        else MS_LAUNCH_BWD(4, false);
 #undef MS_LAUNCH_BWD
         MS_LAUNCH_CHECK();
         if (overwrite)
