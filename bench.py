@@ -327,6 +327,10 @@ def main():
         torch.cuda.synchronize()
         render_mod._STAGE_HOOK = None
 
+    band_bounds_end = None
+    if world > 1:
+        from mojosplat_amd.distributed import band_bounds
+        band_bounds_end = band_bounds(g[0], cam, 16, world)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     vflag = torch.tensor([1 if verified else 0], device=dev)
     if world > 1:
@@ -497,7 +501,13 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"{world} tile-row bands + RCCL all-gather" + (", gather of frame k overlapped with render of frame k+1" if mode["async"] else " (blocking)")},
             "verified": verified, "max_abs_vs_stagewise": max_abs, "verification": verification,
             "rccl": None if world == 1 else {"world": dist.get_world_size(), "backend": dist.get_backend(),
-                                             "devices": "all ranks on cuda:0 (rehearsal)" if rehearse else "one per rank"},
+                                             "devices": "all ranks on cuda:0 (rehearsal)" if rehearse else "one per rank",
+                                             "algo": {"framebuffer": "grouped isend / irecv into the image's rows (MOJOSPLAT_GATHER=direct)"
+                                                      if os.environ.get("MOJOSPLAT_GATHER") == "direct"
+                                                      else "in-place all_gather_into_tensor (padded slots + one compaction copy once bands are ragged)",
+                                                      "status": "all_gather of 16 bytes per rank per frame (on-grid count, balance weight)",
+                                                      "band_balance": os.environ.get("MOJOSPLAT_BALANCE", "1") != "0",
+                                                      "bands_at_end": band_bounds_end}},
             "roofline": roofline, "cpu_baseline": cpu,
             "extras": (dict(extras or {}, **legs) or None),
         }

@@ -102,7 +102,7 @@ class _Frame:
     `run(phase)` makes the library call; `finish()` completes a frame that was only begun."""
 
     def __init__(self, means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                 stage_events, row_range, out, lane, stream=None, own=False, rows16=False):
+                 stage_events, row_range, out, lane, stream=None, own=False, rows16=False, out_y0=None):
         """own=True: the frame gets FRESH scratch (workspace, intersection buffer) and the per-pixel
         records of the backward pass instead of the lane's cached buffers -- a differentiable frame
         keeps them until its backward has run.  Only the size hint, the pinned record and the event
@@ -148,7 +148,17 @@ class _Frame:
         # current depth level, or full sorts once the lane has given up on them
         self.level = int(st.get("front_level", 0))
         self.mode = (FULL_SORT if st.get("full_sort") else FRONT_LEVEL * self.level) | self.rows16
-        if out is not None:
+        self.img_ptr = None
+        if out is not None and out_y0 is not None:
+            # `out` is a SLAB holding image rows [out_y0, out_y0 + out.shape[0]) (a rank's slot of a padded gather
+            # buffer): the library addresses the full image, so it is handed the address image row 0 would have --
+            # rows outside the band are never touched
+            assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev and tuple(out.shape[1:]) == (W, C)
+            px = tile_size if not self.rows16 else 16
+            assert row_range is not None and out.shape[0] >= min(r1 * px, H) - min(r0 * px, H) and out_y0 == min(r0 * px, H)
+            self.img = out
+            self.img_ptr = ctypes.c_void_p(out.data_ptr() - out_y0 * W * C * 4)
+        elif out is not None:
             assert out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
             assert out.shape[0] >= H and tuple(out.shape[1:]) == (W, C)
             self.img = out
@@ -162,7 +172,7 @@ class _Frame:
         self.head = (N, _hip.ptr(means3d), _hip.ptr(scales), 1, _hip.ptr(quats), _hip.ptr(op), _hip.ptr(colors),
                      cdt, C, _hip.ptr(vm), camera.fx, camera.fy, camera.cx, camera.cy, W, H, EPS2D, camera.near,
                      camera.far, tile_size, r0, r1, _hip.ptr(bg), _hip.ptr(ws), ws.numel())
-        self.tail = (_hip.ptr(self.img), _hip.ptr(self.alphas), _hip.ptr(self.last), evs,
+        self.tail = (self.img_ptr if self.img_ptr is not None else _hip.ptr(self.img), _hip.ptr(self.alphas), _hip.ptr(self.last), evs,
                      ctypes.c_void_p(st["ev"].cuda_event) if st.get("speculate", True) else None,
                      _hip.stream(dev) if stream is None else ctypes.c_void_p(stream))
         self.host_ptr = ctypes.c_void_p(st["host"].data_ptr())
@@ -268,7 +278,7 @@ class _Frame:
 
 
 def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                   stage_events=None, row_range=None, out=None, lane=0, info=None, rows16=False):
+                   stage_events=None, row_range=None, out=None, lane=0, info=None, rows16=False, out_y0=None):
     """-> (image (H,W,C) f32, M).  `background` may be None.  stage_events: None or a list of 4
     torch.cuda.Event that have been recorded once (so their handles exist).
     row_range=(r0, r1) renders only tile rows [r0, r1) into `out` (a caller-owned framebuffer of
@@ -278,7 +288,7 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
     FULL tile grid (band-independent)."""
     with _frame_lock:
         return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                      stage_events, row_range, out, lane, rows16=rows16).finish(WHOLE, info)
+                      stage_events, row_range, out, lane, rows16=rows16, out_y0=out_y0).finish(WHOLE, info)
 
 
 def last_frame_list_entries(dev, N, tile_w, tile_h, lane=0):

@@ -20,6 +20,16 @@ so this is new design, MI355X-first:
     `async_op=True` hands back a PendingFrame right after the all-gather is enqueued on RCCL's
     stream; the caller's stream only waits for it in `.wait()`.
 
+  * LOAD BALANCE (round 3).  Equal bands are not equal work: a centre-heavy scene gives the middle ranks twice the
+    pairs of the edge ranks (config 5 cut 8 ways: 157-323 us per band).  Every frame's 16-byte status record (the
+    on-grid flag and the band's pair count, all-gathered beside the framebuffer in place of round 2's 4-byte
+    all-reduce) lets all ranks recompute the SAME band boundaries from the same numbers every few frames: cost of a
+    band = half its share of the pairs + half its share of the rows, boundaries moved 70 % of the way to the equal-
+    cost cut, until the spread is under 8 %.  Bands are then ragged, and the exchange is either the padded in-place
+    all-gather plus one compaction copy, or (MOJOSPLAT_GATHER=direct) grouped point-to-point sends / receives
+    straight into the image's rows -- xGMI is point to point, every GPU has a link to every other, and ragged
+    bands need no padding there.  MOJOSPLAT_BALANCE=0 keeps equal bands.
+
 One process per GPU; backend "nccl" is RCCL on ROCm.  `stages` makes the orchestration testable
 on CPU with gloo (tests inject CPU stage functions); without it the HIP library renders the band.
 """
@@ -37,6 +47,80 @@ def band_plan(tile_rows: int, world: int) -> Tuple[int, list]:
     rows = -(-tile_rows // world)
     bands = [(min(r * rows, tile_rows), min((r + 1) * rows, tile_rows)) for r in range(world)]
     return rows, bands
+
+
+def rebalance(bounds, pairs, damping: float = 0.7, min_rows: int = 1):
+    """New band boundaries (tile rows, len world + 1) from the weights the ranks reported for the current ones (the
+    Gaussians that reach a pre-culled band, or a band's pairs).
+    Cost of a band = 0.5 * its share of the weights + 0.5 * its share of the rows (the binning side of a band frame
+    follows the Gaussians / pairs, the rasteriser of a dense scene the pixels); weights are taken as uniform inside a band.  The
+    boundaries move `damping` of the way to the equal-cost cut.  Pure integer / float arithmetic on numbers every
+    rank holds identically -> every rank gets the same answer.  -> (bounds, spread = max cost / mean cost BEFORE)."""
+    world = len(bounds) - 1
+    th = bounds[-1]
+    total = float(sum(pairs))
+    rows = [bounds[r + 1] - bounds[r] for r in range(world)]
+    if total <= 0 or th <= 0:
+        return list(bounds), 1.0
+    cost = [0.5 * pairs[r] / total + 0.5 * rows[r] / th for r in range(world)]
+    spread = max(cost) * world          # (the costs sum to 1: mean = 1 / world)
+    # cumulative cost at every row boundary, piecewise linear inside a band
+    dens = [(cost[r] / rows[r]) if rows[r] > 0 else 0.0 for r in range(world)]
+    new = [0]
+    r, acc = 0, 0.0                      # acc = cumulative cost at the start of band r
+    for k in range(1, world):
+        want = k / world
+        while r < world - 1 and acc + cost[r] < want:
+            acc += cost[r]
+            r += 1
+        inside = (want - acc) / dens[r] if dens[r] > 0 else 0.0
+        target = bounds[r] + inside
+        b = bounds[k] + damping * (target - bounds[k])
+        new.append(int(round(b)))
+    new.append(th)
+    # monotone, every band at least min_rows (as far as the image allows)
+    for k in range(1, world):
+        new[k] = max(new[k], new[k - 1] + min_rows)
+    for k in range(world - 1, 0, -1):
+        new[k] = min(new[k], new[k + 1] - min_rows)
+    for k in range(1, world):
+        new[k] = min(max(new[k], 0), th)
+        new[k] = max(new[k], new[k - 1])
+    return new, spread
+
+
+def _gather_mode():
+    import os
+    v = os.environ.get("MOJOSPLAT_GATHER", "allgather")
+    if v not in ("allgather", "ring", "direct"):
+        raise ValueError("MOJOSPLAT_GATHER must be 'allgather' or 'direct'")
+    return "direct" if v == "direct" else "allgather"
+
+
+def _balance_enabled():
+    import os
+    return os.environ.get("MOJOSPLAT_BALANCE", "1") != "0"
+
+
+_plans = {}   # plan key -> dict(bounds, frame): the bands of the next frame of that scene, identical on every rank
+_CHECK_EVERY, _CHECK_SETTLED, _SPREAD_OK = 8, 64, 1.08
+
+
+def _plan_key(means3d, camera, tile_size, world):
+    import math
+    n = means3d.shape[0]
+    return (means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H, tile_size, world)
+
+
+def band_bounds(means3d, camera, tile_size, world):
+    """The band boundaries (tile rows) the next sharded frame of this scene uses -- equal bands until the ranks'
+    pair counts say otherwise."""
+    th = -(-camera.H // tile_size)
+    p = _plans.get(_plan_key(means3d, camera, tile_size, world))
+    if p is not None:
+        return list(p["bounds"])
+    rows, bands = band_plan(th, world)
+    return [b[0] for b in bands] + [th]
 
 
 @dataclass
@@ -118,8 +202,9 @@ def _band_learn(key, mode, m, info, camera, band):
     R._settle(key, mode, nxt)
 
 
-def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size, band, out):
-    """Render tile rows `band` into `out`; -> Gaussians touching the full grid (0 = empty frame)."""
+def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size, band, out, out_y0=None):
+    """Render tile rows `band` into `out` (the full framebuffer, or -- out_y0 given -- a slab whose first row is image
+    row out_y0); -> (Gaussians touching the full grid (0 = empty frame), pairs in the band)."""
     r0, r1 = band
     H, W = camera.H, camera.W
     th, tw = -(-H // tile_size), -(-W // tile_size)
@@ -131,14 +216,14 @@ def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg
         # (rows16: the band stays in 16-px rows while the BINS follow the rule -- only when the caller's tiles are the
         # 16-px ones; an explicit tile_size of 32 / 48 / 64 keeps band_plan's units, tile rows of that size)
         _, m = render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, mode,
-                              row_range=b, out=out, info=info, rows16=(tile_size == 16))
+                              row_range=b, out=out, info=info, rows16=(tile_size == 16), out_y0=out_y0)
         _band_learn(key, mode, m, info, camera, b)
-        return info["on_grid"]
+        return info["on_grid"], m
     means2d, conics, depths, radii = stages.project(means3d, scales, quats, opacities, camera)
     ids, ranges = stages.bin(means2d, radii, depths, tile_size, tw, th, band)
     if r1 > r0:
         stages.raster(means2d, conics, features, opacities, bg, ranges, ids, camera, tile_size, band, out)
-    return _on_grid_count(means2d, radii, tile_size, tw, th)
+    return _on_grid_count(means2d, radii, tile_size, tw, th), int(ids.numel())
 
 
 class PendingFrame:
@@ -190,10 +275,12 @@ def _lane_events(dev, lane):
 def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera: Camera,
                              background_color: Optional[torch.Tensor] = None, tile_size: int = 16,
                              group=None, stages: Optional[Stages] = None, async_op: bool = False,
-                             rehearse: Optional[Tuple[int, int]] = None):
+                             rehearse: Optional[Tuple[int, int]] = None, bounds: Optional[list] = None):
     """Every rank returns the full (H, W, C) image.  Inputs must be identical on all ranks.
     rehearse=(rank, world) acts as that rank WITHOUT a process group and without the exchange
     (only its own slab of the image is rendered): single-GPU timing of one rank's share.
+    bounds: the world + 1 band boundaries in tile rows (rehearsals, tests); default: the scene's current plan --
+    equal bands, then what `rebalance` makes of the ranks' pair counts.
 
     async_op=True returns a PendingFrame (call .wait() for the image) and is meant to be used one
     frame ahead: `nxt = render(..., async_op=True); img = cur.wait(); cur = nxt`.  The band is
@@ -208,7 +295,6 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     C = features.shape[-1]
     H, W = camera.H, camera.W
     th = -(-H // tile_size)
-    rows, bands = band_plan(th, world)
     # the background takes the colours' dtype first, as in render_gaussians (reference render.py:55): with
     # fp16 colours 0.1 is 0.09998 on every path
     bg = torch.zeros(C, device=dev, dtype=torch.float32) if background_color is None else \
@@ -216,63 +302,112 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     if bg.shape[0] != C:
         raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color channels ({C})")
 
-    slab = rows * tile_size
-    H_pad = max(world * slab, H)
+    # ---- this frame's bands: equal until the ranks' pair counts say otherwise (rebalance, module docstring)
+    live = world > 1 and rehearse is None                 # a real process group: status records are exchanged
+    pkey = _plan_key(means3d, camera, tile_size, world)
+    if bounds is None:
+        bounds = band_bounds(means3d, camera, tile_size, world)
+    assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == th and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    bands = [(bounds[r], bounds[r + 1]) for r in range(world)]
+    rows_max = max(b - a for a, b in bands)
+    equal = all(a == min(r * rows_max, th) and b == min((r + 1) * rows_max, th) for r, (a, b) in enumerate(bands))
+    mode = _gather_mode()
+    slab = rows_max * tile_size
+    y0s = [min(a * tile_size, H) for a, _ in bands]
+    y1s = [min(b * tile_size, H) for _, b in bands]
+    # Framebuffer: equal bands render straight into their slot of the padded image (in-place all-gather, as round
+    # 2); "direct" renders into the image and exchanges rows point to point; ragged bands under the all-gather go
+    # through a (world, slab) buffer, each rank's band at the start of its slot, and ONE compaction copy.
+    padded = live and mode == "allgather" and not equal
+    H_pad = max(world * slab, H) if (equal or not live) else H
 
     # A HIP band frame reports how many of ITS Gaussians touch the full grid: the library pre-culls what cannot
     # reach the band (csrc/binning.hip, k_band_precull), so the frame-level "nothing on the grid -> zeros image"
-    # rule (render.py:73-76) needs the OR over the ranks: one 4-byte all-reduce beside the framebuffer gather.
-    # (A Gaussian on the grid reaches some band and is counted by that band's rank.)  Every rank always takes
-    # part in both collectives.  Injected CPU stages count over all Gaussians and need no exchange.
-    need_flag = stages is None and world > 1 and rehearse is None
+    # rule (render.py:73-76) needs the OR over the ranks.  Every frame of a live group therefore all-gathers a
+    # 16-byte status record per rank -- (Gaussians on the grid, pairs in the band) -- beside the framebuffer; every
+    # rank always takes part in both collectives.  (Injected CPU stages count the on-grid Gaussians over ALL of
+    # them, but exchange the record all the same: the pair counts steer the band boundaries.)
+    def exchange(buf, on_grid, m_band):
+        """-> (image or a callable that yields it, [works]): the exchange step, or the frame-level zeros rule."""
+        if not live:
+            if rehearse is not None and stages is None and world > 1:
+                # a rehearsed rank of the HIP path: its on-grid count is the count AFTER the band pre-cull, so an
+                # empty band of a non-empty frame also reports 0 -- the frame-level zeros rule cannot be decided
+                # locally; the band (background where nothing reaches it) is what this rank contributes
+                return buf[:H], []
+            if on_grid == 0:
+                return torch.zeros(H, W, C, device=dev, dtype=torch.float32), []   # zeros, not background (render.py:73-76)
+            return buf[:H], []
+        # (the weight the plan balances on: a pre-culled HIP band reports the Gaussians that reach IT -- comparable
+        # across ranks whatever bin size each one runs on, which pair counts are not; else the band's pairs)
+        culled = stages is None and C == 3 and means3d.shape[0] >= 32768 and 10 * (bands[rank][1] - bands[rank][0]) < 6 * th
+        status = torch.tensor([on_grid, on_grid if culled else m_band], dtype=torch.int64, device=dev)
+        status_all = torch.empty((world, 2), dtype=torch.int64, device=dev)
+        works = [dist.all_gather_into_tensor(status_all.view(-1), status, group=group, async_op=True)]
+        if mode == "direct":
+            ops = []
+            for peer in range(world):
+                if peer == rank:
+                    continue
+                if y1s[rank] > y0s[rank]:
+                    ops.append(dist.P2POp(dist.isend, buf[y0s[rank]:y1s[rank]], peer, group))
+                if y1s[peer] > y0s[peer]:
+                    ops.append(dist.P2POp(dist.irecv, buf[y0s[peer]:y1s[peer]], peer, group))
+            if ops:
+                works += dist.batch_isend_irecv(ops)
+        elif padded:
+            works.append(dist.all_gather_into_tensor(buf.view(-1), buf[rank].reshape(-1), group=group, async_op=True))
+        else:
+            works.append(dist.all_gather_into_tensor(buf[:world * slab], buf[rank * slab:(rank + 1) * slab],
+                                                     group=group, async_op=True))
+        plan = _plans.setdefault(pkey, dict(bounds=list(bounds), frame=0))
+        plan["frame"] += 1
+        check = _balance_enabled() and plan["bounds"] == list(bounds) and \
+            plan["frame"] % (_CHECK_SETTLED if plan.get("settled") else _CHECK_EVERY) == 0
 
-    def gather(full, on_grid):
-        """-> (image or a callable that yields it, work): the exchange step, or the frame-level zeros rule."""
-        if need_flag:
-            flag = torch.tensor([1 if on_grid > 0 else 0], dtype=torch.int32, device=dev)
-            fwork = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group, async_op=True)
-            work = dist.all_gather_into_tensor(full[:world * slab], full[rank * slab:(rank + 1) * slab],
-                                               group=group, async_op=True)
+        def image():
+            # the OR over the ranks is at least this rank's own bit: only a rank whose band holds nothing has to READ
+            # the records (a device-to-host read, i.e. a host stall), and every rank on the frames that re-plan
+            frame = torch.cat([buf[r, :y1s[r] - y0s[r]] for r in range(world)]) if padded else buf[:H]
+            if on_grid > 0 and not check:
+                return frame
+            rec = status_all.cpu()
+            if check:
+                # identical numbers on every rank -> identical new bounds on every rank, from the next frame on
+                nb, spread = rebalance(list(bounds), [int(v) for v in rec[:, 1]])
+                plan["settled"] = spread <= _SPREAD_OK
+                if not plan["settled"]:
+                    plan["bounds"] = nb
+            if int(rec[:, 0].max()) == 0:
+                return torch.zeros(H, W, C, device=dev, dtype=torch.float32)
+            return frame
+        return image, works
 
-            def image():
-                # every rank completes the flag's collective (RCCL: the current stream waits for it, no host stall;
-                # an error of the collective surfaces here on every rank) ...
-                fwork.wait()
-                # ... but the OR over the ranks is at least this rank's own bit: only a rank whose band holds nothing
-                # has to READ the reduced flag (a device-to-host read, i.e. a host stall per frame otherwise)
-                if on_grid > 0:
-                    return full[:H]
-                return full[:H] if int(flag.item()) > 0 else torch.zeros(H, W, C, device=dev, dtype=torch.float32)
-            return image, work
-        if rehearse is not None and stages is None and world > 1:
-            # a rehearsed rank of the HIP path: its on-grid count is the count AFTER the band pre-cull, so an empty
-            # band of a non-empty frame also reports 0 -- the frame-level zeros rule cannot be decided locally;
-            # the band (background where nothing reaches it) is what this rank contributes
-            return full[:H], None
-        if on_grid == 0:
-            # zeros, not background (render.py:73-76); identical inputs -> every rank takes this
-            # branch, so skipping the collective is consistent across the group
-            return torch.zeros(H, W, C, device=dev, dtype=torch.float32), None
-        if world == 1 or rehearse is not None:
-            return full[:H], None
-        work = dist.all_gather_into_tensor(full[:world * slab], full[rank * slab:(rank + 1) * slab],
-                                           group=group, async_op=True)
-        return full[:H], work
-
-    def resolve(img, work):
-        if work is not None:
-            work.wait()
+    def resolve(img, works):
+        for w_ in works:
+            w_.wait()
         return img() if callable(img) else img
 
+    def framebuffer():
+        # fresh per frame (caching allocator: no hipMalloc), handed out as a view
+        if padded:
+            return torch.empty((world, slab, W, C), dtype=torch.float32, device=dev)
+        return torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
+
     if stages is not None or not async_op:
-        # a fresh framebuffer per frame (caching allocator: no hipMalloc), handed out as a view
-        full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
-        on_grid = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                               bands[rank], full)
-        img, work = gather(full, on_grid)
+        buf = framebuffer()
+        if padded and stages is not None:
+            tmp = torch.empty((H, W, C), dtype=torch.float32, device=dev)     # (CPU test stages address the full image)
+            on_grid, m_band = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                                           bands[rank], tmp)
+            buf[rank, :y1s[rank] - y0s[rank]] = tmp[y0s[rank]:y1s[rank]]
+        else:
+            on_grid, m_band = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                                           bands[rank], buf[rank] if padded else buf, y0s[rank] if padded else None)
+        img, works = exchange(buf, on_grid, m_band)
         if not async_op:
-            return resolve(img, work)
-        return PendingFrame(finalize=lambda: resolve(img, work))
+            return resolve(img, works)
+        return PendingFrame(finalize=lambda: resolve(img, works))
 
     # asynchronous HIP path: band on a lane stream (ms_render_fwd BEGIN, no host wait).  Streams
     # are addressed by handle and ordered with events; torch's current stream is never switched
@@ -283,7 +418,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     lane = _turn.get(dev, 0)
     _turn[dev] = 1 - lane
     s = lanes[lane]
-    full = torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
+    buf = framebuffer()
     from . import render as _render   # bench.py's in-situ kernel timing hook (None otherwise)
     evs = _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None
     # Marshal first (non-fp32 / strided inputs and the view matrix are copied by kernels enqueued on the
@@ -292,7 +427,8 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     my_band = _band_of(bands[rank], th)
     bkey, bmode = _band_bin(means3d, camera, my_band, tile_size)
     frame = _Frame(means3d, scales, quats, opacities, features, camera, bg, bmode, evs,
-                   my_band, full, 1 + lane, s.cuda_stream, rows16=(tile_size == 16))
+                   my_band, buf[rank] if padded else buf, 1 + lane, s.cuda_stream, rows16=(tile_size == 16),
+                   out_y0=y0s[rank] if padded else None)
     # (persistent events per lane: Stream.wait_stream creates a fresh event per call, ~8 us of host time each)
     ev_in, ev_out = _lane_events(dev, lane)
     ev_in.record(cur)
@@ -301,7 +437,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     # tensors allocated on the current stream and used on the lane: the caching allocator must not hand
     # their memory out again before the lane is done with it
     seen = set()
-    for t in (means3d, scales, quats, opacities, features, bg, full) + tuple(x for x in frame.keep[:-1] if x is not None):
+    for t in (means3d, scales, quats, opacities, features, bg, buf) + tuple(x for x in frame.keep[:-1] if x is not None):
         if id(t) not in seen:     # (already-fp32 contiguous inputs ARE their marshalled copies)
             seen.add(id(t))
             t.record_stream(s)
@@ -313,8 +449,8 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         now = _current_stream(dev)
         ev_out.record(s)
         now.wait_event(ev_out)       # the band is complete before the exchange starts
-        img, work = gather(full, info["on_grid"])   # RCCL's stream waits for `now`
-        return resolve(img, work)                   # ... and `now` for the gather
+        img, works = exchange(buf, info["on_grid"], m)   # the collectives' stream waits for `now`
+        return resolve(img, works)                       # ... and `now` for the exchange
     return PendingFrame(finalize=finalize)
 
 

@@ -1,12 +1,17 @@
-"""Strong-scaling rehearsal on ONE GPU: time each rank's tile-row band of the same frame (no
-collective) for world = 1, 2, 4, 8, and the host-side enqueue cost of a frame.  The slowest band
-bounds what N GPUs can reach before the framebuffer all-gather is added.
+"""Strong-scaling rehearsal on ONE GPU: every rank's band of the same frame through the sharded entry point
+(rehearse = act as that rank, no exchange), for world = 1, 2, 4, 8 -- with the band boundaries the ranks' own pair
+counts lead to (distributed.rebalance, iterated here as the live group iterates it) beside the equal bands.
 
-    python scripts/band_bench.py [--workload cfg3] [--steps 100]
+    python scripts/band_bench.py [--workload cfg3] [--frames 300]
+
+Per rank: the MEDIAN time of `frames` blocking frames (GPU work + the host's enqueue, each frame synchronised), the
+median per-frame period of the pipelined entry point (two frames in flight) and the host time of an enqueue.  The
+slowest rank's median bounds what N GPUs can reach before the exchange is added.  One JSON line per (world, plan).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -15,14 +20,15 @@ import torch  # noqa: E402
 
 from bench import WORKLOADS  # noqa: E402
 from mojosplat_amd import _fused  # noqa: E402
-from mojosplat_amd.distributed import band_plan, render_gaussians_sharded  # noqa: E402
+from mojosplat_amd.distributed import band_plan, rebalance, render_gaussians_sharded  # noqa: E402
 from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--worlds", default="1,2,4,8")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     N, W, H, ell, fp16 = WORKLOADS[args.workload]
@@ -32,46 +38,81 @@ def main():
     bg = torch.tensor(BACKGROUND_V1, device=dev)
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     th = -(-H // 16)
-    for world in (1, 2, 4, 8):
+
+    def render(r, world, bounds, **kw):
+        return render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world), bounds=bounds, **kw)
+
+    def pairs_of(r, world, bounds):
+        """the weight a live rank reports for its band: the Gaussians that reach it (pre-culled band) or its pairs"""
+        for _ in range(3):      # (a band's first frames settle its bin size)
+            render(r, world, bounds)
+        torch.cuda.synchronize()
+        h = _fused._state[(dev, 0)]["host_np"]
+        culled = N >= 32768 and 10 * (bounds[r + 1] - bounds[r]) < 6 * th
+        return int(h[6]) if culled else int(h[0])
+
+    def measure(world, bounds, label):
+        ranks = []
+        for r in range(world):
+            for _ in range(12):
+                render(r, world, bounds)
+            torch.cuda.synchronize()
+            blocking, host = [], []
+            for _ in range(args.frames):
+                t0 = time.perf_counter()
+                render(r, world, bounds)
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                blocking.append(time.perf_counter() - t0)
+                host.append(t1 - t0)
+            # pipelined: frame k + 1 begun before frame k is finished (no exchange in rehearsal mode)
+            cur = None
+            for _ in range(24):
+                nxt = render(r, world, bounds, async_op=True)
+                if cur is not None:
+                    cur.wait()
+                cur = nxt
+            cur.wait()
+            torch.cuda.synchronize()
+            stamps = [time.perf_counter()]
+            cur = None
+            for _ in range(args.frames):
+                nxt = render(r, world, bounds, async_op=True)
+                if cur is not None:
+                    cur.wait()
+                cur = nxt
+                stamps.append(time.perf_counter())
+            cur.wait()
+            torch.cuda.synchronize()
+            periods = [b - a for a, b in zip(stamps[1:-1], stamps[2:])]
+            ranks.append(dict(band=[bounds[r], bounds[r + 1]], pairs=int(_fused._state[(dev, 1)]["host_np"][0]),
+                              blocking_us_median=round(statistics.median(blocking) * 1e6, 1),
+                              blocking_us_p90=round(sorted(blocking)[int(0.9 * len(blocking))] * 1e6, 1),
+                              pipelined_us_median=round(statistics.median(periods) * 1e6, 1),
+                              host_us_median=round(statistics.median(host) * 1e6, 1)))
+        worst_b = max(x["blocking_us_median"] for x in ranks)
+        worst_p = max(x["pipelined_us_median"] for x in ranks)
+        best_b = min(x["blocking_us_median"] for x in ranks)
+        print(json.dumps(dict(workload=args.workload, world=world, plan=label, bounds=bounds, frames=args.frames,
+                              slowest_blocking_us_median=worst_b, rank_spread=round(worst_b / best_b, 3),
+                              slowest_pipelined_us_median=worst_p, fps_bound_pipelined=round(1e6 / worst_p, 1), ranks=ranks)),
+              flush=True)
+
+    for world in [int(v) for v in args.worlds.split(",")]:
         rows, bands = band_plan(th, world)
-        frame = torch.empty((max(world * rows * 16, H), W, 3), device=dev)
-        per_rank = []
-        for r, band in enumerate(bands):
-            # the blocking sharded entry point acting as rank r (no exchange): pre-cull, the band's own bin size
-            for _ in range(6):
-                render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world))
-            t_host = time.perf_counter() - t0
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            from mojosplat_amd.render import _bin_mode
-            per_rank.append(dict(band=band, bin_px=[v for k, v in _bin_mode.items() if k[0] == "band" and k[5] == tuple(band)][-1:] or [16],
-                                 us=round(dt / args.steps * 1e6, 1), host_us=round(t_host / args.steps * 1e6, 1)))
-        # the same through the asynchronous sharded entry point (frame k+1 begun before frame k is
-        # finished; no exchange in rehearsal mode): what a rank's host + GPU can sustain
-        for r, rec in enumerate(per_rank):
-            def run(n):
-                cur = None
-                for _ in range(n):
-                    nxt = render_gaussians_sharded(*g, cam, background_color=bg, async_op=True, rehearse=(r, world))
-                    if cur is not None:
-                        cur.wait()
-                    cur = nxt
-                cur.wait()
-            run(24)   # (a rank's first pipelined frames grow its lanes' buffers and settle its bin size)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(args.steps)
-            torch.cuda.synchronize()
-            rec["pipelined_us"] = round((time.perf_counter() - t0) / args.steps * 1e6, 1)
-        worst = max(r["us"] for r in per_rank)
-        worst_p = max(r["pipelined_us"] for r in per_rank)
-        print(json.dumps(dict(workload=args.workload, world=world, slowest_band_us=worst,
-                              fps_bound=round(1e6 / worst, 1), slowest_pipelined_us=worst_p,
-                              fps_bound_pipelined=round(1e6 / worst_p, 1), ranks=per_rank)), flush=True)
+        equal = [b[0] for b in bands] + [th]
+        measure(world, equal, "equal bands")
+        if world == 1:
+            continue
+        # the plan a live group converges to: re-plan from the bands' pair counts until the spread is under 8 %
+        b = list(equal)
+        for it in range(8):
+            nb, spread = rebalance(b, [pairs_of(r, world, b) for r in range(world)])
+            if spread <= 1.08 or nb == b:
+                break
+            b = nb
+        if b != equal:
+            measure(world, b, f"balanced on the bands' reported weights ({it + 1} re-plans)")
 
 
 if __name__ == "__main__":

@@ -42,6 +42,28 @@ try:
                 assert torch.equal(cur.wait(), ref), f"tile_size={ts}: pipelined frame {k - 1} differs"
             cur = nxt
         assert torch.equal(cur.wait(), ref)
+    # ragged bands (explicit, then as the ranks' pair counts move them: the plan is re-made on every second frame
+    # here) under the exchange form MOJOSPLAT_GATHER selects -- the padded in-place all-gather + compaction copy, or
+    # grouped point-to-point sends / receives into the image's rows
+    import mojosplat_amd.distributed as D
+    D._CHECK_EVERY = 2
+    th = -(-cam.H // 16)
+    ragged = [0, 3, th] if world == 2 else [0, 2, 9, th]
+    assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, bounds=ragged), ref), "ragged blocking frame differs"
+    assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, bounds=ragged, async_op=True).wait(), ref)
+    plans = []
+    cur = None
+    for k in range(10):
+        plans.append(tuple(D.band_bounds(g[0], cam, 16, world)))
+        nxt = render_gaussians_sharded(*g, cam, background_color=bg, async_op=True)
+        if cur is not None:
+            assert torch.equal(cur.wait(), ref), f"balanced pipelined frame {k - 1} differs"
+        cur = nxt
+    assert torch.equal(cur.wait(), ref)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, plans)
+    assert all(p == gathered[0] for p in gathered), "the ranks' plans diverged"
+    print(f"rank {rank}/{world}: plans {sorted(set(plans))} gather={os.environ.get('MOJOSPLAT_GATHER', 'allgather')}", flush=True)
     # inputs the frame has to marshal (float64 / strided / fp16): their copies are made on the current stream
     # and read on a lane stream -- the ordering the pipelined path must get right
     g2 = (g[0].double(), torch.stack([g[1], g[1]], 1)[:, 0], g[2].double(), g[3], g[4].half())

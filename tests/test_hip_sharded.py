@@ -20,12 +20,12 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_hip_path_with_a_process_group(world):
+@pytest.mark.parametrize("world,gather", [(2, "allgather"), (3, "allgather"), (3, "direct")])
+def test_sharded_hip_path_with_a_process_group(world, gather):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "scripts", "sharded_gloo_gpu.py")]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MOJOSPLAT_GATHER=gather)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
