@@ -37,25 +37,25 @@ static inline ProjParams make_proj_params(float fx, float fy, float cx, float cy
     return P;
 }
 
-// The projection of one Gaussian.
-// -DMS_PROJ_FAST (NOT the shipped build; kept as a measured negative result): the chain written for the
-// instruction count -- the fused projection + count kernel was VALU bound in round 2 (1 200 instructions per
-// Gaussian, a third of them this chain):
+// The projection of one Gaussian.  Round 3: the chain is written for the instruction count -- the fused projection +
+// count kernel was VALU bound in round 2 (1 200 instructions per Gaussian, a third of them this chain):
 //   * cov2d = (J W M)(J W M)^T with M = R diag(s): the 2x3 matrix T = J W costs 12 operations, B = T R 18,
 //     A = B diag(s) 6 and the three entries of A A^T 9 -- 45 multiply-adds where the reference's order
 //     (cov3d = M M^T, W cov3d W^T, J . J^T; projection.mojo:129-198) takes ~160; same quantity, rounded differently
 //     at the 1e-7 level;
-//   * FMA contraction on; v_rsq_f32 / v_rcp_f32 (+ one Newton step for 1/z and 1/det) / v_sqrt_f32 / v_log_f32
-//     instead of the IEEE division and square-root sequences (~10 instructions each).
-// 507 -> 273 VALU instructions for the stand-alone kernel, k_project_hist 31.8 -> 28.3 us at config 3 -- and 27
-// pixels of the config-3 frame beyond 1e-4 of the oracle's with no branch of its walk within 2e-5 of a threshold
-// (round 2's chain: 0): cov2d's determinant cancels for elongated footprints (condition number a c / det up to
-// ~1e3), so two fp32 evaluations of a, b, c that are each good to 1e-7 but rounded in a different ORDER give conics
-// that differ by 1e-4 relative, i.e. alphas by 5e-4 at the 1/255 threshold.  The shipped chain therefore keeps the
-// reference's operation order for cov2d, uncontracted (bit for bit the oracle's a, b, c up to the ulp of expf), and
-// is fast only where an error is not amplified: the conics' common factor 1 / det.
+//   * FMA contraction on; v_rsq_f32 / v_rcp_f32 + one Newton step / v_sqrt_f32 / v_log_f32 instead of the IEEE
+//     division and square-root sequences (~10 instructions each) -- on the COVARIANCE side only.
+// What stays in the reference's operation order, uncontracted and IEEE: the camera-space mean, 1 / z and means2d.
+// A first version that let those take part (v_rcp for 1 / z, contracted products) left 27 pixels of the config-3
+// frame beyond 1e-4 of the oracle's with no branch of its walk within 2e-5 of a threshold: an ulp of a mean at
+// x ~ 1000 px is 6e-5 px, which moves sigma by 3e-5 for a 3-px Gaussian evaluated 5 px out -- more than the margin
+// the parity bar grants -- while an ulp of the conic moves it by 5e-7.  So means2d and the depth are bit for bit the
+// oracle's, the conics agree to ~1e-7 relative, and the integer radii agree except where extent * sqrt(cov) lands
+// within a few ulp of an integer (a counted handful per 100k Gaussians, as before: libm's expf / logf already
+// differed from the GPU's by an ulp).  -DMS_PROJ_STRICT compiles round 2's chain throughout.
 template <class Idx>
 __device__ __forceinline__ float ld_f32(const float *base, Idx i, int stride, int k) {
+    // Idx = uint32_t: byte offsets formed in 32 bits against uniform base pointers (saddr + voffset addressing)
     if constexpr (sizeof(Idx) == 4)
         return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (uint32_t)(4u * ((uint32_t)stride * (uint32_t)i + (uint32_t)k)));
     else
@@ -74,7 +74,7 @@ __device__ __forceinline__ float rcp_nr(float x) {   // 1 / x to ~0.5 ulp: v_rcp
     return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
 
-#ifdef MS_PROJ_FAST
+#ifndef MS_PROJ_STRICT
 template <class Idx>
 __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ means3d,
                                                const float *__restrict__ scales, const float *__restrict__ quats,
@@ -85,17 +85,21 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> s_load
 
-    const float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
-    const float mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
-    const float my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
-    const float z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
+    const float p0 = ld_f32(means3d, i, 3, 0), p1 = ld_f32(means3d, i, 3, 1), p2 = ld_f32(means3d, i, 3, 2);
+    float mx, my, z;
+    {   // the camera-space mean: the reference's operation order, uncontracted (see above: means2d and the depth)
+#pragma clang fp contract(off)
+        mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
+        my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
+        z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
+    }
 
     float o_m0 = 0.f, o_m1 = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_d = 0.f;
     int o_r0 = 0, o_r1 = 0;
 
     bool alive = !(z < P.near_plane || z > P.far_plane);
     if (alive) {
-        const float4 q4 = reinterpret_cast<const float4 *>(quats)[i];
+        const float4 q4 = ld_f32x4(quats, i);
         float w = q4.x, x = q4.y, y = q4.z, zq = q4.w;
         const float inv_norm = __builtin_amdgcn_rsqf(x * x + y * y + zq * zq + w * w);
         w *= inv_norm; x *= inv_norm; y *= inv_norm; zq *= inv_norm;
@@ -105,11 +109,17 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
         const float R10 = 2.f * (xy + wz), R11 = 1.f - 2.f * (x2 + z2), R12 = 2.f * (yz - wx);
         const float R20 = 2.f * (xz - wy), R21 = 2.f * (yz + wx), R22 = 1.f - 2.f * (x2 + y2);
 
-        float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+        float s0 = ld_f32(scales, i, 3, 0), s1 = ld_f32(scales, i, 3, 1), s2 = ld_f32(scales, i, 3, 2);
         if (P.scales_are_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
 
         // pinhole Jacobian with the 1.3x FOV clamp; T = J Wv (2x3)
-        const float rz = rcp_nr(z);
+        float rz, m2x, m2y;
+        {   // means2d: IEEE 1 / z and the reference's products, uncontracted -- bit for bit the oracle's
+#pragma clang fp contract(off)
+            rz = 1.0f / z;
+            m2x = P.fx * mx * rz + P.cx;
+            m2y = P.fy * my * rz + P.cy;
+        }
         const float tx = z * fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz));
         const float ty = z * fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
         const float J00 = P.fx * rz, J02 = -(J00 * tx) * rz;
@@ -124,14 +134,13 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
         const float a = A00 * A00 + A01 * A01 + A02 * A02 + P.eps2d;
         const float b = A00 * A10 + A01 * A11 + A02 * A12;
         const float c = A10 * A10 + A11 * A11 + A12 * A12 + P.eps2d;
-        const float m2x = (P.fx * mx) * rz + P.cx, m2y = (P.fy * my) * rz + P.cy;
 
         const float det = a * c - b * b;
         alive = det > 0.f;
 
         float extend = 3.33f;
         if (alive && P.has_opacity) {
-            const float op = opacities[i];
+            const float op = ld_f32(opacities, i, 1, 0);
             if (op < kAlphaThreshold) {
                 alive = false;
             } else {
@@ -158,9 +167,8 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
     return ProjOut{o_m0, o_m1, o_c0, o_c1, o_c2, o_d, o_r0, o_r1};
 }
 #else
-// The shipped chain: strict fp32 evaluation order (no FMA contraction), the reference's operation order
-// (projection.mojo:89-211), so that the only differences against the CPU oracle come from expf / logf and the
-// conics' common factor; radii are integers and flip on 1-ulp changes.
+// Round 2's chain (-DMS_PROJ_STRICT): strict fp32 evaluation order (no FMA contraction), the reference's operation
+// order throughout (projection.mojo:89-211); only the conics' common factor 1 / det is a v_rcp_f32 + Newton step.
 template <class Idx>
 __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ means3d,
                                                const float *__restrict__ scales, const float *__restrict__ quats,
