@@ -264,9 +264,9 @@ def main():
 
     # Every event between two kernels costs the GPU a bubble (measured: the pair around the rasteriser on
     # every frame costs 7-8 us per frame, 3 % of the headline): long runs instrument every 8th frame of the
-    # timed region, runs of 16-63 steps every 4th (the driver's 20-step run: 5 launches), shorter ones every frame.
+    # timed region (the driver's 20-step run: 2 launches), runs under 16 steps every frame.
     # `avg_kernel_us` is the mean over the instrumented launches.
-    every = 8 if args.steps >= 64 else 4 if args.steps >= 16 else 1
+    every = 8 if args.steps >= 16 else 1
     calls = [0]
 
     def hook():
@@ -279,8 +279,8 @@ def main():
 
     # Everything that idles the GPU (event creation, the band statistics above) is done: now the untimed frames.
     # A short run (the driver's 20 steps are 4 ms) otherwise starts on a chip whose clock has not ramped yet:
-    # 32 spin-up frames, then the W warm-up steps the contract asks for, then the barrier and the timed loop.
-    for _ in range(32):
+    # 128 spin-up frames (23 ms), then the W warm-up steps the contract asks for, then the barrier and the timed loop.
+    for _ in range(128):
         step()
     for _ in range(args.warmup):
         step()

@@ -575,7 +575,8 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                     col[0] = __half2float(c[3 * src]); col[1] = __half2float(c[3 * src + 1]); col[2] = __half2float(c[3 * src + 2]);
                 } else {
                     const float *c = reinterpret_cast<const float *>(colors) + 3 * b0;
-                    col[0] = ms::ld_f32(c, src, 3, 0); col[1] = ms::ld_f32(c, src, 3, 1); col[2] = ms::ld_f32(c, src, 3, 2);
+                    const ms::F3 c3 = ms::ld_f32x3(c, src);
+                    col[0] = c3.x; col[1] = c3.y; col[2] = c3.z;
                 }
                 const ms::RasterRecord r = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), col[0], col[1], col[2]);
                 // (stores likewise: the step's slice of the output + a 32-bit byte offset)

@@ -123,13 +123,14 @@ int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means
                   const LazyLists *lazy, const void *records, const int32_t *order, int clip_row16_begin,
                   int clip_row16_end, void *after_raster_event, void *stream);
 
-// rasterize_bwd.hip: ms_rasterize_to_pixels_3dgs_bwd with the forward frame's ready-made records (or null)
+// rasterize_bwd.hip: ms_rasterize_to_pixels_3dgs_bwd with the forward frame's ready-made records (or null) and its
+// heaviest-first order of the image's tiles (16-px tiles only; or null: the kernel's own counting sort)
 int rasterize_bwd(int64_t N, int64_t M, const float *means2d, const float *conics, const float *colors, int CDIM,
                   const float *opacities, const float *backgrounds, int W, int H, int tile_size,
                   const int32_t *tile_ranges, const int32_t *flatten_ids, const float *render_alphas,
                   const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, float *v_means2d,
                   float *v_conics, float *v_colors, float *v_opacities, void *workspace, size_t workspace_bytes,
-                  int overwrite, const void *records, void *stream);
+                  int overwrite, const void *records, const int32_t *block_order, void *stream);
 
 // Block lists of a split frame (ms_render_fwd): what the sort kernels of 32-px bins write instead of
 // flatten_ids.  Bin `b` with list [start, start + n) owns block_ids[4 start, 4 (start + n)): its block q

@@ -452,7 +452,10 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     float *v_means2d = (float *)(bw + rb), *v_conics = (float *)(bw + rb + ms::align_up((size_t)N * 8, 256));
     if (int rc = ms::rasterize_bwd(N, M, means2d, conics, colors, CDIM, opacities, backgrounds, W, H, tile_size, ranges, ids,
                                    render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors,
-                                   v_opacities, rb ? bw : nullptr, rb, /*overwrite=*/1, records, stream_))
+                                   v_opacities, rb ? bw : nullptr, rb, /*overwrite=*/1, records,
+                                   // (a whole-image frame on 16-px tiles: its count pass ordered exactly these blocks)
+                                   (tile_size == 16 && ms_order_enabled()) ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr,
+                                   stream_))
         return rc;
     if (mid_event) MS_HIP(hipEventRecord((hipEvent_t)mid_event, stream));   // (in-situ timing: between the two stages)
     return ms_project_gaussians_bwd(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, radii,

@@ -69,6 +69,16 @@ __device__ __forceinline__ float4 ld_f32x4(const float *base, Idx i) {
         return reinterpret_cast<const float4 *>(base)[i];
 }
 
+// three consecutive floats of an AoS row as ONE 12-byte load (global_load_dwordx3; 4-byte alignment suffices)
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+template <class Idx>
+__device__ __forceinline__ F3 ld_f32x3(const float *base, Idx i) {
+    if constexpr (sizeof(Idx) == 4)
+        return *reinterpret_cast<const F3 *>(reinterpret_cast<const char *>(base) + (uint32_t)(12u * (uint32_t)i));
+    else
+        return reinterpret_cast<const F3 *>(base)[i];
+}
+
 __device__ __forceinline__ float rcp_nr(float x) {   // 1 / x to ~0.5 ulp: v_rcp_f32 + one Newton step
     const float r = __builtin_amdgcn_rcpf(x);
     return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
@@ -85,7 +95,8 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = viewmat[k];  // uniform -> s_load
 
-    const float p0 = ld_f32(means3d, i, 3, 0), p1 = ld_f32(means3d, i, 3, 1), p2 = ld_f32(means3d, i, 3, 2);
+    const F3 p3 = ld_f32x3(means3d, i);
+    const float p0 = p3.x, p1 = p3.y, p2 = p3.z;
     float mx, my, z;
     {   // the camera-space mean: the reference's operation order, uncontracted (see above: means2d and the depth)
 #pragma clang fp contract(off)
@@ -109,7 +120,8 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
         const float R10 = 2.f * (xy + wz), R11 = 1.f - 2.f * (x2 + z2), R12 = 2.f * (yz - wx);
         const float R20 = 2.f * (xz - wy), R21 = 2.f * (yz + wx), R22 = 1.f - 2.f * (x2 + y2);
 
-        float s0 = ld_f32(scales, i, 3, 0), s1 = ld_f32(scales, i, 3, 1), s2 = ld_f32(scales, i, 3, 2);
+        const F3 s3 = ld_f32x3(scales, i);
+        float s0 = s3.x, s1 = s3.y, s2 = s3.z;
         if (P.scales_are_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
 
         // pinhole Jacobian with the 1.3x FOV clamp; T = J Wv (2x3)

@@ -567,7 +567,7 @@ extern "C" int ms_rasterize_to_pixels_3dgs_bwd(
     size_t workspace_bytes, int overwrite, void *stream) {
     return ms::rasterize_bwd(N, M, means2d, conics, colors, CDIM, opacities, backgrounds, W, H, tile_size, tile_ranges,
                              flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d, v_conics,
-                             v_colors, v_opacities, workspace, workspace_bytes, overwrite, nullptr, stream);
+                             v_colors, v_opacities, workspace, workspace_bytes, overwrite, nullptr, nullptr, stream);
 }
 
 int ms::rasterize_bwd(
@@ -576,7 +576,7 @@ int ms::rasterize_bwd(
     const int32_t *tile_ranges, const int32_t *flatten_ids, const float *render_alphas,
     const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
     float *v_means2d, float *v_conics, float *v_colors, float *v_opacities, void *workspace,
-    size_t workspace_bytes, int overwrite, const void *records, void *stream) {
+    size_t workspace_bytes, int overwrite, const void *records, const int32_t *block_order, void *stream) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_bwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_bwd: CDIM %d not in 1..32", CDIM);
@@ -627,6 +627,10 @@ int ms::rasterize_bwd(
         // reserves it); two waves per block while the launch is a few rounds at most
         B2.order = nullptr;
         const size_t order_off = ms::align_up(packed_bytes, 256);
+        if (block_order && A.nsub == 1) {
+            // the forward frame's own heaviest-first order of the same tiles (its count pass left it): no k_bwd_order
+            B2.order = block_order;
+        } else
         if (workspace_bytes >= order_off + (size_t)blocks * sizeof(int32_t)) {
             int32_t *order = (int32_t *)((char *)workspace + order_off);
             hipLaunchKernelGGL(k_bwd_order, dim3(1), dim3(1024), 0, st, A.tw * th, A.nsub, tile_ranges, order);
