@@ -26,9 +26,10 @@
  *   - destination passing: the caller (PyTorch) owns and pre-allocates every buffer,
  *     including scratch; the library never allocates device memory and keeps no per-frame or
  *     per-scene state.  What it does keep, process-wide and thread-safe: the thread-local
- *     error string, three environment switches read once (MOJOSPLAT_LAZY_SORT, MOJOSPLAT_SPLIT,
- *     MOJOSPLAT_SPLIT_MAX_ENTRIES) and a mutex-guarded table of the (device, kernel) pairs whose
- *     dynamic-LDS ceiling it has already raised (hipFuncSetAttribute);
+ *     error string, the environment switches it reads once (MOJOSPLAT_LAZY_SORT, MOJOSPLAT_SPLIT,
+ *     MOJOSPLAT_SPLIT_MAX_ENTRIES, MOJOSPLAT_LEAN, MOJOSPLAT_DEFER_TOTAL and the measurement knobs listed in
+ *     INTEGRATION.md) and a mutex-guarded table of the (device, kernel) pairs whose dynamic-LDS ceiling it has
+ *     already raised (hipFuncSetAttribute);
  *   - all pointers are DEVICE pointers unless a parameter says "host"; tensors are
  *     contiguous row-major with the layouts written next to each parameter;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); the per-stage
@@ -304,6 +305,10 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  *                record to start afresh.
  *   stage_events: NULL, or 4 hipEvent_t recorded on `stream` at: start, after projection,
  *                after binning, after rasterisation (for in-situ kernel timing).
+ * LEAN FRAMES.  A plain forward frame with CDIM == 3 keeps NO projected arrays in `workspace`: its rasteriser reads
+ * the 48-byte records the count kernel leaves per Gaussian, its scatter kernel a 12-byte (tile box, depth bits, reach
+ * mask) record; means2d / conics / depths / radii are only written for frames that are asked for render_alphas or
+ * last_ids (what a backward needs), for other channel counts, or with MOJOSPLAT_LEAN=0 in the environment.
  * SPLIT FRAMES.  A plain forward frame (no render_alphas / last_ids, CDIM <= 4) at tile_size 16 over the
  * whole image or a band of >= 16 tile rows is binned on 32-px bins with block masks (see `tight`), and
  * the sort kernels cut every bin's sorted list into the lists of its four 16x16 blocks, which is what
