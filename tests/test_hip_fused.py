@@ -116,6 +116,22 @@ def test_sharded_bands_with_an_explicit_tile_size_and_on_sparse_scenes(device):
     assert torch.equal(out, ref2)
 
 
+def test_lean_frames_on_wide_grids_and_small_tiles(device):
+    """The records a lean frame's count kernel leaves for its scatter kernel: 12 bytes on plain bins of grids up to 255
+    tiles a side, 16 + 8 bytes beyond that (here: 8-px tiles across a 2 100-px-wide strip, 263 tiles a row) and on
+    split frames; boxes of 33-64 tiles keep every tile under the 12-byte form (large footprints on 8-px tiles).  Every
+    form, sync-free and exact, equals the per-stage path bit for bit."""
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    for (n, W, H, ell, ts) in ((40_000, 2100, 96, -3.2, 8), (20_000, 640, 360, -2.2, 8), (20_000, 640, 360, -2.2, 32),
+                               (30_000, 4128, 64, -3.0, 16)):
+        sc, cam = randscene_v1(n, W, H, ell=ell, seed=21, device=device)
+        g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+        ref = stagewise(sc, cam, bg, ts)
+        for k in range(3):     # exact path (no buffer yet), then two sync-free frames
+            img = ms.render_gaussians(*g, cam, background_color=bg, backend="hip", tile_size=ts)
+            assert torch.equal(img, ref), (n, W, H, ell, ts, k)
+
+
 def test_split_frames_on_bands_that_cut_through_bin_rows(device):
     """Bands of >= 16 tile rows are split frames (32-px bins cut into block lists) even when they start
     or end in the middle of a bin row: the bins of that row are binned whole, only the band's blocks are

@@ -192,6 +192,25 @@ def test_c_abi_argument_validation_returns_status_codes():
     assert frame(r0=1, r1=0) == INVALID and "band" in err()
     assert frame(wsb=8) == WORKSPACE and "workspace" in err()
     assert L.ms_render_workspace_bytes(N, 1, 1) >= L.ms_isect_workspace_bytes(N, 1, 1)
+    # backward of a differentiable frame
+    host[0], host[6], host[7] = 100, 5, 4          # 100 pairs, 5 Gaussians on the grid, exact layout
+    bws = L.ms_render_bwd_workspace_bytes(N, 3)
+    assert bws >= L.ms_rasterize_bwd_workspace_bytes(N, 3) + 10 * 20
+
+    def bwd(n=N, cdim=3, wsb=1 << 30, isb=1 << 20, bwsb=None, hinfo=host, ws=P):
+        return L.ms_render_bwd(n, P, P, 1, P, P, P, cdim, P, 1., 1., 0., 0., 16, 16, .3, 16, None, ws, wsb, P, isb, hinfo,
+                               P, P, P, None, P, P, P, P, P, P, bws if bwsb is None else bwsb, None, None)
+    assert bwd(cdim=40) == INVALID and "sizes" in err()
+    assert bwd(hinfo=None) == INVALID and "null" in err()
+    assert bwd(ws=None) == INVALID and "null" in err()
+    assert bwd(wsb=8) == WORKSPACE and "workspace" in err()
+    assert bwd(bwsb=8) == WORKSPACE and "backward workspace" in err()
+    assert bwd(isb=64) == WORKSPACE and "ids" in err()
+    host[7] = 4 | 8
+    assert bwd() == INVALID and "split" in err()
+    assert bwd(n=ctypes.c_int64(0)) == OK          # nothing to differentiate
+    for k in range(8):
+        host[k] = 0
 
 
 def test_bin_rule_on_the_baseline_configs():
