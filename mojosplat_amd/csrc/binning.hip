@@ -71,6 +71,8 @@ constexpr bool kLean12Enabled = false;   // (variant builds: A/B against the 16 
 #else
 constexpr bool kLean12Enabled = true;
 #endif
+constexpr int kLightBucket = 32;   // length bucket (4 per octave) of the longest LIGHT list: 255 entries
+constexpr int kLightCap = 256;     // ... sorted by ONE wave (sort_segment_lds<64, 4>), eight lists to a workgroup
 constexpr int kLean = 64;          // ... the frame keeps LeanRecs instead of the projected arrays (internal: ms_render_fwd)
 constexpr int kDeferTotal = 128;   // ... the scans' total pass rides in the scatter launch (internal: sync-free frames)
 static_assert(kLean == ms::kTightLean && kDeferTotal == ms::kTightDeferTotal, "internal flag bits out of sync");
@@ -794,6 +796,10 @@ __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
             s_base[126 - 2 * lane] = excl + c0;
         }
         __syncthreads();
+        // where the LIGHT lists (bucket <= kLightBucket: at most 255 entries) begin in the order: k_tile_front sorts
+        // those eight to a workgroup
+        if (threadIdx.x == 0 && A.wg_on_grid) const_cast<uint32_t *>(A.wg_on_grid)[kMaxG + 1] = s_base[kLightBucket];
+        __syncthreads();
         auto place = [&](int t, unsigned int c) {
             if (t < w1 && t >= band0 && t < band1) order[atomicAdd(&s_base[bucket_of(c)], 1u)] = t;
         };
@@ -998,6 +1004,8 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
             s_base[127 - 2 * lane] = excl;
             s_base[126 - 2 * lane] = excl + c0;
         }
+        __syncthreads();
+        if (tid == 0 && A.wg_on_grid) const_cast<uint32_t *>(A.wg_on_grid)[kMaxG + 1] = s_base[kLightBucket];   // (see tile_scan_total)
         __syncthreads();
         for (int t = tid; t < T_local; t += kHistThreads)
             A.order[atomicAdd(&s_base[bucket_of(A.tile_count[t])], 1u)] = band0 + t;
@@ -1278,7 +1286,8 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
                                                      uint32_t fixed_min, int fixed_shift, int front_k,
                                                      ms::BlockLists blocks, int bin_w,
                                                      const uint32_t *__restrict__ wg_depth, int n_wg,
-                                                     const int32_t *__restrict__ order, int n_order, int front_cap) {
+                                                     const int32_t *__restrict__ order, int n_order, int front_cap,
+                                                     const uint32_t *__restrict__ n_big_dev) {
     static_assert(!(SPLIT && MERGED), "block lists are cut by the two-launch path");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem_dyn);
@@ -1291,6 +1300,27 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
     const int nx = info_dev ? (int)info_dev[4] : nx_host;
     const int total = MERGED ? n_order : nm + nl + nx;
     if ((int)blockIdx.x >= total) return;   // (uniform; a sync-free launch is sized for the worst case)
+    const int n_big = (MERGED && n_big_dev) ? min((int)*n_big_dev, total) : -1;
+    if constexpr (MERGED) {
+        // LIGHT lists (at most 255 entries; the order lists them last, from index n_big on): a whole 512-thread
+        // workgroup per list spends 4 us of barriers and round trips on each -- 907 of config 3's 2 040 bins, which
+        // only find a slot once the heavy bins have finished (profiles/r03_bin_phases.txt) -- so they are sorted
+        // EIGHT to a workgroup, one per wave, wave-synchronously (no workgroup barrier on this path).
+        if (n_big >= 0 && (int)blockIdx.x >= n_big) {
+            const int e = n_big + 8 * ((int)blockIdx.x - n_big) + w;
+            if (e < total) {
+                const int tile = order[e];
+                const int start = tile_ranges[2 * tile], n = tile_ranges[2 * tile + 1] - start;
+                if (n > 0 && n <= kLightCap && (int64_t)start + n <= cap)
+                    sort_segment_lds<64, kLightCap / 64>(smem_dyn + (size_t)w * SortCfg<64, kLightCap / 64>::LDS, keys, start, n, tile,
+                                                         flatten_ids, nullptr, nullptr);
+            }
+            return;
+        }
+    }
+#ifdef MS_DIAG
+    if (g_diag_bin && tid == 0) g_diag_bin[(3 * 1024 + (blockIdx.x & 1023)) * 8 + (blockIdx.x >> 10) * 3] = __builtin_amdgcn_s_memrealtime();
+#endif
     // The frame's own depth range (per-workgroup min / max left by the scatter) beats the camera planes:
     // the scene fills a fraction of (near, far), and buckets that are several times finer make the
     // ranking inside a bucket as many times shorter.  (MERGED: only a block that meets a heavy tile needs it.)
@@ -1331,6 +1361,12 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
                     sort_segment_lds<kFrontThreads, kSmallCap / kFrontThreads>(smem_dyn, keys, start, n, tile, flatten_ids,
                                                                                nullptr, nullptr);
                 __syncthreads();   // LDS is reused by the next list entry
+#ifdef MS_DIAG
+                if (g_diag_bin && tid == 0) {
+                    unsigned long long *d = g_diag_bin + (3 * 1024 + (blockIdx.x & 1023)) * 8 + (blockIdx.x >> 10) * 3;
+                    d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = (unsigned long long)n;
+                }
+#endif
                 continue;
             }
             frame_range();
@@ -1354,6 +1390,12 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
             for (int i = tid; i < F; i += THREADS) flatten_ids[start + i] = (int32_t)(uint32_t)s_out[i];
         if (tid == 0) front_count[tile] = F;
         __syncthreads();   // LDS is reused by the next list entry
+#ifdef MS_DIAG
+        if (g_diag_bin && tid == 0) {
+            unsigned long long *d = g_diag_bin + (3 * 1024 + (blockIdx.x & 1023)) * 8 + (blockIdx.x >> 10) * 3;
+            d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = (unsigned long long)n;
+        }
+#endif
     }
 }
 
@@ -1843,13 +1885,18 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             const ms::FrontParams fp = ms::front_params(tile_size, lazy, depth_near, depth_far, merged, bl.block_ids != nullptr);
             const uint32_t fixed_min = fp.fixed_min;
             const int fixed_shift = fp.fixed_shift, front_k = fp.front_k, front_cap = fp.front_cap;
-            const size_t front_lds = kFrontLds - (size_t)(kFrontCap - front_cap) * 8;
+            size_t front_lds = kFrontLds - (size_t)(kFrontCap - front_cap) * 8;
+            // (merged launch: room for eight waves' private sorts of light lists)
+            static const bool light_env = [] { const char *e = getenv("MOJOSPLAT_LIGHT_SORT"); return !e || atoi(e) != 0; }();
+            const bool light = merged && light_env;
+            if (light && front_lds < 8 * SortCfg<64, kLightCap / 64>::LDS) front_lds = 8 * SortCfg<64, kLightCap / 64>::LDS;
             hipLaunchKernelGGL(front, dim3(merged ? (unsigned)p.T_local : grid), dim3(kFrontThreads), front_lds, stream,
                                medium, large, xl,
                                spec ? info_dev : nullptr, (int)n_medium, (int)n_large, (int)n_xl, tile_ranges,
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift,
                                front_k, bl, tile_w, (const uint32_t *)(ws + p.off_depth_wg), p.G,
-                               (const int32_t *)(ws + p.off_order), p.T_local, front_cap);
+                               (const int32_t *)(ws + p.off_order), p.T_local, front_cap,
+                               light ? (const uint32_t *)(ws + p.off_on_grid) + kMaxG + 1 : nullptr);
             MS_LAUNCH_CHECK();
         }
         if (merged) return MS_OK;

@@ -118,7 +118,19 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + Cfg::CAP);
     uint32_t *s_red = s_cnt + Cfg::NB;  // 64 words of reduction scratch
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // THREADS == 64: ONE WAVE sorts the segment on its own (smem is the wave's private slice; wave-level
+    // synchronisation only): several short lists per workgroup, one per wave, no workgroup barrier anywhere
+    constexpr bool WAVE = THREADS == 64;
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, w = WAVE ? 0 : tid >> 6;
+    auto sync = [&]() __attribute__((always_inline)) {
+        if constexpr (WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __syncthreads();
+        }
+    };
 
     // 1. keys -> registers; min / max of the depth bits
     uint64_t k[E];
@@ -141,7 +153,7 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
     if (lane == 0) { s_red[w] = kmin; s_red[16 + w] = kmax; }
     const int B = min(Cfg::NB, max(64, 2 * next_pow2(n)));
     for (int b = tid; b < B; b += THREADS) s_cnt[b] = 0;
-    __syncthreads();
+    sync();
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) { kmin = min(kmin, s_red[ww]); kmax = max(kmax, s_red[16 + ww]); }
     const uint32_t span = kmax - kmin;
@@ -152,7 +164,7 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (e * THREADS + tid < n) atomicAdd(&s_cnt[((uint32_t)(k[e] >> 32) - kmin) >> shift], 1u);
-    __syncthreads();
+    sync();
 
     // 3. exclusive scan of the B counters (each lane owns `per` consecutive ones)
     const int per = (B + THREADS - 1) / THREADS;   // <= NB / THREADS, a power of two or 1
@@ -173,10 +185,10 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d));
-    __syncthreads();  // s_red reuse
+    sync();  // s_red reuse
     if (lane == 63) s_red[w] = incl;
     if (lane == 0) s_red[16 + w] = cmax;
-    __syncthreads();
+    sync();
     uint32_t run = incl - sum;
     cmax = 0;
 #pragma unroll
@@ -189,7 +201,7 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
         const int b = tid * per + q;
         if (q < per && b < B) { s_cnt[b] = run; run += local[q]; }
     }
-    __syncthreads();
+    sync();
 
     // 4. scatter into buckets (s_cnt[b] becomes the END of bucket b)
 #pragma unroll
@@ -198,13 +210,13 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
             const uint32_t pos = atomicAdd(&s_cnt[((uint32_t)(k[e] >> 32) - kmin) >> shift], 1u);
             s_out[pos] = k[e];
         }
-    __syncthreads();
+    sync();
 
     // 5. finish.  Every key ranks itself inside its bucket (reads only: k independent LDS loads
     //    for a bucket of k keys, no divergent dependent chains), barrier, then drops into place.
     //    Keys are distinct, so ranks are a permutation.  A crowded bucket (many identical depths)
     //    sends the tile to the oblivious network instead.
-    if (cmax <= (uint32_t)kBucketFallback) {
+    if (WAVE || cmax <= (uint32_t)kBucketFallback) {   // (a wave's list is shorter than any crowded bucket)
         int dest[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -217,19 +229,19 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
                 dest[e] = beg + r;
             }
         }
-        __syncthreads();
+        sync();
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (dest[e] >= 0) s_out[dest[e]] = k[e];
-    } else {
+    } else if constexpr (!WAVE) {
         const int P = max(2, next_pow2(n));
         for (int i = n + tid; i < P; i += THREADS) s_out[i] = ~0ull;
-        __syncthreads();
+        sync();
         bitonic_sort_lds<THREADS>(s_out, P);
     }
-    __syncthreads();
+    sync();
     if (blocks) {   // split frame: block lists instead of the bin's own list
-        if constexpr (E * (THREADS / 64) <= 64)   // (only the small class sorts bins)
+        if constexpr (E * (THREADS / 64) <= 64 && THREADS >= 256)   // (only the small class sorts bins)
             emit_block_lists<THREADS, E>(s_out, n, n, start, tile, bin_w, *blocks, s_cnt);
         return;
     }

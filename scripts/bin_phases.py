@@ -37,12 +37,34 @@ def main():
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     for _ in range(8):
         ms.render_gaussians(*g, cam, background_color=bg)
-    buf = torch.zeros(3 * 1024 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(4 * 1024 * 8, dtype=torch.int64, device=dev)
     _hip.check(L.ms_diag_set_bin_stamps(ctypes.c_void_p(buf.data_ptr())), "diag")
     ms.render_gaussians(*g, cam, background_color=bg)
     torch.cuda.synchronize()
     _hip.check(L.ms_diag_set_bin_stamps(None), "diag")
-    d = buf.cpu().numpy().reshape(3, 1024, 8).astype(np.float64)
+    raw = buf.cpu().numpy()
+    # k_tile_front (kernel 3): up to three blocks per slot (blockIdx & 1023, blockIdx >> 10): start, end, list length
+    fr = raw[3 * 1024 * 8:].reshape(1024, 8)
+    rows = []
+    for q in range(2):
+        blk = fr[:, 3 * q:3 * q + 3]
+        rows.append(blk[blk[:, 0] != 0])
+    fr = np.concatenate(rows).astype(np.float64)
+    if len(fr):
+        t0 = fr[:, 0].min()
+        life = (fr[:, 1] - fr[:, 0]) / 100.0
+        out = {"kernel": "k_tile_front<merged>", "workgroups": int(len(fr)), "first_start_to_last_end_us": round((fr[:, 1].max() - t0) / 100.0, 2)}
+        for lo, hi in ((0, 256), (256, 1024), (1024, 2048), (2048, 4096), (4096, 1 << 30)):
+            m = (fr[:, 2] > lo) & (fr[:, 2] <= hi)
+            if m.any():
+                out[f"n in ({lo}, {hi}]"] = {"count": int(m.sum()), "life_us_p50": round(float(np.percentile(life[m], 50)), 2),
+                                           "life_us_max": round(float(life[m].max()), 2),
+                                           "start_us_p50": round(float(np.percentile((fr[m, 0] - t0) / 100.0, 50)), 2),
+                                           "start_us_max": round(float(((fr[m, 0] - t0) / 100.0).max()), 2)}
+        rel0, rel1 = (fr[:, 0] - t0) / 100.0, (fr[:, 1] - t0) / 100.0
+        out["resident_workgroups_at_us"] = {str(t): int(((rel0 <= t) & (rel1 > t)).sum()) for t in (1, 3, 5, 7, 9, 11, 13)}
+        print(json.dumps(out), flush=True)
+    d = raw[:3 * 1024 * 8].reshape(3, 1024, 8).astype(np.float64)
     pct = lambda v: {k: round(float(np.percentile(v, q)) / 100.0, 2) for k, q in (("p10", 10), ("p50", 50), ("p90", 90), ("max", 100))}
     for k, (kname, phases) in NAMES.items():
         wg = d[k][d[k][:, 0] != 0]
