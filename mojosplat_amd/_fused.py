@@ -19,10 +19,51 @@ from .projection import EPS2D
 
 LAZY_SORT = os.environ.get("MOJOSPLAT_LAZY_SORT", "1") != "0"  # mirrors csrc/pipeline.hip
 
-_state = {}  # (device, lane) -> dict(ws, isect, host, ev); lane 0 = the plain single-frame path
-# Host threads that render on the same device share that device's cached scratch: whole frames
-# (render_fwd_hip) take this lock, so they run one after the other instead of racing on it.  (Split-phase
-# frames -- begin/finish on lanes -- are driven by one thread by design.)
+class _LaneStates:
+    """(device, lane) -> dict(ws, isect, host, ev, ...): the cached scratch of a lane.
+
+    Lane 0 -- the blocking single-frame path behind render_gaussians and the differentiable frame -- is PER HOST
+    THREAD (round 3): every thread that renders gets its own workspace, intersection buffer, pinned size record and
+    event the first time it does, so host threads render concurrently on one device (their kernels interleave on
+    whatever streams they use; 288 GB of HBM make a ~100 MB scratch set per thread a non-issue) and a thread's frame
+    hints -- the previous frame's size record, its learnt sorting mode -- are its own.  The scratch dies with the
+    thread.  Lanes >= 1 (multi-view batches, the asynchronous band path) are shared and driven by one thread at a
+    time by design (`_frame_lock`)."""
+
+    def __init__(self):
+        self._shared = {}
+        self._tls = threading.local()
+
+    def _of(self, key):
+        if key[1] != 0:
+            return self._shared
+        d = getattr(self._tls, "d", None)
+        if d is None:
+            d = self._tls.d = {}
+        return d
+
+    def get(self, key, default=None):
+        return self._of(key).get(key, default)
+
+    def __getitem__(self, key):
+        return self._of(key)[key]
+
+    def __setitem__(self, key, value):
+        self._of(key)[key] = value
+
+    def __contains__(self, key):
+        return key in self._of(key)
+
+    def clear(self):
+        """Forget the shared lanes and the CALLING thread's lane 0 (tests start from no scratch this way)."""
+        self._shared.clear()
+        d = getattr(self._tls, "d", None)
+        if d is not None:
+            d.clear()
+
+
+_state = _LaneStates()
+# The shared lanes' scratch is one-frame-at-a-time: whole calls on them (multi-view batches) take this lock.
 _frame_lock = threading.RLock()
 
 
@@ -286,6 +327,9 @@ def render_fwd_hip(means3d, scales, quats, opacities, colors, camera, background
     `lane` selects an independent set of scratch buffers (frames in flight at the same time each
     need their own).  `info`: optional dict, receives `on_grid` = number of Gaussians touching the
     FULL tile grid (band-independent)."""
+    if lane == 0:   # the calling thread's own scratch: no lock
+        return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
+                      stage_events, row_range, out, lane, rows16=rows16, out_y0=out_y0).finish(WHOLE, info)
     with _frame_lock:
         return _Frame(means3d, scales, quats, opacities, colors, camera, background, tile_size,
                       stage_events, row_range, out, lane, rows16=rows16, out_y0=out_y0).finish(WHOLE, info)

@@ -132,6 +132,41 @@ def test_lean_frames_on_wide_grids_and_small_tiles(device):
             assert torch.equal(img, ref), (n, W, H, ell, ts, k)
 
 
+def test_host_threads_render_concurrently_on_their_own_scratch(device):
+    """Lane 0 is per host thread: four threads render four different scenes (different sizes and image shapes, so that
+    shared scratch would be torn apart) frame after frame at the same time; every frame of every thread equals that
+    scene's per-stage frame bit for bit, and each thread ends up with scratch of its own."""
+    import threading
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    jobs = []
+    for k, (n, W, H, ell) in enumerate(((30_000, 640, 360, -3.0), (8_000, 320, 200, -2.5), (60_000, 800, 448, -3.5),
+                                          (2_000, 256, 256, -2.0))):
+        sc, cam = randscene_v1(n, W, H, ell=ell, seed=30 + k, device=device)
+        jobs.append((sc, cam, stagewise(sc, cam, bg, 16)))
+    torch.cuda.synchronize()
+    errors, scratch = [], []
+
+    def work(sc, cam, ref):
+        try:
+            g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+            for i in range(25):
+                img = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+                if not torch.equal(img, ref):
+                    errors.append(f"frame {i} of a {g[0].shape[0]}-Gaussian scene differs")
+                    return
+            scratch.append(_fused._dev_state(g[0].device, 0)["ws"].data_ptr())
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert len(set(scratch)) == len(jobs), "threads shared a workspace"
+
+
 def test_split_frames_on_bands_that_cut_through_bin_rows(device):
     """Bands of >= 16 tile rows are split frames (32-px bins cut into block lists) even when they start
     or end in the middle of a bin row: the bins of that row are binned whole, only the band's blocks are
