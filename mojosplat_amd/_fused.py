@@ -104,7 +104,10 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 #   light_bet_lost    ... because a frame that bet on "no heavy tile" (short sorts only) had one
 #   other_miss        ... any other reason (a tile class that was not launched, an empty frame)
 #   buffer_grown      frames that had to grow the intersection buffer (a subset of overflow / first frames)
-#   redo_tiles        tiles the clean-up pass redid (reported one frame late by the library; exact-path frames excluded)
+#   redo_tiles        tiles the clean-up pass redid because their sorted front was too short (reported one frame late by
+#                     the library; exact-path frames excluded)
+#   cut_redo_tiles    ... because their depth cut-off was: their dropped pairs were regenerated (likewise)
+#   depth_cut         frames that dropped the pairs behind their bins' depth cut-offs
 #   front_level_up / full_sort_on   the lane's lazy-sorting mode escalated
 FRAME_STATS = None
 
@@ -129,7 +132,10 @@ def _count_frame(stats, frame, host, grew):
                 why = "other_miss"
             stats[why] = stats.get(why, 0) + 1
     if not flags & 4:
-        stats["redo_tiles"] = stats.get("redo_tiles", 0) + int(host[5])
+        stats["redo_tiles"] = stats.get("redo_tiles", 0) + (int(host[5]) & 0xffffffff)
+        stats["cut_redo_tiles"] = stats.get("cut_redo_tiles", 0) + (int(host[5]) >> 32)
+    if flags & 64:
+        stats["depth_cut"] = stats.get("depth_cut", 0) + 1
 
 
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
@@ -270,9 +276,10 @@ class _Frame:
             memo = st.setdefault("learnt", {})   # shape -> (full_sort, front_level): a lane that alternates between
             if not same_shape:                   # shapes (render.py's race between grids) does not learn them anew
                 st["full_sort"], st["front_level"] = memo.get(self.shape, (False, 0))
-            elif (rc == 0 and not (int(host[7]) & 4) and int(host[5]) > 0 and not st.get("full_sort")
+            # (low 32 bits: a bin redone because of its depth cut-off -- the high bits -- says nothing about the fronts)
+            elif (rc == 0 and not (int(host[7]) & 4) and (int(host[5]) & 0xffffffff) > 0 and not st.get("full_sort")
                   and st.get("prev_level") == st.get("front_level", 0)):
-                if int(host[5]) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
+                if (int(host[5]) & 0xffffffff) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
                     st["full_sort"] = True
                     if FRAME_STATS is not None:
                         FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1

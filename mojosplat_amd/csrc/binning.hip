@@ -518,13 +518,27 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     float *__restrict__ depths, int32_t *__restrict__ radii, uint32_t *__restrict__ hist,
     uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks,
     const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
-    LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth) {
-    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range)
+    LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth, const uint32_t *__restrict__ tau,
+    uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp) {
+    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes]
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
     MS_BIN_STAMP(0, 0);
+    // DEPTH CUT (tau != null; LEAN == 2 only): a pair whose depth bits exceed its tile's cut-off -- where the PREVIOUS
+    // frame's sorted front of that tile ended, with a margin -- is FAR: it is not counted into the tile's list, the tile
+    // is marked (has_far[tile] = the frame's stamp), and the scatter kernel never sees it: boxes of up to 32 tiles leave
+    // it the mask of their NEAR tiles (`masks`, one word per Gaussian) instead of the reach mask.  Should a pixel
+    // outlive a marked tile's list, the clean-up launch regenerates the tile's far pairs from the box records
+    // (rasterize.hip, k_far_regen).
+    uint32_t *s_tau = s_cnt + T_local + 4;
+    unsigned char *s_farflag = reinterpret_cast<unsigned char *>(s_tau + T_local);
+    uint32_t far_pairs = 0;
+    if constexpr (LEAN == 2) {
+        if (tau)
+            for (int t = threadIdx.x; t < T_local; t += kHistThreads) { s_tau[t] = tau[g.row_begin * g.tw + t]; s_farflag[t] = 0; }
+    }
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
-    if (threadIdx.x == 0) { s_on_grid = 0; s_cnt[T_local + 1] = 0xffffffffu; s_cnt[T_local + 2] = 0u; }
+    if (threadIdx.x == 0) { s_on_grid = 0; s_cnt[T_local + 1] = 0xffffffffu; s_cnt[T_local + 2] = 0u; s_cnt[T_local + 3] = 0u; }
     // lean frames: the range of the depth bits of everything this workgroup's Gaussians can emit, for k_tile_front's
     // buckets (the scatter kernel -- a chain of round trips -- otherwise ends with this reduction and its barriers)
     uint32_t dmin = 0xffffffffu, dmax = 0u;
@@ -544,6 +558,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0, gi = 0;
         bool on_grid = false;
         unsigned long long mask = ~0ull;
+        uint32_t dbits_of_step = 0u;   // (depth cut: this lane's depth bits)
         if (j < i1) {
             // A band's candidates: the INPUT arrays are gathered through the candidate list; everything this
             // kernel writes -- and every index the later stages see -- is the POSITION j in that list, so the
@@ -602,8 +617,10 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                         *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(masks + base) + 8u * (uint32_t)threadIdx.x) = mask;
                 }
             }
+            dbits_of_step = __float_as_uint(o.d);
             if constexpr (LEAN != 0) {
-                if (n > 0) { dmin = min(dmin, __float_as_uint(o.d)); dmax = max(dmax, __float_as_uint(o.d)); }
+                // (a depth-cut frame: only Gaussians that keep a pair stretch the range the sort kernel's buckets cover)
+                if (n > 0 && !(LEAN == 2 && tau)) { dmin = min(dmin, __float_as_uint(o.d)); dmax = max(dmax, __float_as_uint(o.d)); }
             }
             if constexpr (LEAN == 2) {
                 uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(reinterpret_cast<Lean12 *>(lean) + base) + 12u * (uint32_t)threadIdx.x);
@@ -615,7 +632,46 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                                                                 __float_as_uint(o.d), (uint32_t)n | ((uint32_t)edges << 28));
         }
         count_on_grid(on_grid, &s_on_grid);
-        walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
+        bool cut = false;
+        if constexpr (LEAN == 2) cut = tau != nullptr;
+        if (cut) {
+            // (only pairs that are kept stretch the depth range the sort kernel's buckets cover)
+            uint32_t near32 = 0u;
+            if (n > 0 && n <= kCoopThreshold) {   // this lane's own box: the reached tiles, bit by bit (as walk_boxes)
+                const int w = x1 - x0;
+                const float inv_w = __builtin_amdgcn_rcpf((float)w);
+                unsigned int m = (unsigned int)mask & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
+                while (m) {
+                    const int k = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const int r = (int)(((float)k + 0.5f) * inv_w);
+                    const int t = (y0 + r - g.row_begin) * g.tw + x0 + (k - r * w);
+                    if (dbits_of_step <= s_tau[t]) {
+                        atomicAdd(&s_cnt[t], 1u);
+                        near32 |= 1u << k;
+                    } else {
+                        ++far_pairs;
+                        s_farflag[t] = 1;
+                    }
+                }
+                if (near32) { dmin = min(dmin, dbits_of_step); dmax = max(dmax, dbits_of_step); }
+            }
+            // larger boxes: the whole wave (db is the OWNER's depth there); the scatter kernel applies the cut-offs itself
+            walk_boxes<PACK>(gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask, [&](int t, int64_t, int, uint32_t db) {
+                if (db <= s_tau[t]) { atomicAdd(&s_cnt[t], 1u); dmin = min(dmin, db); dmax = max(dmax, db); }
+                else { ++far_pairs; s_farflag[t] = 1; }
+            }, dbits_of_step);
+            if (j < i1) reinterpret_cast<uint32_t *>(masks)[j] = near32;
+        } else {
+            walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
+        }
+    }
+    if constexpr (LEAN == 2) {
+        if (tau) {   // this workgroup's far pairs (the frame's size record counts them: the buffer keeps room for them)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) far_pairs += (uint32_t)__shfl_xor((int)far_pairs, d);
+            if ((threadIdx.x & 63) == 0 && far_pairs) atomicAdd(&s_cnt[T_local + 3], far_pairs);
+        }
     }
     if constexpr (LEAN != 0) {
         if (wg_depth) {
@@ -636,6 +692,13 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
     if constexpr (LEAN != 0) {
         if (wg_depth && threadIdx.x == 0) { wg_depth[2 * blockIdx.x] = s_cnt[T_local + 1]; wg_depth[2 * blockIdx.x + 1] = s_cnt[T_local + 2]; }
+    }
+    if constexpr (LEAN == 2) {
+        if (tau) {
+            if (threadIdx.x == 0) wg_far[wg] = s_cnt[T_local + 3];
+            for (int t = threadIdx.x; t < T_local; t += kHistThreads)   // the tiles this workgroup dropped pairs of
+                if (s_farflag[t]) has_far[g.row_begin * g.tw + t] = cut_stamp;   // (every writer stores the same value)
+        }
     }
     MS_BIN_STAMP(0, 3);
 }
@@ -676,6 +739,12 @@ struct ScanTotalArgs {
     int64_t *info, *info_mirror;
     int32_t *order;
     uint32_t *ticket;   // k_tile_scan_wg: arrival counter of its workgroups (zeroed by the frame's count kernel)
+    // depth-cut frame (cut_stamp != 0): far pairs per count workgroup (G of them) for the size record; the cut-offs the
+    // scatter kernel holds the boxes of more than 32 tiles against
+    const uint32_t *wg_far;
+    const uint32_t *tau;
+    uint32_t cut_stamp;
+    uint32_t *far_zero;   // 2 T words the clean-up launches count the regenerated pairs in: zeroed by the total pass
 };
 
 // HANDOFF: the counts were written by other workgroups of the SAME launch (k_tile_scan_wg's last workgroup runs
@@ -814,8 +883,14 @@ __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
         info[2] = (int64_t)s_nmedium;
         info[3] = (int64_t)s_nlarge;
         info[4] = (int64_t)s_nxl;
-        info[5] = (int64_t)prev_redo;  // tiles the PREVIOUS frame on this workspace had to redo (lazy sorting)
-        *redo_count = 0;
+        // tiles the PREVIOUS frame on this workspace had to redo (lazy sorting): low 32 bits = because their sorted
+        // front was too short, high 32 bits = because their depth cut-off was (redo_count[1] counts those)
+        {
+            const int prev_cut = min(max(redo_count[1], 0), max(prev_redo, 0));
+            info[5] = (int64_t)(prev_redo - prev_cut) + ((int64_t)prev_cut << 32);
+        }
+        redo_count[0] = 0;
+        redo_count[1] = 0;
         info[6] = (int64_t)s_on_grid;  // Gaussians whose tile box touches the FULL grid (band-independent)
         info[7] = 0;
         if (info_mirror) {
@@ -1011,16 +1086,23 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
             A.order[atomicAdd(&s_base[bucket_of(A.tile_count[t])], 1u)] = band0 + t;
         return;
     }
-    __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid;
-    if (tid == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; }
+    if (A.far_zero)   // (depth-cut frame: the clean-up launches' per-tile counts and cursors; every tile of the grid)
+        for (int t = tid; t < 2 * A.g.tw * A.g.th; t += kHistThreads) A.far_zero[t] = 0u;
+    __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid, s_far;
+    if (tid == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; s_far = 0; }
     const int prev_redo = tid == 0 ? *A.redo_count : 0;
     unsigned int on_grid_part = tid < A.G ? A.wg_on_grid[tid] : 0u;   // G <= kMaxG <= blockDim
+    unsigned int far_part = (A.wg_far && tid < A.G) ? A.wg_far[tid] : 0u;   // depth-cut frame: the far log's length
     const unsigned long long grand = tile_prefix_lds(A.tile_count, T_local, s);   // (its barriers also publish the zeros above)
     if (tid == 0) s[T_local] = (uint32_t)min(grand, 0x7fffffffull);    // the end of the last tile (the LDS block's spare words)
     __syncthreads();
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) on_grid_part += (unsigned int)__shfl_xor((int)on_grid_part, d);
+    for (int d = 32; d > 0; d >>= 1) {
+        on_grid_part += (unsigned int)__shfl_xor((int)on_grid_part, d);
+        far_part += (unsigned int)__shfl_xor((int)far_part, d);
+    }
     if (lane == 0 && on_grid_part) atomicAdd(&s_on_grid, on_grid_part);
+    if (lane == 0 && far_part) atomicAdd(&s_far, far_part);
     unsigned int lmax = 0;
     for (int t = tid; t < T_local; t += kHistThreads) {
         const uint32_t b = s[t], e = s[t + 1], c = e - b;
@@ -1046,12 +1128,19 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
     if (lane == 0) atomicMax(&s_max, lmax);
     __syncthreads();
     if (tid == 0) {
-        int64_t rec[7] = {(int64_t)grand, (int64_t)s_max, (int64_t)s_nmedium, (int64_t)s_nlarge, (int64_t)s_nxl,
-                          (int64_t)prev_redo, (int64_t)s_on_grid};
+        // (a depth-cut frame reports ALL its pairs -- the lists' and the far log's: the buffer has to hold both -- and
+        // leaves the split in two device-only words behind the record for the clean-up pass)
+        const int prev_cut = min(max(A.redo_count[1], 0), max(prev_redo, 0));   // (see tile_scan_total)
+        int64_t rec[7] = {(int64_t)grand + (int64_t)s_far, (int64_t)s_max, (int64_t)s_nmedium, (int64_t)s_nlarge, (int64_t)s_nxl,
+                          (int64_t)(prev_redo - prev_cut) + ((int64_t)prev_cut << 32), (int64_t)s_on_grid};
 #pragma unroll
         for (int k = 0; k < 7; ++k) A.info[k] = rec[k];
         A.info[7] = 0;
-        *A.redo_count = 0;
+        A.info[8] = (int64_t)grand;
+        A.info[9] = (int64_t)s_far;
+        A.info[10] = 0;   // (the clean-up launch's cursor into the regenerated far pairs)
+        A.redo_count[0] = 0;
+        A.redo_count[1] = 0;
         if (A.info_mirror) {
 #pragma unroll
             for (int k = 0; k < 7; ++k) A.info_mirror[k] = rec[k];
@@ -1100,11 +1189,16 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     constexpr int kAhead = 2;
     LeanRec r_q[kAhead] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     unsigned long long m_q[kAhead] = {~0ull, ~0ull};
+    // depth-cut frame (A.cut_stamp; LEAN == 2 && DEFER only): the count kernel neither counted the pairs behind their
+    // tile's cut-off nor left them in the masks of boxes of up to 32 tiles (one word per Gaussian in `masks`: the NEAR
+    // tiles); larger boxes -- walked by the whole wave -- are held against the cut-offs here
+    bool cut = false;
+    if constexpr (LEAN == 2 && DEFER) cut = A.cut_stamp != 0u;
     // (LEAN == 2: a 12-byte record, unpacked into the same registers)
     auto load_rec = [&](int64_t j, LeanRec &r, unsigned long long &m) __attribute__((always_inline)) {
         if constexpr (LEAN == 2) {
             const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const Lean12 *>(lean) + j);
-            const uint32_t box = q[0], db = q[1], mk = q[2];
+            const uint32_t box = q[0], db = q[1], mk = cut ? reinterpret_cast<const uint32_t *>(masks)[j] : q[2];
             const uint32_t x0 = box & 0xffu, y0 = (box >> 8) & 0xffu, w = (box >> 16) & 0xffu, h = box >> 24;
             r.xy0 = x0 | (y0 << 16);
             r.xy1 = (x0 + w) | ((y0 + h) << 16);
@@ -1124,8 +1218,11 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
         }
     }
     MS_BIN_STAMP(2, 1);
+    uint32_t *s_tau = s_cur + T_local + 4;   // (depth-cut frame: the cut-offs, for the boxes the whole wave walks)
+    if (cut)
+        for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_tau[t] = A.tau[band0 + t];
     if constexpr (DEFER) {
-        (void)tile_prefix_lds(A.tile_count, T_local, s_cur, row);   // (its last barrier publishes the cursors)
+        (void)tile_prefix_lds(A.tile_count, T_local, s_cur, row);   // (its last barrier publishes the cursors, and a cut frame's cut-offs)
         MS_BIN_STAMP(2, 2);
     } else {
         for (int t = threadIdx.x; t < T_local; t += kHistThreads)
@@ -1151,16 +1248,23 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
                 edges = (int)(r.n_edges >> 28);
                 x0 = (int)(r.xy0 & 0xffffu); y0 = (int)(r.xy0 >> 16);
                 x1 = (int)(r.xy1 & 0xffffu); y1 = (int)(r.xy1 >> 16);
-                if (masks && (n > 1 || (PACK && n > 0))) mask = mk;
+                if (masks && (n > 1 || (PACK && n > 0) || cut)) mask = mk;
             }
             const uint32_t dbits = r.depth_bits;
             if (n > 0) { dmin = min(dmin, dbits); dmax = max(dmax, dbits); }
-            walk_boxes<PACK>((int)j, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t i, int q, uint32_t db) {
-                const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+            auto emit = [&](int t, int64_t i, int q, uint32_t db) __attribute__((always_inline)) {
                 const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
                 const uint64_t key = ((uint64_t)db << 32) | low;
+                const uint32_t slot = atomicAdd(&s_cur[t], 1u);
                 if ((int64_t)slot < M) keys[slot] = key;
-            }, dbits);
+            };
+            if (cut) {
+                walk_boxes<PACK>((int)j, x0, x1, y0, y1, n <= kCoopThreshold ? n : 0, edges, g, mask, emit, dbits);
+                walk_boxes<PACK>((int)j, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask,
+                                 [&](int t, int64_t i, int q, uint32_t db) { if (db <= s_tau[t]) emit(t, i, q, db); }, dbits);
+            } else {
+                walk_boxes<PACK>((int)j, x0, x1, y0, y1, n, edges, g, mask, emit, dbits);
+            }
         }
     } else {
         for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, cand, G, [&](int t, int64_t i, int q) {
@@ -1287,8 +1391,17 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
                                                      ms::BlockLists blocks, int bin_w,
                                                      const uint32_t *__restrict__ wg_depth, int n_wg,
                                                      const int32_t *__restrict__ order, int n_order, int front_cap,
-                                                     const uint32_t *__restrict__ n_big_dev) {
+                                                     const uint32_t *__restrict__ n_big_dev,
+                                                     uint32_t *__restrict__ tau, const uint32_t *__restrict__ tau_now,
+                                                     const uint32_t *__restrict__ has_far, uint32_t cut_stamp) {
     static_assert(!(SPLIT && MERGED), "block lists are cut by the two-launch path");
+    // DEPTH CUT-OFF of the NEXT frame (tau, merged launch only): a tile whose list was sorted whole keeps every pair next
+    // time (0xffffffff) -- unless this frame's list was itself cut short (the tile is marked) and sufficed: then this
+    // frame's cut-off (tau_now) stands; a heavy tile's cut-off is where its sorted front ended, plus a quarter of the
+    // front's depth span.  (A tile that outlives its list after all is reset by the clean-up launch.)
+    auto next_cut_whole = [&](int tile) {
+        if (tau) tau[tile] = (cut_stamp && has_far[tile] == cut_stamp) ? tau_now[tile] : 0xffffffffu;
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     uint64_t *s_out = reinterpret_cast<uint64_t *>(smem_dyn);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_out + front_cap);   // front_cap <= kFrontCap keys of LDS room
@@ -1314,6 +1427,7 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
                 if (n > 0 && n <= kLightCap && (int64_t)start + n <= cap)
                     sort_segment_lds<64, kLightCap / 64>(smem_dyn + (size_t)w * SortCfg<64, kLightCap / 64>::LDS, keys, start, n, tile,
                                                          flatten_ids, nullptr, nullptr);
+                if (lane == 0) next_cut_whole(tile);
             }
             return;
         }
@@ -1360,6 +1474,7 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
                 if (n > 0 && (int64_t)start + n <= cap)
                     sort_segment_lds<kFrontThreads, kSmallCap / kFrontThreads>(smem_dyn, keys, start, n, tile, flatten_ids,
                                                                                nullptr, nullptr);
+                if (tid == 0) next_cut_whole(tile);
                 __syncthreads();   // LDS is reused by the next list entry
 #ifdef MS_DIAG
                 if (g_diag_bin && tid == 0) {
@@ -1389,6 +1504,16 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
         else
             for (int i = tid; i < F; i += THREADS) flatten_ids[start + i] = (int32_t)(uint32_t)s_out[i];
         if (tid == 0) front_count[tile] = F;
+        if (MERGED && tid == 0 && tau) {
+            if (F >= n) next_cut_whole(tile);   // (the front is the whole list)
+            else {
+                const uint32_t edge = (uint32_t)s_sel[2];
+                const uint32_t base = wg_depth ? fixed_min : 0u;   // (the buckets' origin: the frame's nearest depth bits)
+                const uint32_t span = edge > base ? edge - base : 0u;
+                const unsigned long long cut = (unsigned long long)edge + (span >> 2) + 1ull;
+                tau[tile] = (uint32_t)(cut > 0xffffffffull ? 0xffffffffull : cut);
+            }
+        }
         __syncthreads();   // LDS is reused by the next list entry
 #ifdef MS_DIAG
         if (g_diag_bin && tid == 0) {
@@ -1476,7 +1601,7 @@ struct Plan {
     int T, T_local;
     size_t lds_bytes;
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
-        off_redo_list, off_redo_count, off_depth_wg, off_order, off_cand_count, off_cand, off_lean, total;
+        off_redo_list, off_redo_count, off_depth_wg, off_order, off_tau, off_has_far, off_wg_far, off_far_seg, off_cand_count, off_cand, off_lean, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -1505,6 +1630,11 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_redo_count = o; o += 256;
     p.off_depth_wg = o;   o += ms::align_up((size_t)kMaxG * 8, 256);   // per-workgroup depth-bit min / max (k_isect_scatter)
     p.off_order = o;      o += ms::align_up((size_t)p.T * 4, 256);     // the band's tiles, heaviest first (rasteriser launch order)
+    p.off_tau = o;        o += ms::align_up((size_t)p.T * 8, 256);     // depth cut: per tile, the depth bits behind which a pair is "far" -- two buffers of T words:
+                                                                       //   a frame reads the one the previous frame's sort kernel wrote and writes the other
+    p.off_has_far = o;    o += ms::align_up((size_t)p.T * 4, 256);     //   this frame's tiles that own far pairs
+    p.off_wg_far = o;     o += ms::align_up((size_t)kMaxG * 4, 256);   //   far pairs per count workgroup
+    p.off_far_seg = o;    o += ms::align_up((size_t)p.T * 12, 256);    //   clean-up: regenerated far pairs per tile -- count, cursor (zeroed by the frame's total pass), start
     // (the only N-dependent block comes last: everything above -- the clean-up count among it, which a caller
     // reads back one frame later -- stays where it is when the scene grows or shrinks on a fixed grid)
     p.off_cand_count = o; o += ms::align_up((size_t)kMaxG * 4, 256);   // band pre-cull: survivors per segment
@@ -1551,7 +1681,7 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
                int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream, bool defer_total = false) {
     ScanTotalArgs A{g, count, tile_ranges, medium, large, xl, wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag),
                     (int32_t *)(ws + p.off_redo_count), band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order),
-                    (uint32_t *)wg_on_grid + kMaxG};
+                    (uint32_t *)wg_on_grid + kMaxG, nullptr, nullptr, 0u, nullptr};
     if (defer_total && p.T_local > 0) {
         // the per-tile prefix over the partial rows alone: the total pass rides in the scatter launch (deferred_total)
         A.ticket = nullptr;
@@ -1635,6 +1765,25 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->row_lo = 0;
     out->row_hi = 0x7fffffff;
     out->redo_grid = 64;
+    out->cut_stamp = 0;   // (a depth-cut frame's caller sets the stamp, the cut-off buffers, the record's words and the log)
+    out->tau = (uint32_t *)(ws + p.off_tau);   // (buffer 0; buffer 1 follows T words on: the caller picks)
+    out->tau_next = nullptr;
+    out->has_far = (const uint32_t *)(ws + p.off_has_far);
+    out->lean = ws + p.off_lean;
+    out->n_lean = N;
+    out->cut_words = nullptr;
+    out->log_keys = nullptr;
+    out->far_cnt = (uint32_t *)(ws + p.off_far_seg);
+    out->far_cur = out->far_cnt + p.T;
+    out->far_start = out->far_cnt + 2 * (size_t)p.T;
+}
+
+// Can a frame on this grid take the depth cut (12-byte box records, room for the cut-offs in the count kernel's LDS)?
+bool ms::depth_cut_fits(int64_t N, int tile_w, int tile_h) {
+    Plan p;
+    if (!make_plan(N, tile_w, tile_h, 0, tile_h, p)) return false;
+    return kLean12Enabled && tile_w <= 255 && tile_h <= 255 && N > 0 && N < (1ll << 28) &&
+           p.lds_bytes + (size_t)p.T_local * 5 + 16 <= kMaxLds;
 }
 
 // The band's tiles, heaviest list first, as the count pass leaves them (order[0 .. band tiles), absolute tile ids).
@@ -1715,7 +1864,7 @@ extern "C" int ms_project_isect_count(int64_t N, const float *means3d, const flo
     return ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy, cx, cy, W, H,
                                    eps2d, near_plane, far_plane, radius_clip, tile_size, row_begin, row_end, tight & 63,
                                    means2d, conics, depths, radii, workspace, workspace_bytes, tile_ranges, isect_info,
-                                   isect_info_mirror, nullptr, 0, nullptr, stream_);
+                                   isect_info_mirror, nullptr, 0, nullptr, stream_, 0u);
 }
 
 int ms::project_isect_count(int64_t N, const float *means3d, const float *scales, int scales_are_log,
@@ -1726,7 +1875,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                             float *depths,
                             int32_t *radii, void *workspace, size_t workspace_bytes,
                             int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
-                            const void *colors3, int color_dtype, void *raster_records, void *stream_) {
+                            const void *colors3, int color_dtype, void *raster_records, void *stream_, uint32_t cut_stamp) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!opacities || !colors3) raster_records = nullptr;
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && fx != 0.f && fy != 0.f, MS_ERR_INVALID_ARG,
@@ -1777,12 +1926,20 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
         const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255 && kLean12Enabled;
         auto kernel = pack ? (lean ? k_project_hist<true, 1> : k_project_hist<true, 0>)
                            : (lean12 ? k_project_hist<false, 2> : lean ? k_project_hist<false, 1> : k_project_hist<false, 0>);
-        if (p.lds_bytes > 48 * 1024)
+        // depth-cut frame: per-tile cut-offs beside the counters (the sort kernel of the previous frame left them)
+        const bool cut = cut_stamp != 0u;   // (bit 9 of `tight`: which of the two cut-off buffers to read)
+        MS_REQUIRE(!cut || (lean12 && !(tight & kBandCull) && (tight & kDeferTotal)), MS_ERR_INVALID_ARG,
+                   "project_isect_count: a depth-cut frame must be a lean sync-free frame on plain bins");
+        const size_t lds = p.lds_bytes + (cut ? (size_t)p.T_local * 5 + 16 : 0);
+        MS_REQUIRE(lds <= kMaxLds, MS_ERR_TOO_LARGE, "project_isect_count: %d tiles with cut-offs need %zu B of LDS", p.T_local, lds);
+        if (lds > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
-        hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), p.lds_bytes, stream, N, means3d, scales,
+        hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), lds, stream, N, means3d, scales,
                            quats, opacities, viewmat, P, g, p.chunk, means2d, conics, depths, radii, hist, on_grid, masks,
                            colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand,
-                           (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg));
+                           (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg),
+                           cut ? (const uint32_t *)(ws + p.off_tau) + (size_t)((tight >> 9) & 1) * p.T : nullptr, (uint32_t *)(ws + p.off_wg_far),
+                           (uint32_t *)(ws + p.off_has_far), cut_stamp);
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
@@ -1799,6 +1956,11 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
               uint64_t *sort_keys, uint64_t *sort_tmp, int32_t *flatten_ids, int64_t *isect_ids,
               hipStream_t stream, const ms::BlockLists *blocks = nullptr, const ms::DeferredTotal *defer = nullptr) {
     const ms::BlockLists bl = blocks ? *blocks : ms::BlockLists{nullptr, nullptr, nullptr, 0, 0};
+    const uint32_t cut_stamp = defer ? defer->cut_stamp : 0u;   // != 0: a depth-cut frame (k_project_hist)
+    // bits 4-5 of `lazy` (ms_render_fwd only): the merged sort launch leaves the NEXT frame's cut-offs in buffer (lazy >> 4) & 1;
+    // a depth-cut frame reads its own from the other one
+    const int tau_out = (lazy >> 4) & 1;
+    const bool write_tau = (lazy & 32) != 0;
     Plan p;
     const bool fits = make_plan(N, tile_w, tile_h, row_begin, row_end, p);
     MS_REQUIRE(fits, MS_ERR_TOO_LARGE, "isect_emit: band too large for LDS");
@@ -1825,8 +1987,17 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             A = ScanTotalArgs{g, (const uint32_t *)(ws + p.off_count), const_cast<int32_t *>(tile_ranges), (int32_t *)(ws + p.off_medium),
                               (int32_t *)(ws + p.off_large), (int32_t *)(ws + p.off_xl), (const uint32_t *)(ws + p.off_on_grid), p.G,
                               (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count), defer->band_only,
-                              defer->info, defer->info_mirror, (int32_t *)(ws + p.off_order), nullptr};
+                              defer->info, defer->info_mirror, (int32_t *)(ws + p.off_order), nullptr,
+                              nullptr, nullptr, 0u, nullptr};
+            if (defer->cut_stamp) {
+                MS_REQUIRE(lean12 && !(tight & kBandCull) && lazy, MS_ERR_INVALID_ARG, "isect emit: a depth-cut frame must be a lean, lazily sorted frame on plain bins");
+                A.wg_far = (const uint32_t *)(ws + p.off_wg_far);
+                A.tau = (const uint32_t *)(ws + p.off_tau) + (size_t)(1 - tau_out) * p.T;
+                A.cut_stamp = defer->cut_stamp;
+                A.far_zero = (uint32_t *)(ws + p.off_far_seg);
+            }
         }
+        const size_t scatter_lds = p.lds_bytes + (A.cut_stamp ? (size_t)p.T_local * 4 + 16 : 0);
         auto pick = [&](auto packc, auto leanc) {
             constexpr bool PK = decltype(packc)::value;
             constexpr int LN = decltype(leanc)::value;
@@ -1835,9 +2006,9 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         auto kernel = pack ? (lean ? pick(std::true_type{}, I1{}) : pick(std::true_type{}, I0{}))
                            : (lean12 ? pick(std::false_type{}, I2{}) : lean ? pick(std::false_type{}, I1{}) : pick(std::false_type{}, I0{}));
-        if (p.lds_bytes > 48 * 1024)
+        if (scatter_lds > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
-        hipLaunchKernelGGL(kernel, dim3(p.G + (deferred ? 2 : 0)), dim3(kHistThreads), p.lds_bytes, stream, N, means2d, radii, depths, masks,
+        hipLaunchKernelGGL(kernel, dim3(p.G + (deferred ? 2 : 0)), dim3(kHistThreads), scatter_lds, stream, N, means2d, radii, depths, masks,
                            (const LeanRec *)(ws + p.off_lean), g, p.chunk, hist, tile_ranges, cap, sort_keys,
                            // (a lean frame's count kernel has left the per-workgroup depth ranges already)
                            lazy && !lean ? (uint32_t *)(ws + p.off_depth_wg) : nullptr,
@@ -1896,7 +2067,9 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                                sort_keys, flatten_ids, (int32_t *)(ws + p.off_front), cap, fixed_min, fixed_shift,
                                front_k, bl, tile_w, (const uint32_t *)(ws + p.off_depth_wg), p.G,
                                (const int32_t *)(ws + p.off_order), p.T_local, front_cap,
-                               light ? (const uint32_t *)(ws + p.off_on_grid) + kMaxG + 1 : nullptr);
+                               light ? (const uint32_t *)(ws + p.off_on_grid) + kMaxG + 1 : nullptr,
+                               merged && write_tau ? (uint32_t *)(ws + p.off_tau) + (size_t)tau_out * p.T : nullptr,
+                               (const uint32_t *)(ws + p.off_tau) + (size_t)(1 - tau_out) * p.T, (const uint32_t *)(ws + p.off_has_far), cut_stamp);
             MS_LAUNCH_CHECK();
         }
         if (merged) return MS_OK;
@@ -1972,7 +2145,7 @@ extern "C" int ms_isect_tiles_emit(int64_t N, const float *means2d, const int32_
                MS_ERR_INVALID_ARG, "isect_emit: null pointer");
     MS_REQUIRE(n_xl == 0 || sort_tmp || lazy, MS_ERR_INVALID_ARG, "isect_emit: sort_tmp required (XL tiles)");
     MS_REQUIRE(!lazy || !isect_ids, MS_ERR_INVALID_ARG, "isect_emit: lazy lists carry no isect_ids");
-    return emit_impl(N, means2d, radii, depths, tight & 63, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+    return emit_impl(N, means2d, radii, depths, tight & 63, lazy & 15, depth_near, depth_far, tile_size, tile_w, tile_h,
                      row_begin, row_end, workspace, workspace_bytes, tile_ranges, host_info, nullptr, M, sort_keys, sort_tmp,
                      flatten_ids, isect_ids, (hipStream_t)stream_);
 }
@@ -1990,7 +2163,7 @@ extern "C" int ms_isect_tiles_emit_speculative(int64_t N, const float *means2d, 
     if (int rc = check_grid(tile_size, tile_w, tile_h, row_begin, row_end)) return rc;
     MS_REQUIRE(workspace && tile_ranges && means2d && radii && depths && sort_keys && flatten_ids,
                MS_ERR_INVALID_ARG, "isect_emit_speculative: null pointer");
-    return emit_impl(N, means2d, radii, depths, tight & 63, lazy, depth_near, depth_far, tile_size, tile_w, tile_h,
+    return emit_impl(N, means2d, radii, depths, tight & 63, lazy & 15, depth_near, depth_far, tile_size, tile_w, tile_h,
                      row_begin, row_end, workspace, workspace_bytes, tile_ranges, prev_info_host, isect_info_dev, capacity,
                      sort_keys, nullptr, flatten_ids, nullptr, (hipStream_t)stream_);
 }

@@ -84,7 +84,7 @@ int project_isect_count(int64_t N, const float *means3d, const float *scales, in
                         float radius_clip, int tile_size, int row_begin, int row_end, int tight, float *means2d,
                         float *conics, float *depths, int32_t *radii, void *workspace, size_t workspace_bytes,
                         int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
-                        const void *colors3, int color_dtype, void *raster_records, void *stream);
+                        const void *colors3, int color_dtype, void *raster_records, void *stream, uint32_t cut_stamp = 0);
 
 // Lazy sorting (binning.hip): tiles longer than front_threshold have only front_count[tile] sorted
 // entries; the rasteriser appends a tile to redo_list when pixels are still alive at the end of it.
@@ -101,8 +101,22 @@ struct LazyLists {
     int row_lo, row_hi;     // split frames: the band in 16-px block rows (the clean-up leaves other rows alone)
     int redo_grid;          // workgroups of the clean-up launch: 1 while recent frames needed none (an empty
                             // 64-workgroup launch costs 4.5 us, a one-workgroup one 2), 64 after a frame that did
+    // depth-cut frame (cut_stamp != 0): the tiles marked has_far[tile] == cut_stamp own pairs that were never written
+    // (depth bits > tau[tile]); the clean-up launches regenerate them for the tiles on the redo list from the frame's
+    // 12-byte box records (`lean`, n_lean of them) into the free tail of the key array behind the cut_words[0] entries
+    // of the lists, one segment per tile: far_cnt[tile] keys from far_start[tile] on (far_cur: the scatter's cursors).
+    uint32_t cut_stamp;
+    const uint32_t *tau;    // this frame's cut-offs (isect_lazy_arrays: buffer 0 of the two, T words each)
+    uint32_t *tau_next;     // the next frame's, as the sort launch left them: the clean-up launch resets the tiles it redoes
+    const uint32_t *has_far;
+    const void *lean;
+    int64_t n_lean;
+    int64_t *cut_words;     // the device record's words 8.. : near pairs, far pairs, log cursor
+    uint64_t *log_keys;     // == keys, writable
+    uint32_t *far_cnt, *far_cur, *far_start;
 };
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
+bool depth_cut_fits(int64_t N, int tile_w, int tile_h);
 // lazily sorted fronts: depth (entries) of a front, LDS room for it, depth buckets from the camera planes
 struct FrontParams {
     uint32_t fixed_min;
@@ -147,9 +161,13 @@ struct DeferredTotal {
     int band_only;
     int64_t *info, *info_mirror;
     void *sync_event;
+    uint32_t cut_stamp;   // != 0: a depth-cut frame; the value its tiles with dropped pairs are marked with (unique per frame)
 };
 // bits of the `tight` flags that only ms_render_fwd sets (the C entry points mask them off)
-constexpr int kTightLean = 64, kTightDeferTotal = 128;
+constexpr int kTightLean = 64, kTightDeferTotal = 128, kTightDepthCutBuf = 512;   // (bit 9: a depth-cut frame reads its cut-offs from buffer 1)
+// DEPTH CUT (sync-free lean frames on plain bins; binning.hip, k_project_hist): pairs behind their tile's cut-off
+// are counted but never written; a tile that outlives its list gets them back from the clean-up launch.
+// (project_isect_count: cut_stamp; the emit and the rasteriser: DeferredTotal::cut_stamp / LazyLists::cut_stamp)
 // binning.hip: ms_isect_tiles_emit_speculative / ms_isect_tiles_emit with the internal flag bits honoured
 int isect_emit_speculative(int64_t N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
                            int tile_w, int tile_h, int row_begin, int row_end, void *workspace, size_t workspace_bytes,

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "ms_common.hpp"
+#include <atomic>
 
 namespace {
 
@@ -80,6 +81,26 @@ static int ms_defer_enabled() {
     return v;
 }
 
+// MOJOSPLAT_DEPTH_CUT=0: never drop the pairs behind a bin's depth cut-off (binning.hip, k_project_hist); 2: take the
+// cut on every frame that can, however few pairs it holds (measurements, tests)
+static int ms_depth_cut_mode() {   // (read per frame: tests and measurements switch it inside one process)
+    const char *e = getenv("MOJOSPLAT_DEPTH_CUT");
+    return e ? atoi(e) : 1;
+}
+// pairs a frame must hold (by the previous frame's record) before the cut is worth its bookkeeping
+static int64_t ms_depth_cut_min_pairs() {
+    const char *e = getenv("MOJOSPLAT_DEPTH_CUT_MIN_PAIRS");
+    const long long n = e ? atoll(e) : -1;
+    return (int64_t)(n >= 0 ? n : 6000000ll);
+}
+static int ms_merged_sort_enabled() {   // (binning.hip reads the same variable)
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_MERGED_SORT");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+
 // MOJOSPLAT_SPLIT=0: bin on the rasteriser's own 16-px tiles instead of 32-px bins cut into block lists
 static int ms_split_enabled() {
     static const int v = [] {
@@ -125,7 +146,7 @@ static size_t split_isect_bytes(int64_t M) {
     return ms::align_up(m * 8, 256) + ms::align_up(m * 4, 256) + ms::align_up(m * 16, 256);
 }
 
-static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const float *scales, int scales_are_log,
+static int render_fwd_impl(int restart, int64_t N, const float *means3d, const float *scales, int scales_are_log,
                              const float *quats, const float *opacities, const void *colors,
                              int color_dtype, int CDIM, const float *viewmat, float fx, float fy,
                              float cx, float cy, int W, int H, float eps2d, float near_plane,
@@ -135,6 +156,9 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                              float *render_colors, float *render_alphas, int32_t *last_ids,
                              void **stage_events, void *sync_event, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    // restart: bit 0 = this frame again without the split, bit 1 = without the depth cut
+    int no_split = restart & 1;
+    const int no_cut = (restart >> 1) & 1;
     const int phase = resume & 0xff;
     MS_REQUIRE(phase >= MS_RENDER_WHOLE && phase <= MS_RENDER_FINISH, MS_ERR_INVALID_ARG, "render_fwd: bad phase %d",
                phase);
@@ -158,6 +182,14 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     const int r0 = tile_row_begin, r1 = tile_row_end;
     // (bit 4 of host_info[7]: this frame was restarted without the split, see below; its redo must agree)
     if (phase == MS_RENDER_RESUME && (host_info[7] & 16)) no_split = 1;
+    // (bit 6: the frame dropped the pairs behind its bins' depth cut-offs -- the exact path cannot finish such a frame:
+    // it starts over without the cut)
+    if (phase == MS_RENDER_RESUME && (host_info[7] & 64))
+        return render_fwd_impl(restart | 2, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
+                               fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, rows16 ? clip0 : tile_row_begin,
+                               rows16 ? clip1 : tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
+                               (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids, stage_events,
+                               sync_event, stream_);
     const WsLayout L = ws_layout(N, tw, th);
     MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_fwd: workspace %zu < %zu", workspace_bytes,
                L.total);
@@ -228,15 +260,38 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                                   : (isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0);
         const bool speculate = sync_event && isect_buf && cap > 0 && N > 0;   // (an empty set has null inputs: exact path, M = 0)
         const bool deferred = speculate && mirror && (split ? b1 > b0 : r1 > r0) && ms_defer_enabled();
-        const ms::DeferredTotal defer{1, info, (int64_t *)mirror, sync_event};
-        const int defer_bit = deferred ? ms::kTightDeferTotal : 0;
+        // the previous frame on this record (same scratch, same grid) had no tile beyond the small sort class:
+        // bet that this one has none either (bit 5 of host_info[7]; checked against the size record below)
+        const bool bet_light = !split && lazy && prev[0] > 0 && prev[2] + prev[3] + prev[4] == 0 && !(prev[7] & 4);
+        // DEPTH CUT-OFFS (binning.hip): the merged sort launch of a whole-grid sync-free frame leaves, per bin, the
+        // depth at which its sorted front ended (bits 7 / 8 of host_info[7]: left, and in which of two buffers); the
+        // next frame on this record -- a lean one on plain bins with enough pairs to matter -- counts the pairs
+        // behind them but never writes or sorts them (bit 6).  Whatever the cut-offs are, the frame is exact: a bin
+        // that outlives its list gets its dropped pairs back in the clean-up launches (rasterize.hip, k_far_regen).
+        const bool leaves_cutoffs = speculate && !split && lazy && !bet_light && r0 == 0 && r1 == th && ms_merged_sort_enabled() &&
+                                    ms_depth_cut_mode() != 0;
+        const int cut_in = (prev[7] & 128) ? (int)((prev[7] >> 8) & 1) : 0, cut_out = (prev[7] & 128) ? 1 - cut_in : 0;
+        // (bits 16-31: the grid those cut-offs belong to -- the record may have served another grid since; a frame whose
+        // predecessor had to regenerate the pairs of more than a handful of bins takes no cut: its cut-offs are fresh)
+        const int64_t cut_grid = (int64_t)((tw & 0xff) | ((th & 0xff) << 8)) << 16;
+        const int64_t prev_cut_redos = (prev[7] & 4) ? 0 : (prev[5] >> 32);
+        const bool cut = leaves_cutoffs && deferred && lean && !(cull & 32) && !no_cut && (prev[7] & 128) &&
+                         (prev[7] & (0xffffll << 16)) == cut_grid && prev_cut_redos <= (tw * th) / 64 + 4 &&
+                         (ms_depth_cut_mode() >= 2 || prev[0] >= ms_depth_cut_min_pairs()) && ms::depth_cut_fits(N, tw, th);
+        static std::atomic<uint32_t> cut_stamps{0};
+        uint32_t cut_stamp = 0;
+        if (cut)
+            while ((cut_stamp = ++cut_stamps) == 0u) {}
+        const ms::DeferredTotal defer{1, info, (int64_t *)mirror, sync_event, cut_stamp};
+        const int defer_bit = (deferred ? ms::kTightDeferTotal : 0) | (cut && cut_in ? ms::kTightDepthCutBuf : 0);
+        const int64_t cut_bits = (cut ? 64 : 0) | (leaves_cutoffs ? (128 | (cut_out << 8) | cut_grid) : 0);
         if (int rc = ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
                                              cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,
                                              split ? 32 : tile_size, split ? b0 : r0, split ? b1 : r1,
                                              /*tight | ranges for the band only (| block masks)=*/(split ? bin_flags : 1 | 2 | cull) | defer_bit,
                                              means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
                                              split ? bin_ranges : ranges, info, (int64_t *)mirror,
-                                             use_records ? colors : nullptr, color_dtype, records, stream))
+                                             use_records ? colors : nullptr, color_dtype, records, stream, cut_stamp))
             return rc;
         mark(1);
         host_info[7] = no_split ? 16 : 0;
@@ -269,16 +324,22 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                 host_info[7] = 1 | 8;
                 if (phase == MS_RENDER_BEGIN) return MS_OK;
             } else {
-            // the previous frame on this record (same scratch, same grid) had no tile beyond the small sort class:
-            // bet that this one has none either (bit 5 of host_info[7]; checked against the size record below)
-            const bool bet_light = lazy && prev[0] > 0 && prev[2] + prev[3] + prev[4] == 0 && !(prev[7] & 4);
             if (int rc = ms::isect_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                     ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
-                                                    /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy | (bet_light ? 8 : 0),
+                                                    /*tight=*/(opacities != nullptr ? 1 : 0) | cull,
+                                                    lazy | (bet_light ? 8 : 0) | (leaves_cutoffs ? 32 | (cut_out << 4) : 0),
                                                     near_plane, far_plane, keys, ids, deferred ? &defer : nullptr, stream))
                 return rc;
             mark(2);
             lazy_lists.keys = keys;
+            if (lazy) {
+                uint32_t *cutoffs = const_cast<uint32_t *>(lazy_lists.tau);   // (two buffers of tw * th words)
+                lazy_lists.tau_next = leaves_cutoffs ? cutoffs + (size_t)cut_out * tw * th : nullptr;
+                lazy_lists.tau = cutoffs + (size_t)cut_in * tw * th;
+                lazy_lists.cut_stamp = cut_stamp;
+                lazy_lists.cut_words = info + 8;
+                lazy_lists.log_keys = keys;
+            }
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
                                            render_colors, render_alphas, last_ids,
@@ -286,7 +347,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
                                            lazy && !bet_light ? &lazy_lists : nullptr,
                                            records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
-            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0);
+            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits;
             }
         }
         if (phase == MS_RENDER_BEGIN) return MS_OK;
@@ -311,6 +372,12 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
     } else {
         speculated = (host_info[7] & 1) != 0;  // a redo after growing the buffer: events were already marked
     }
+    if (host_info[7] & 64)   // a depth-cut frame that did not fit its buffer: the frame again, every pair written
+        return render_fwd_impl(restart | 2, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
+                               fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, rows16 ? clip0 : tile_row_begin,
+                               rows16 ? clip1 : tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
+                               (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids,
+                               speculated ? nullptr : stage_events, sync_event, stream_);
     const int64_t M = host_info[0], n_xl = host_info[4];
     MS_REQUIRE(M >= 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_fwd: %lld intersections do not fit int32",
                (long long)M);
@@ -324,7 +391,7 @@ static int render_fwd_impl(int no_split, int64_t N, const float *means3d, const 
         return MS_OK;
     }
     if (split && M > ms_split_max_entries())   // 4 M block-list slots would not fit int32: the frame again, on 16-px tiles
-        return render_fwd_impl(1, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
+        return render_fwd_impl(restart | 1, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
                                fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, tile_row_begin,
                                tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
                                (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids,

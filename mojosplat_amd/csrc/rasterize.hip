@@ -483,6 +483,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     }
 #endif
     int redo_tile = end < end_all ? tile : -1;  // wave-uniform; only heavy tiles of a lazily sorted frame
+    // (depth-cut frame: ... and tiles whose list is short of the pairs behind the tile's cut-off)
+    bool cut_short = false;
+    if (A.lazy.cut_stamp && redo_tile < 0 && A.lazy.has_far[tile] == A.lazy.cut_stamp) { redo_tile = tile; cut_short = true; }
     if (A.lazy.bin_more) {   // split frame: this block's list was cut from the front of its 32-px bin
         const int bin = (tile_y >> 1) * A.lazy.bin_w + (tile_x >> 1);
         if (A.lazy.bin_more[bin]) redo_tile = bin;
@@ -494,8 +497,10 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         if (alive) {
             // pixels outlived the sorted front: the clean-up kernel redoes the whole tile (and
             // overwrites what is stored below); once per tile, whichever wave gets there first
-            if (lane == 0 && atomicExch(&A.lazy.redo_flag[redo_tile], 1) == 0)
+            if (lane == 0 && atomicExch(&A.lazy.redo_flag[redo_tile], 1) == 0) {
                 A.lazy.redo_list[atomicAdd(A.lazy.redo_count, 1)] = redo_tile;
+                if (cut_short) atomicAdd(A.lazy.redo_count + 1, 1);   // (reported apart: the caller's front depth is not to blame)
+            }
         }
     }
 
@@ -574,6 +579,87 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_
 // list is exhausted.  Any list length, no scratch beyond LDS.  Slow and simple by design.
 constexpr int kRedoChunk = 1024, kRedoCap = 2048, kRedoNB = 2048;
 
+// Depth-cut frame (binning.hip, k_project_hist): the pairs behind a tile's cut-off were counted but never written.
+// When the rasteriser put tiles that own such pairs on the redo list, two launches -- between the rasteriser and
+// k_tile_redo, empty otherwise: every workgroup reads the redo count and leaves -- walk the frame's 12-byte box
+// records again: PASS 0 counts the dropped pairs of THOSE tiles (far_cnt), PASS 1 gives every such tile a segment of
+// the free tail of the key array behind the lists (far_start: a prefix over the redo list that every workgroup takes
+// for itself; the size record counted the dropped pairs, so the buffer has room for all of them) and writes the keys.
+// The same pairs the scatter kernel would have written: box, reach mask and depth bits are the record's.
+constexpr int kRegenThreads = 256, kRegenMaxTiles = 65536;
+template <int PASS>
+__global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, int tw, int n_tiles, int64_t cap) {
+    const int n_redo = min(*Z.redo_count, n_tiles);
+    if (n_redo <= 0) return;
+    __shared__ uint32_t s_bits[kRegenMaxTiles / 32];
+    __shared__ uint32_t s_wtot[kRegenThreads / 64];
+    __shared__ int s_any;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < kRegenMaxTiles / 32; i += kRegenThreads) s_bits[i] = 0u;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    auto marked = [&](int ri) {
+        const int tile = ri < n_redo ? Z.redo_list[ri] : -1;
+        return (tile >= 0 && tile < n_tiles && Z.has_far[tile] == Z.cut_stamp) ? tile : -1;
+    };
+    for (int ri = tid; ri < n_redo; ri += kRegenThreads) {
+        const int tile = marked(ri);
+        if (tile >= 0) {
+            atomicOr(&s_bits[tile >> 5], 1u << (tile & 31));
+            s_any = 1;
+        }
+    }
+    __syncthreads();
+    if (!s_any) return;
+    if constexpr (PASS == 1) {
+        // far_start[tile] = the dropped pairs of the marked tiles before it on the redo list (the same values in every workgroup)
+        uint32_t running = 0;
+        for (int base = 0; base < n_redo; base += kRegenThreads) {
+            const int tile = marked(base + tid);
+            const uint32_t c = tile >= 0 ? Z.far_cnt[tile] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) s_wtot[w] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int ww = 0; ww < kRegenThreads / 64; ++ww) {
+                if (ww < w) before += s_wtot[ww];
+                total += s_wtot[ww];
+            }
+            if (tile >= 0) Z.far_start[tile] = running + before + incl - c;
+            running += total;
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int64_t near = Z.cut_words[0];
+    const uint32_t *recs = reinterpret_cast<const uint32_t *>(Z.lean);
+    for (int64_t j = (int64_t)blockIdx.x * kRegenThreads + tid; j < Z.n_lean; j += (int64_t)gridDim.x * kRegenThreads) {
+        const uint32_t box = recs[3 * j], db = recs[3 * j + 1], mk = recs[3 * j + 2];
+        const int x0 = (int)(box & 0xffu), y0 = (int)((box >> 8) & 0xffu), bw = (int)((box >> 16) & 0xffu), bh = (int)(box >> 24);
+        const int n = bw * bh;
+        for (int r = 0, k = 0; r < bh; ++r) {
+            for (int c = 0; c < bw; ++c, ++k) {
+                if (n <= 32 && !((mk >> k) & 1u)) continue;   // (the count / scatter kernels' rule: walk_boxes)
+                const int tile = (y0 + r) * tw + x0 + c;
+                if (!((s_bits[tile >> 5] >> (tile & 31)) & 1u) || db <= Z.tau[tile]) continue;
+                if constexpr (PASS == 0) {
+                    atomicAdd(&Z.far_cnt[tile], 1u);
+                } else {
+                    const int64_t pos = near + (int64_t)Z.far_start[tile] + (int64_t)atomicAdd(&Z.far_cur[tile], 1u);
+                    if (pos < cap) Z.log_keys[pos] = ((uint64_t)db << 32) | (uint32_t)j;
+                }
+            }
+        }
+    }
+}
+
 template <int CP, typename ColorT>
 __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     __shared__ uint64_t s_key[kRedoCap];
@@ -597,6 +683,19 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
         const int start = min(A.tile_ranges[2 * tile], end_all);
         const int n = end_all - start;
         const uint64_t *kin = A.lazy.keys + start;
+        // depth-cut frame: the tile's dropped pairs are back in a segment behind the lists (k_far_regen, the launches
+        // before this one); every pass over "the tile's keys" below takes both
+        const bool far_tile = A.lazy.cut_stamp && A.lazy.has_far[tile] == A.lazy.cut_stamp;
+        const int64_t far_base = far_tile ? min((int64_t)A.lazy.cut_words[0] + (int64_t)A.lazy.far_start[tile], (int64_t)A.max_isects) : 0;
+        const int n_far = far_tile ? (int)min((int64_t)A.lazy.far_cnt[tile], (int64_t)A.max_isects - far_base) : 0;
+        const uint64_t *fkeys = A.lazy.keys + far_base;
+        auto each_key = [&](auto &&fn) __attribute__((always_inline)) {
+            for (int i = tid; i < n; i += 256) fn(kin[i]);
+            for (int i = tid; i < n_far; i += 256) fn(fkeys[i]);
+        };
+        // the next frame keeps every pair of a tile that outlived its front (k_tile_front, which ran before this
+        // launch, has just set the cut-off where that front ended)
+        if (A.lazy.tau_next && tid == 0) A.lazy.tau_next[tile] = 0xffffffffu;
         for (int sub = 0; sub < A.nsub; ++sub) {
             const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
             if (A.lazy.packed) {   // a bin at the edge of a band: only the block rows inside it (uniform)
@@ -627,10 +726,9 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                 for (;;) {
                     unsigned long long mn = ~0ull, mx = 0ull;
                     unsigned int cnt = 0;
-                    for (int i = tid; i < n; i += 256) {
-                        const unsigned long long k = kin[i];
+                    each_key([&](unsigned long long k) {
                         if (k >= wlo && k <= whi) { mn = k < mn ? k : mn; mx = k > mx ? k : mx; ++cnt; }
-                    }
+                    });
 #pragma unroll
                     for (int d = 32; d > 0; d >>= 1) {
                         const unsigned long long omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
@@ -656,10 +754,9 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                     const unsigned long long span = mx - mn;
                     const int bits = span ? 64 - __clzll((long long)span) : 0;
                     shift = max(0, bits - 11);
-                    for (int i = tid; i < n; i += 256) {
-                        const unsigned long long k = kin[i];
+                    each_key([&](unsigned long long k) {
                         if (k >= wlo && k <= whi) atomicAdd(&s_cnt[(unsigned int)((k - kmin) >> shift)], 1u);
-                    }
+                    });
                     __syncthreads();
                     // exclusive scan of 2048 counters: thread t owns buckets 8t .. 8t+7
                     unsigned int c[8], sum = 0;
@@ -701,13 +798,12 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                 }
                 if (none) break;
                 // gather + rank
-                for (int i = tid; i < n; i += 256) {
-                    const unsigned long long k = kin[i];
+                each_key([&](unsigned long long k) {
                     if (k >= wlo && k <= whi) {
                         const int b = (int)((k - kmin) >> shift);
                         if (b <= bstar) s_key[atomicAdd(&s_cnt[b], 1u)] = k;
                     }
-                }
+                });
                 __syncthreads();
                 unsigned long long kk[kRedoCap / 256];
                 int dest[kRedoCap / 256];
@@ -848,8 +944,14 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
         // lazily sorted frame: redo the (normally zero) tiles whose front did not saturate them
         // (measured by leaving it out: the launch costs the frame 2.4 us -- 0.1826 -> 0.1802 ms at config 3 -- although
         // rocprofv3 shows the empty kernel at 4.5 us)
-        if (A.lazy.front_count)
+        if (A.lazy.front_count) {
+            if (A.lazy.cut_stamp) {
+                const int n_tiles = A.tw * ((A.H + A.ts - 1) / A.ts);
+                hipLaunchKernelGGL(k_far_regen<0>, dim3(256), dim3(kRegenThreads), 0, stream, A.lazy, A.tw, n_tiles, (int64_t)A.max_isects);
+                hipLaunchKernelGGL(k_far_regen<1>, dim3(256), dim3(kRegenThreads), 0, stream, A.lazy, A.tw, n_tiles, (int64_t)A.max_isects);
+            }
             hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(redo_grid(A)), dim3(256), 0, stream, A);
+        }
     }
 }
 

@@ -259,7 +259,8 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
 // order-preserving buckets;  scan;  b* = first bucket whose inclusive prefix reaches front_k;  pass C: keys of buckets
 // <= b* go to LDS, rank themselves inside their bucket (as in sort_segment_lds) and drop into place.
 // -> F, the number of sorted keys left in s_out[0, F) (<= front_cap; possibly 0: >= front_cap entries at one depth).
-// Every thread of the (THREADS-thread) workgroup; s_cnt: kFrontNB words, s_red: 64 words, s_sel: 2 words of LDS.
+// Every thread of the (THREADS-thread) workgroup; s_cnt: kFrontNB words, s_red: 64 words, s_sel: 4 words of LDS
+// (s_sel[2] = the depth bits at which the selected front ends, for the depth cut-off of the next frame).
 constexpr int kFrontK = 1024;
 constexpr int kFrontCap = 4096;   // LDS room for selected keys (32 KB)
 constexpr int kFrontNB = 2048;    // buckets
@@ -358,6 +359,11 @@ __device__ __forceinline__ int front_select_lds(const uint64_t *__restrict__ kin
     }
     __syncthreads();
     const int bstar = s_sel[0], F = s_sel[1];
+    // (for the caller: the depth bits at which bucket b* ends, i.e. where this front ends -- s_sel[2] -- saturating)
+    if (tid == 0) {
+        const unsigned long long edge = (unsigned long long)kmin + (((unsigned long long)(bstar + 1)) << shift);
+        s_sel[2] = (int)(uint32_t)(edge > 0xffffffffull ? 0xffffffffull : edge);
+    }
     // C. select
     for (int i0 = 0; i0 < n; i0 += kLoads * THREADS) {
         uint64_t k[kLoads];
