@@ -519,17 +519,21 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks,
     const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
     LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth, const uint32_t *__restrict__ tau,
-    uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp) {
+    uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp, LeanRec *__restrict__ near_recs) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes]
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
     MS_BIN_STAMP(0, 0);
     // DEPTH CUT (tau != null; LEAN == 2 only): a pair whose depth bits exceed its tile's cut-off -- where the PREVIOUS
     // frame's sorted front of that tile ended, with a margin -- is FAR: it is not counted into the tile's list, the tile
-    // is marked (has_far[tile] = the frame's stamp), and the scatter kernel never sees it: boxes of up to 32 tiles leave
-    // it the mask of their NEAR tiles (`masks`, one word per Gaussian) instead of the reach mask.  Should a pixel
-    // outlive a marked tile's list, the clean-up launch regenerates the tile's far pairs from the box records
-    // (rasterize.hip, k_far_regen).
+    // is marked (has_far[tile] = the frame's stamp), and the scatter kernel never sees it: that kernel's time follows the
+    // number of RECORDS it walks, not of pairs (its scattered stores and LDS atomics cost per wave instruction, however
+    // few lanes are live), so the Gaussians that keep a pair at all leave it a record of their own -- box, depth bits,
+    // the mask of their NEAR tiles, their index -- compacted per workgroup (near_recs; wg_far[kMaxG + g] of them).
+    // Should a pixel outlive a marked tile's list, the clean-up launch regenerates the tile's far pairs from the box
+    // records every Gaussian still writes (rasterize.hip, k_far_regen).
+    __shared__ unsigned int s_near_n;
+    if (threadIdx.x == 0) s_near_n = 0;
     uint32_t *s_tau = s_cnt + T_local + 4;
     unsigned char *s_farflag = reinterpret_cast<unsigned char *>(s_tau + T_local);
     uint32_t far_pairs = 0;
@@ -661,7 +665,20 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 if (db <= s_tau[t]) { atomicAdd(&s_cnt[t], 1u); dmin = min(dmin, db); dmax = max(dmax, db); }
                 else { ++far_pairs; s_farflag[t] = 1; }
             }, dbits_of_step);
-            if (j < i1) reinterpret_cast<uint32_t *>(masks)[j] = near32;
+            // (boxes the whole wave walked: kept whatever the cut-offs say -- their owner does not know)
+            const bool keep = near32 != 0u || n > kCoopThreshold;
+            const unsigned long long kb = __ballot(keep);
+            if (kb) {
+                const int lane = threadIdx.x & 63;
+                unsigned int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_near_n, (unsigned int)__popcll(kb));
+                wbase = (unsigned int)__builtin_amdgcn_readfirstlane((int)wbase);
+                if (keep) {
+                    const unsigned int pos = wbase + (unsigned int)__popcll(kb & ((1ull << lane) - 1ull));
+                    const uint32_t box = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24);
+                    reinterpret_cast<uint4 *>(near_recs)[i0 + pos] = make_uint4(box, (uint32_t)gi, dbits_of_step, near32);
+                }
+            }
         } else {
             walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
         }
@@ -695,7 +712,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     }
     if constexpr (LEAN == 2) {
         if (tau) {
-            if (threadIdx.x == 0) wg_far[wg] = s_cnt[T_local + 3];
+            if (threadIdx.x == 0) { wg_far[wg] = s_cnt[T_local + 3]; wg_far[kMaxG + wg] = s_near_n; }
             for (int t = threadIdx.x; t < T_local; t += kHistThreads)   // the tiles this workgroup dropped pairs of
                 if (s_farflag[t]) has_far[g.row_begin * g.tw + t] = cut_stamp;   // (every writer stores the same value)
         }
@@ -744,6 +761,7 @@ struct ScanTotalArgs {
     const uint32_t *wg_far;
     const uint32_t *tau;
     uint32_t cut_stamp;
+    const LeanRec *near_recs;   // the records that keep a pair, compacted per count workgroup (wg_far[kMaxG + g] of them from g * chunk on)
     uint32_t *far_zero;   // 2 T words the clean-up launches count the regenerated pairs in: zeroed by the total pass
 };
 
@@ -1183,38 +1201,60 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
             stride = (int64_t)G * kHistThreads;
         }
     }
-    // The kernel is a chain of round trips (waves sat in s_waitcnt 71 % of their life), so everything the first TWO
-    // steps read -- all a workgroup has at 2 048 Gaussians per chunk -- is on its way before the cursors are set
-    // up: the records, and the reach masks (unconditionally: which boxes need theirs is only known from the record)
-    constexpr int kAhead = 2;
-    LeanRec r_q[kAhead] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    unsigned long long m_q[kAhead] = {~0ull, ~0ull};
-    // depth-cut frame (A.cut_stamp; LEAN == 2 && DEFER only): the count kernel neither counted the pairs behind their
-    // tile's cut-off nor left them in the masks of boxes of up to 32 tiles (one word per Gaussian in `masks`: the NEAR
-    // tiles); larger boxes -- walked by the whole wave -- are held against the cut-offs here
+    // The kernel is a chain of round trips (waves sat in s_waitcnt 71 % of their life), so everything the first
+    // kAhead steps read -- all a workgroup has at 2 048 Gaussians per chunk -- is on its way before the cursors are set
+    // up: the records, and the reach masks (unconditionally: which boxes need theirs is only known from the record).
+    // Larger chunks (N / kMaxG Gaussians: 12 steps at 6 M) go kAhead steps at a time, the next kAhead records loaded
+    // while these are walked: a wave cannot tell a record's arrival from the completion of the scattered key stores
+    // issued since (one counter, in order), so every wait for records also drains the stores -- once per kAhead steps
+    // instead of once per step (config 4: 131 -> 58 us).
+    constexpr int kAhead = 4;
+    LeanRec r_q[kAhead], r_nx[kAhead];
+    unsigned long long m_q[kAhead], m_nx[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) { r_q[k] = r_nx[k] = LeanRec{0u, 0u, 0u, 0u}; m_q[k] = m_nx[k] = ~0ull; }
+    // depth-cut frame (A.cut_stamp; LEAN == 2 && DEFER only): the count kernel did not count the pairs behind their
+    // tile's cut-off, and left the Gaussians that keep a pair records of their own, compacted per workgroup -- box, index,
+    // depth bits, the mask of the NEAR tiles of a box of up to 32 tiles; larger boxes, walked by the whole wave, are
+    // held against the cut-offs here.  This workgroup walks those records alone.
     bool cut = false;
     if constexpr (LEAN == 2 && DEFER) cut = A.cut_stamp != 0u;
-    // (LEAN == 2: a 12-byte record, unpacked into the same registers)
+    if (cut) i1 = i0 + (int64_t)A.wg_far[kMaxG + wg];
+    // (LEAN == 2: a 12-byte record, kept as its three words while it waits -- three registers a record in flight, not
+    // six: at 2 x kAhead records the kernel must stay within the 64 registers that let two workgroups share a CU --
+    // and unpacked into the 16-byte form when its turn comes)
     auto load_rec = [&](int64_t j, LeanRec &r, unsigned long long &m) __attribute__((always_inline)) {
         if constexpr (LEAN == 2) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const Lean12 *>(lean) + j);
-            const uint32_t box = q[0], db = q[1], mk = cut ? reinterpret_cast<const uint32_t *>(masks)[j] : q[2];
-            const uint32_t x0 = box & 0xffu, y0 = (box >> 8) & 0xffu, w = (box >> 16) & 0xffu, h = box >> 24;
-            r.xy0 = x0 | (y0 << 16);
-            r.xy1 = (x0 + w) | ((y0 + h) << 16);
-            r.depth_bits = db;
-            r.n_edges = w * h;
-            m = w * h > 32u ? ~0ull : (unsigned long long)mk;
+            if (cut) {
+                r = A.near_recs[j];   // box, Gaussian, depth bits, near mask
+            } else {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const Lean12 *>(lean) + j);
+                r.xy0 = q[0];
+                r.xy1 = (uint32_t)j;
+                r.depth_bits = q[1];
+                r.n_edges = q[2];
+            }
         } else {
             r = lean[j];
             if (masks) m = masks[j];
+        }
+    };
+    auto unpack_rec = [&](LeanRec &r, unsigned long long &m, int64_t &gauss) __attribute__((always_inline)) {
+        if constexpr (LEAN == 2) {
+            const uint32_t box = r.xy0, mk = r.n_edges;
+            gauss = (int64_t)r.xy1;   // (a depth-cut frame's compacted records: not the position)
+            const uint32_t x0 = box & 0xffu, y0 = (box >> 8) & 0xffu, w = (box >> 16) & 0xffu, h = box >> 24;
+            r.xy0 = x0 | (y0 << 16);
+            r.xy1 = (x0 + w) | ((y0 + h) << 16);
+            r.n_edges = w * h;
+            m = w * h > 32u ? ~0ull : (unsigned long long)mk;
         }
     };
     if constexpr (LEAN != 0) {
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) {
             const int64_t j = i0 + k * stride + threadIdx.x;
-            if (j < i1) load_rec(j, r_q[k], m_q[k]);
+            if (j < i1) load_rec(j, r_nx[k], m_nx[k]);
         }
     }
     MS_BIN_STAMP(2, 1);
@@ -1233,37 +1273,78 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     // emits: k_tile_front spreads its buckets over the frame's range
     uint32_t dmin = 0xffffffffu, dmax = 0u;
     if constexpr (LEAN != 0) {
-        for (int64_t base = i0; base < i1; base += stride) {
-            const LeanRec r = r_q[0];
-            const unsigned long long mk = m_q[0];
+        auto emit = [&](int t, int64_t i, int q, uint32_t db) __attribute__((always_inline)) {
+            const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
+            const uint64_t key = ((uint64_t)db << 32) | low;
+            const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+            if ((int64_t)slot < M) keys[slot] = key;
+        };
+        for (int64_t base = i0; base < i1; base += kAhead * stride) {
 #pragma unroll
-            for (int k = 0; k + 1 < kAhead; ++k) { r_q[k] = r_q[k + 1]; m_q[k] = m_q[k + 1]; }
-            const int64_t jn = base + kAhead * stride + threadIdx.x;
-            if (jn < i1) load_rec(jn, r_q[kAhead - 1], m_q[kAhead - 1]);
-            const int64_t j = base + threadIdx.x;
-            int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
-            unsigned long long mask = ~0ull;
-            if (j < i1) {
-                n = (int)(r.n_edges & 0x0fffffffu);
-                edges = (int)(r.n_edges >> 28);
-                x0 = (int)(r.xy0 & 0xffffu); y0 = (int)(r.xy0 >> 16);
-                x1 = (int)(r.xy1 & 0xffffu); y1 = (int)(r.xy1 >> 16);
-                if (masks && (n > 1 || (PACK && n > 0) || cut)) mask = mk;
+            for (int k = 0; k < kAhead; ++k) { r_q[k] = r_nx[k]; m_q[k] = m_nx[k]; }
+            if (base + kAhead * stride < i1) {   // (uniform)
+#pragma unroll
+                for (int k = 0; k < kAhead; ++k) {
+                    const int64_t jn = base + (kAhead + k) * stride + threadIdx.x;
+                    if (jn < i1) load_rec(jn, r_nx[k], m_nx[k]);
+                }
             }
-            const uint32_t dbits = r.depth_bits;
-            if (n > 0) { dmin = min(dmin, dbits); dmax = max(dmax, dbits); }
-            auto emit = [&](int t, int64_t i, int q, uint32_t db) __attribute__((always_inline)) {
-                const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
-                const uint64_t key = ((uint64_t)db << 32) | low;
-                const uint32_t slot = atomicAdd(&s_cur[t], 1u);
-                if ((int64_t)slot < M) keys[slot] = key;
-            };
-            if (cut) {
-                walk_boxes<PACK>((int)j, x0, x1, y0, y1, n <= kCoopThreshold ? n : 0, edges, g, mask, emit, dbits);
-                walk_boxes<PACK>((int)j, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask,
-                                 [&](int t, int64_t i, int q, uint32_t db) { if (db <= s_tau[t]) emit(t, i, q, db); }, dbits);
-            } else {
-                walk_boxes<PACK>((int)j, x0, x1, y0, y1, n, edges, g, mask, emit, dbits);
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                if (base + k * stride >= i1) break;   // (uniform)
+                LeanRec r = r_q[k];
+                unsigned long long mk = m_q[k];
+                const int64_t j = base + k * stride + threadIdx.x;
+                int64_t gi = j;   // the Gaussian (the list id): the position, unless the record names it
+                unpack_rec(r, mk, gi);
+                int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
+                unsigned long long mask = ~0ull;
+                if (j < i1) {
+                    n = (int)(r.n_edges & 0x0fffffffu);
+                    edges = (int)(r.n_edges >> 28);
+                    x0 = (int)(r.xy0 & 0xffffu); y0 = (int)(r.xy0 >> 16);
+                    x1 = (int)(r.xy1 & 0xffffu); y1 = (int)(r.xy1 >> 16);
+                    if (masks && (n > 1 || (PACK && n > 0) || cut)) mask = mk;
+                }
+                const uint32_t dbits = r.depth_bits;
+                if (n > 0) { dmin = min(dmin, dbits); dmax = max(dmax, dbits); }
+                if constexpr (!PACK) {
+                    // Boxes of up to 32 tiles, each lane its own -- FOUR pairs a pass: the cursor of a pair comes back
+                    // from LDS ~130 cycles after it is asked for, and a loop that asks, waits and stores pair by pair
+                    // spends its life in that wait (measured: the kernel's time followed the number of RECORDS, not of
+                    // pairs); four cursors in flight per wait, a quarter of the passes.
+                    const int w = x1 - x0;
+                    const float inv_w = __builtin_amdgcn_rcpf((float)max(w, 1));
+                    unsigned int m = (n > 0 && n <= kCoopThreshold) ? ((unsigned int)mask & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u))) : 0u;
+                    const uint64_t key = ((uint64_t)dbits << 32) | (uint32_t)gi;
+                    while (m) {
+                        int tt[4];
+                        bool vv[4];
+                        uint32_t slot[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            vv[u] = m != 0u;
+                            const int k = vv[u] ? __ffs((int)m) - 1 : 0;
+                            m &= m - 1u;   // (0 stays 0)
+                            const int r = (int)(((float)k + 0.5f) * inv_w);   // k / w, exact for k < 64
+                            tt[u] = (y0 + r - g.row_begin) * g.tw + x0 + (k - r * w);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (vv[u]) slot[u] = atomicAdd(&s_cur[tt[u]], 1u);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (vv[u] && (int64_t)slot[u] < M) keys[slot[u]] = key;
+                    }
+                    // larger boxes: the whole wave (a depth-cut frame holds them against the cut-offs here)
+                    if (cut)
+                        walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask,
+                                         [&](int t, int64_t i, int q, uint32_t db) { if (db <= s_tau[t]) emit(t, i, q, db); }, dbits);
+                    else
+                        walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask, emit, dbits);
+                } else {
+                    walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n, edges, g, mask, emit, dbits);
+                }
             }
         }
     } else {
@@ -1507,10 +1588,11 @@ __global__ __launch_bounds__(kFrontThreads, (MERGED ? MS_MERGED_WAVES : 1)) void
         if (MERGED && tid == 0 && tau) {
             if (F >= n) next_cut_whole(tile);   // (the front is the whole list)
             else {
+                // (the margin: 1/16 of an octave of depth -- 2^19 steps of the float's bits, +4.4 % -- beyond the bucket that
+                // completed the front; a margin taken from the front's own depth span is at the mercy of the list's
+                // nearest entry: one Gaussian at the camera's feet, in every bin of config 4, made it two octaves)
                 const uint32_t edge = (uint32_t)s_sel[2];
-                const uint32_t base = wg_depth ? fixed_min : 0u;   // (the buckets' origin: the frame's nearest depth bits)
-                const uint32_t span = edge > base ? edge - base : 0u;
-                const unsigned long long cut = (unsigned long long)edge + (span >> 2) + 1ull;
+                const unsigned long long cut = (unsigned long long)edge + (1ull << 19);
                 tau[tile] = (uint32_t)(cut > 0xffffffffull ? 0xffffffffull : cut);
             }
         }
@@ -1601,7 +1683,7 @@ struct Plan {
     int T, T_local;
     size_t lds_bytes;
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
-        off_redo_list, off_redo_count, off_depth_wg, off_order, off_tau, off_has_far, off_wg_far, off_far_seg, off_cand_count, off_cand, off_lean, total;
+        off_redo_list, off_redo_count, off_depth_wg, off_order, off_tau, off_has_far, off_wg_far, off_far_seg, off_cand_count, off_cand, off_lean, off_near, total;
 };
 
 bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
@@ -1633,7 +1715,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_tau = o;        o += ms::align_up((size_t)p.T * 8, 256);     // depth cut: per tile, the depth bits behind which a pair is "far" -- two buffers of T words:
                                                                        //   a frame reads the one the previous frame's sort kernel wrote and writes the other
     p.off_has_far = o;    o += ms::align_up((size_t)p.T * 4, 256);     //   this frame's tiles that own far pairs
-    p.off_wg_far = o;     o += ms::align_up((size_t)kMaxG * 4, 256);   //   far pairs per count workgroup
+    p.off_wg_far = o;     o += ms::align_up((size_t)kMaxG * 8, 256);   //   far pairs per count workgroup | records that keep a pair per count workgroup
     p.off_far_seg = o;    o += ms::align_up((size_t)p.T * 12, 256);    //   clean-up: regenerated far pairs per tile -- count, cursor (zeroed by the frame's total pass), start
     // (the only N-dependent block comes last: everything above -- the clean-up count among it, which a caller
     // reads back one frame later -- stays where it is when the scene grows or shrinks on a fixed grid)
@@ -1641,6 +1723,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
     p.off_cand = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 4, 256);  // band pre-cull: candidate list
     p.off_lean = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * sizeof(LeanRec), 256);  // lean frames: box + depth per position
+    p.off_near = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * sizeof(LeanRec), 256);  // depth-cut frames: the records that keep a pair, compacted per count workgroup
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -1681,7 +1764,7 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
                int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream, bool defer_total = false) {
     ScanTotalArgs A{g, count, tile_ranges, medium, large, xl, wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag),
                     (int32_t *)(ws + p.off_redo_count), band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order),
-                    (uint32_t *)wg_on_grid + kMaxG, nullptr, nullptr, 0u, nullptr};
+                    (uint32_t *)wg_on_grid + kMaxG, nullptr, nullptr, 0u, nullptr, nullptr};
     if (defer_total && p.T_local > 0) {
         // the per-tile prefix over the partial rows alone: the total pass rides in the scatter launch (deferred_total)
         A.ticket = nullptr;
@@ -1939,7 +2022,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                            colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand,
                            (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg),
                            cut ? (const uint32_t *)(ws + p.off_tau) + (size_t)((tight >> 9) & 1) * p.T : nullptr, (uint32_t *)(ws + p.off_wg_far),
-                           (uint32_t *)(ws + p.off_has_far), cut_stamp);
+                           (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near));
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
@@ -1988,13 +2071,14 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                               (int32_t *)(ws + p.off_large), (int32_t *)(ws + p.off_xl), (const uint32_t *)(ws + p.off_on_grid), p.G,
                               (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count), defer->band_only,
                               defer->info, defer->info_mirror, (int32_t *)(ws + p.off_order), nullptr,
-                              nullptr, nullptr, 0u, nullptr};
+                              nullptr, nullptr, 0u, nullptr, nullptr};
             if (defer->cut_stamp) {
                 MS_REQUIRE(lean12 && !(tight & kBandCull) && lazy, MS_ERR_INVALID_ARG, "isect emit: a depth-cut frame must be a lean, lazily sorted frame on plain bins");
                 A.wg_far = (const uint32_t *)(ws + p.off_wg_far);
                 A.tau = (const uint32_t *)(ws + p.off_tau) + (size_t)(1 - tau_out) * p.T;
                 A.cut_stamp = defer->cut_stamp;
                 A.far_zero = (uint32_t *)(ws + p.off_far_seg);
+                A.near_recs = (const LeanRec *)(ws + p.off_near);
             }
         }
         const size_t scatter_lds = p.lds_bytes + (A.cut_stamp ? (size_t)p.T_local * 4 + 16 : 0);

@@ -260,7 +260,8 @@ __device__ __forceinline__ void sort_segment_lds(unsigned char *smem, const uint
 // <= b* go to LDS, rank themselves inside their bucket (as in sort_segment_lds) and drop into place.
 // -> F, the number of sorted keys left in s_out[0, F) (<= front_cap; possibly 0: >= front_cap entries at one depth).
 // Every thread of the (THREADS-thread) workgroup; s_cnt: kFrontNB words, s_red: 64 words, s_sel: 4 words of LDS
-// (s_sel[2] = the depth bits at which the selected front ends, for the depth cut-off of the next frame).
+// (s_sel[2] / s_sel[3] = the depth bits at which the selected front ends / the list begins, for the depth cut-off of the
+// next frame).
 constexpr int kFrontK = 1024;
 constexpr int kFrontCap = 4096;   // LDS room for selected keys (32 KB)
 constexpr int kFrontNB = 2048;    // buckets
@@ -336,7 +337,7 @@ __device__ __forceinline__ int front_select_lds(const uint64_t *__restrict__ kin
     }
     __syncthreads();   // s_red reuse
     if (lane == 63) s_red[w] = incl;
-    if (tid == 0) { s_sel[0] = -1; s_sel[1] = 0; }
+    if (tid == 0) { s_sel[0] = -1; s_sel[1] = 0; s_sel[3] = 0; }
     __syncthreads();
     uint32_t run = incl - sum;
 #pragma unroll
@@ -354,15 +355,19 @@ __device__ __forceinline__ int front_select_lds(const uint64_t *__restrict__ kin
             if (i <= (uint32_t)front_cap) { s_sel[0] = kBpt * tid + j; s_sel[1] = (int)i; }
             else { s_sel[0] = kBpt * tid + j - 1; s_sel[1] = (int)e; }
         }
+        if (c[j] && e == 0u) s_sel[3] = kBpt * tid + j;   // the first bucket that holds anything (exactly one thread)
         s_cnt[kBpt * tid + j] = e;
         run = i;
     }
     __syncthreads();
     const int bstar = s_sel[0], F = s_sel[1];
-    // (for the caller: the depth bits at which bucket b* ends, i.e. where this front ends -- s_sel[2] -- saturating)
+    // (for the caller: the depth bits at which bucket b* ends, i.e. where this front ends -- s_sel[2], saturating -- and
+    // those at which the list's first occupied bucket begins -- s_sel[3])
     if (tid == 0) {
         const unsigned long long edge = (unsigned long long)kmin + (((unsigned long long)(bstar + 1)) << shift);
+        const unsigned long long first = (unsigned long long)kmin + (((unsigned long long)s_sel[3]) << shift);
         s_sel[2] = (int)(uint32_t)(edge > 0xffffffffull ? 0xffffffffull : edge);
+        s_sel[3] = (int)(uint32_t)(first > 0xffffffffull ? 0xffffffffull : first);
     }
     // C. select
     for (int i0 = 0; i0 < n; i0 += kLoads * THREADS) {

@@ -19,7 +19,8 @@ import mojosplat_amd as ms  # noqa: E402
 from mojosplat_amd import _hip  # noqa: E402
 from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1  # noqa: E402
 
-CFG = {"cfg2": (100_000, 1920, 1080, -4.0), "cfg3": (1_000_000, 1920, 1080, -4.0), "cfg5": (5_000_000, 3840, 2160, -4.0)}
+CFG = {"cfg2": (100_000, 1920, 1080, -4.0), "cfg3": (1_000_000, 1920, 1080, -4.0), "cfg4": (6_000_000, 1600, 1063, -4.0),
+       "cfg5": (5_000_000, 3840, 2160, -4.0)}
 NAMES = {0: ("k_project_hist", ["loop", "barrier", "row out"]),
          1: ("k_tile_scan_wg", ["loads + wave scan", "barrier", "combine + stores"]),
          2: ("k_isect_scatter", ["prefetch issue", "tile prefix", "walk + stores", "last wave"])}

@@ -55,3 +55,20 @@ for label, seq in seqs.items():
     worst = max(float((a - b).abs().max()) for a, b in zip(ref, got))
     print(json.dumps({"config": name, "bin_px": px, "sequence": label, "frames": len(seq), "all_equal": all(same), "equal": same,
                       "max_abs_diff": worst, "stats_cut": st, "stats_uncut": {k: st0[k] for k in ("frames", "redo_tiles") if k in st0}}))
+
+# the split of the last depth-cut frame's pairs (device words 8 / 9 of the size record: near, far)
+import ctypes
+from mojosplat_amd import _hip
+os.environ["MOJOSPLAT_DEPTH_CUT"] = "2"
+_fused._state.clear()
+for _ in range(4):
+    ms.render_gaussians(*g(sc), cam, backend="hip", bin_size=px)
+torch.cuda.synchronize()
+st = _fused._dev_state(dev, 0)
+bpx = px or 32
+tw, th = -(-W // bpx), -(-H // bpx)
+off = (ctypes.c_size_t * 6)()
+_hip.lib().ms_render_workspace_layout(N, tw, th, off)
+info_off = off[4] + ((tw * th * 8 + 255) // 256) * 256
+info = st["ws"][info_off:info_off + 96].view(torch.int64).cpu().tolist()
+print(json.dumps({"config": name, "bin_px": bpx, "pairs": info[0], "near": info[8], "far": info[9], "near_fraction": round(info[8] / max(1, info[0]), 3)}))
