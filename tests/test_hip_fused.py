@@ -604,3 +604,57 @@ def test_light_frame_bet_is_repaired_when_heavy_tiles_appear(device):
     # and the frame after it (its predecessor had heavy bins) does not bet
     b2 = ms.render_gaussians(*args(dense), cam, background_color=bg, bin_size=32)
     assert not (int(st["host_np"][7]) & 32) and torch.equal(b, b2)
+
+
+def _orbit(cam, angle):
+    import math
+    from mojosplat_amd.utils import Camera
+    c, s = math.cos(angle), math.sin(angle)
+    ry = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], device=cam.R.device)
+    return Camera(R=cam.R @ ry, T=cam.T, H=cam.H, W=cam.W, fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy)
+
+
+@pytest.mark.parametrize("N,W,H,ell,px", [(500_000, 1280, 720, -3.5, 32), (500_000, 1280, 720, -3.0, 64)])
+def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, px):
+    """Sync-free frames on plain bins drop the pairs behind the depth at which the previous frame's sorted front of
+    their bin ended (csrc/binning.hip, k_project_hist; forced here whatever the scene's size: MOJOSPLAT_DEPTH_CUT=2).
+    Bit for bit the uncut frames (MOJOSPLAT_DEPTH_CUT=0): on a still camera, along an orbit, and across a swap to a scene
+    whose near Gaussians have all but vanished -- stale cut-offs that leave bins short of pairs, which the clean-up
+    launches regenerate from the box records (rasterize.hip, k_far_regen) -- and back."""
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=device)   # (a scene whose sorted fronts saturate its pixels)
+    faint = dict(sc)
+    depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
+    faint["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.02, sc["opacities"])
+    sequences = {
+        "still": [(sc, cam)] * 5,
+        "orbit": [(sc, _orbit(cam, 0.004 * i)) for i in range(8)],
+        "swap": [(sc, cam)] * 3 + [(faint, cam)] * 3 + [(sc, cam)] * 2,
+    }
+
+    def run(mode, seq):
+        monkeypatch.setenv("MOJOSPLAT_DEPTH_CUT", mode)
+        _fused._state.clear()
+        _fused.FRAME_STATS = {}
+        try:
+            frames = [ms.render_gaussians(s["means3d"], s["scales"], s["quats"], s["opacities"], s["features"], c,
+                                          background_color=bg, bin_size=px).clone() for s, c in seq]
+            torch.cuda.synchronize()
+            return frames, dict(_fused.FRAME_STATS)
+        finally:
+            _fused.FRAME_STATS = None
+
+    for label, seq in sequences.items():
+        ref, st0 = run("0", seq)
+        got, st = run("2", seq)
+        # (the faint scene's fronts do not saturate its pixels either: the lane ends up on full sorts, which take no cut)
+        assert st0.get("depth_cut", 0) == 0 and st.get("depth_cut", 0) >= (len(seq) - 4 if label != "swap" else 1), (label, st)
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (label, k, float((a - b).abs().max()))
+        if label != "swap":
+            assert st.get("cut_redo_tiles", 0) == 0, (label, st)   # the cut-offs hold while the view changes slowly
+        else:
+            assert st.get("cut_redo_tiles", 0) > 0, st                # ... and the swap is what the fallback is for
+    # the first frame of a sequence is the per-stage path's (an uncut frame of the fused path is tested to be)
+    assert torch.equal(ref[0], stagewise(sc, cam, bg, 16))
+    _fused._state.clear()
