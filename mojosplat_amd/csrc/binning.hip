@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
 // LEAN (ms_render_fwd's plain 3-channel forward frames): nobody reads the projected arrays of such a frame -- the
 // rasteriser stages from the ready-made records, the scatter kernel wants the tile box and the depth -- so the
 // kernel stores one 16-byte LeanRec per position instead of means2d / conics / depths / radii (32 bytes).
-template <bool PACK, int LEAN>   // LEAN: 0 = the projected arrays, 1 = LeanRec + reach mask, 2 = Lean12 (plain bins)
+template <bool PACK, int LEAN, bool CUT = false>   // LEAN: 0 = the projected arrays, 1 = LeanRec + reach mask, 2 = Lean12 (plain bins); CUT: a depth-cut frame (LEAN == 2)
 __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ opacities, const float *__restrict__ viewmat,
@@ -537,10 +537,9 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     uint32_t *s_tau = s_cnt + T_local + 4;
     unsigned char *s_farflag = reinterpret_cast<unsigned char *>(s_tau + T_local);
     uint32_t far_pairs = 0;
-    if constexpr (LEAN == 2) {
-        if (tau)
-            for (int t = threadIdx.x; t < T_local; t += kHistThreads) { s_tau[t] = tau[g.row_begin * g.tw + t]; s_farflag[t] = 0; }
-    }
+    static_assert(!CUT || LEAN == 2, "depth-cut frames keep 12-byte box records");
+    if constexpr (CUT)
+        for (int t = threadIdx.x; t < T_local; t += kHistThreads) { s_tau[t] = tau[g.row_begin * g.tw + t]; s_farflag[t] = 0; }
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_cnt[t] = 0;
     if (threadIdx.x == 0) { s_on_grid = 0; s_cnt[T_local + 1] = 0xffffffffu; s_cnt[T_local + 2] = 0u; s_cnt[T_local + 3] = 0u; }
     // lean frames: the range of the depth bits of everything this workgroup's Gaussians can emit, for k_tile_front's
@@ -563,6 +562,33 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
         bool on_grid = false;
         unsigned long long mask = ~0ull;
         uint32_t dbits_of_step = 0u;   // (depth cut: this lane's depth bits)
+        // depth-cut frame: the rasteriser's record of a Gaussian is only written once it is known to keep a pair (48 of
+        // the ~120 bytes this kernel moves per Gaussian; the clean-up launch writes the record of a dropped Gaussian it
+        // brings back: rasterize.hip, k_far_regen) -- what it is made of waits in these
+        // (never a band's gathered candidates: such a frame reads its inputs at threadIdx.x of the step's slice)
+        bool rec_pending = false;
+        float rec_m0 = 0.f, rec_m1 = 0.f, rec_c0 = 0.f, rec_c1 = 0.f, rec_c2 = 0.f;
+        auto write_record = [&](int64_t b0, uint32_t rec_src, float m0, float m1, float c0, float c1, float c2) __attribute__((always_inline)) {
+            // the rasteriser's staged record, ready made (ms::RasterRecord, ms_common.hpp): three 16-byte
+            // words per visible Gaussian instead of seven scattered 4-12-byte gathers + arithmetic per
+            // (tile, Gaussian) pair.  Same expressions as the rasteriser's own staging: same bits.
+            const float *opac_b = opacities ? opacities + b0 : nullptr;
+            float col[3];
+            if (color_f16) {
+                const __half *c = reinterpret_cast<const __half *>(colors) + 3 * b0;
+                col[0] = __half2float(c[3 * rec_src]); col[1] = __half2float(c[3 * rec_src + 1]); col[2] = __half2float(c[3 * rec_src + 2]);
+            } else {
+                const float *c = reinterpret_cast<const float *>(colors) + 3 * b0;
+                const ms::F3 c3 = ms::ld_f32x3(c, rec_src);
+                col[0] = c3.x; col[1] = c3.y; col[2] = c3.z;
+            }
+            const ms::RasterRecord r = ms::make_raster_record(m0, m1, c0, c1, c2, ms::ld_f32(opac_b, rec_src, 1, 0), col[0], col[1], col[2]);
+            // (stores likewise: the step's slice of the output + a 32-bit byte offset)
+            char *rb = reinterpret_cast<char *>(rec + 3 * base) + 48u * (uint32_t)threadIdx.x;
+            *reinterpret_cast<float4 *>(rb) = r.a;
+            *reinterpret_cast<float4 *>(rb + 16) = r.b;
+            *reinterpret_cast<float4 *>(rb + 32) = r.c;
+        };
         if (j < i1) {
             // A band's candidates: the INPUT arrays are gathered through the candidate list; everything this
             // kernel writes -- and every index the later stages see -- is the POSITION j in that list, so the
@@ -587,24 +613,12 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
             }
             if (rec && o.r0 > 0 && o.r1 > 0) {
-                // the rasteriser's staged record, ready made (ms::RasterRecord, ms_common.hpp): three 16-byte
-                // words per visible Gaussian instead of seven scattered 4-12-byte gathers + arithmetic per
-                // (tile, Gaussian) pair.  Same expressions as the rasteriser's own staging: same bits.
-                float col[3];
-                if (color_f16) {
-                    const __half *c = reinterpret_cast<const __half *>(colors) + 3 * b0;
-                    col[0] = __half2float(c[3 * src]); col[1] = __half2float(c[3 * src + 1]); col[2] = __half2float(c[3 * src + 2]);
+                if constexpr (CUT) {
+                    rec_pending = true;
+                    rec_m0 = o.m0; rec_m1 = o.m1; rec_c0 = o.c0; rec_c1 = o.c1; rec_c2 = o.c2;
                 } else {
-                    const float *c = reinterpret_cast<const float *>(colors) + 3 * b0;
-                    const ms::F3 c3 = ms::ld_f32x3(c, src);
-                    col[0] = c3.x; col[1] = c3.y; col[2] = c3.z;
+                    write_record(b0, src, o.m0, o.m1, o.c0, o.c1, o.c2);
                 }
-                const ms::RasterRecord r = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), col[0], col[1], col[2]);
-                // (stores likewise: the step's slice of the output + a 32-bit byte offset)
-                char *rb = reinterpret_cast<char *>(rec + 3 * base) + 48u * (uint32_t)threadIdx.x;
-                *reinterpret_cast<float4 *>(rb) = r.a;
-                *reinterpret_cast<float4 *>(rb + 16) = r.b;
-                *reinterpret_cast<float4 *>(rb + 32) = r.c;
             }
             if (o.r0 > 0 && o.r1 > 0) {
                 on_grid = bin_box<PACK>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             dbits_of_step = __float_as_uint(o.d);
             if constexpr (LEAN != 0) {
                 // (a depth-cut frame: only Gaussians that keep a pair stretch the range the sort kernel's buckets cover)
-                if (n > 0 && !(LEAN == 2 && tau)) { dmin = min(dmin, __float_as_uint(o.d)); dmax = max(dmax, __float_as_uint(o.d)); }
+                if (n > 0 && !CUT) { dmin = min(dmin, __float_as_uint(o.d)); dmax = max(dmax, __float_as_uint(o.d)); }
             }
             if constexpr (LEAN == 2) {
                 uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(reinterpret_cast<Lean12 *>(lean) + base) + 12u * (uint32_t)threadIdx.x);
@@ -636,9 +650,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                                                                 __float_as_uint(o.d), (uint32_t)n | ((uint32_t)edges << 28));
         }
         count_on_grid(on_grid, &s_on_grid);
-        bool cut = false;
-        if constexpr (LEAN == 2) cut = tau != nullptr;
-        if (cut) {
+        if constexpr (CUT) {
             // (only pairs that are kept stretch the depth range the sort kernel's buckets cover)
             uint32_t near32 = 0u;
             if (n > 0 && n <= kCoopThreshold) {   // this lane's own box: the reached tiles, bit by bit (as walk_boxes)
@@ -667,6 +679,11 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             }, dbits_of_step);
             // (boxes the whole wave walked: kept whatever the cut-offs say -- their owner does not know)
             const bool keep = near32 != 0u || n > kCoopThreshold;
+#ifndef MS_K1_ALL_RECORDS
+            if (rec_pending && keep) write_record(base, (uint32_t)threadIdx.x, rec_m0, rec_m1, rec_c0, rec_c1, rec_c2);
+#else
+            if (rec_pending) write_record(base, (uint32_t)threadIdx.x, rec_m0, rec_m1, rec_c0, rec_c1, rec_c2);
+#endif
             const unsigned long long kb = __ballot(keep);
             if (kb) {
                 const int lane = threadIdx.x & 63;
@@ -683,8 +700,8 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
         }
     }
-    if constexpr (LEAN == 2) {
-        if (tau) {   // this workgroup's far pairs (the frame's size record counts them: the buffer keeps room for them)
+    if constexpr (CUT) {
+        {   // this workgroup's far pairs (the frame's size record counts them: the buffer keeps room for them)
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) far_pairs += (uint32_t)__shfl_xor((int)far_pairs, d);
             if ((threadIdx.x & 63) == 0 && far_pairs) atomicAdd(&s_cnt[T_local + 3], far_pairs);
@@ -710,8 +727,8 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     if constexpr (LEAN != 0) {
         if (wg_depth && threadIdx.x == 0) { wg_depth[2 * blockIdx.x] = s_cnt[T_local + 1]; wg_depth[2 * blockIdx.x + 1] = s_cnt[T_local + 2]; }
     }
-    if constexpr (LEAN == 2) {
-        if (tau) {
+    if constexpr (CUT) {
+        {
             if (threadIdx.x == 0) { wg_far[wg] = s_cnt[T_local + 3]; wg_far[kMaxG + wg] = s_near_n; }
             for (int t = threadIdx.x; t < T_local; t += kHistThreads)   // the tiles this workgroup dropped pairs of
                 if (s_farflag[t]) has_far[g.row_begin * g.tw + t] = cut_stamp;   // (every writer stores the same value)
@@ -1859,6 +1876,7 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->far_cnt = (uint32_t *)(ws + p.off_far_seg);
     out->far_cur = out->far_cnt + p.T;
     out->far_start = out->far_cnt + 2 * (size_t)p.T;
+    out->cut_inputs = nullptr;
 }
 
 // Can a frame on this grid take the depth cut (12-byte box records, room for the cut-offs in the count kernel's LDS)?
@@ -1867,6 +1885,142 @@ bool ms::depth_cut_fits(int64_t N, int tile_w, int tile_h) {
     if (!make_plan(N, tile_w, tile_h, 0, tile_h, p)) return false;
     return kLean12Enabled && tile_w <= 255 && tile_h <= 255 && N > 0 && N < (1ll << 28) &&
            p.lds_bytes + (size_t)p.T_local * 5 + 16 <= kMaxLds;
+}
+
+namespace {
+// Depth-cut frame (binning.hip, k_project_hist): the pairs behind a tile's cut-off were counted but never written.
+// When the rasteriser put tiles that own such pairs on the redo list, two launches -- between the rasteriser and
+// k_tile_redo, empty otherwise: every workgroup reads the redo count and leaves -- walk the frame's 12-byte box
+// records again: PASS 0 counts the dropped pairs of THOSE tiles (far_cnt), PASS 1 gives every such tile a segment of
+// the free tail of the key array behind the lists (far_start: a prefix over the redo list that every workgroup takes
+// for itself; the size record counted the dropped pairs, so the buffer has room for all of them) and writes the keys.
+// The same pairs the scatter kernel would have written: box, reach mask and depth bits are the record's.
+// PASS 1 also writes the rasteriser's record of every Gaussian it brings back that the count kernel kept none of
+// (a depth-cut frame's k_project_hist only writes the records of Gaussians that keep a pair): the same inputs through
+// the same functions in the same translation unit -- project_one, make_raster_record -- as that kernel.
+struct RegenProject {
+    const float *means3d, *scales, *quats, *opacities, *viewmat;
+    const void *colors;
+    int color_f16;
+    ms::ProjParams P;
+    float4 *rec;
+};
+constexpr int kRegenThreads = 256, kRegenMaxTiles = 65536;
+template <int PASS>
+__global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, int tw, int n_tiles, int64_t cap, RegenProject R) {
+    const int n_redo = min(*Z.redo_count, n_tiles);
+    if (n_redo <= 0) return;
+    __shared__ uint32_t s_bits[kRegenMaxTiles / 32];
+    __shared__ uint32_t s_wtot[kRegenThreads / 64];
+    __shared__ int s_any;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < kRegenMaxTiles / 32; i += kRegenThreads) s_bits[i] = 0u;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    auto marked = [&](int ri) {
+        const int tile = ri < n_redo ? Z.redo_list[ri] : -1;
+        return (tile >= 0 && tile < n_tiles && Z.has_far[tile] == Z.cut_stamp) ? tile : -1;
+    };
+    for (int ri = tid; ri < n_redo; ri += kRegenThreads) {
+        const int tile = marked(ri);
+        if (tile >= 0) {
+            atomicOr(&s_bits[tile >> 5], 1u << (tile & 31));
+            s_any = 1;
+        }
+    }
+    __syncthreads();
+    if (!s_any) return;
+    if constexpr (PASS == 1) {
+        // far_start[tile] = the dropped pairs of the marked tiles before it on the redo list (the same values in every workgroup)
+        uint32_t running = 0;
+        for (int base = 0; base < n_redo; base += kRegenThreads) {
+            const int tile = marked(base + tid);
+            const uint32_t c = tile >= 0 ? Z.far_cnt[tile] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) s_wtot[w] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int ww = 0; ww < kRegenThreads / 64; ++ww) {
+                if (ww < w) before += s_wtot[ww];
+                total += s_wtot[ww];
+            }
+            if (tile >= 0) Z.far_start[tile] = running + before + incl - c;
+            running += total;
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int64_t near = Z.cut_words[0];
+    const uint32_t *recs = reinterpret_cast<const uint32_t *>(Z.lean);
+    for (int64_t j = (int64_t)blockIdx.x * kRegenThreads + tid; j < Z.n_lean; j += (int64_t)gridDim.x * kRegenThreads) {
+        const uint32_t box = recs[3 * j], db = recs[3 * j + 1], mk = recs[3 * j + 2];
+        const int x0 = (int)(box & 0xffu), y0 = (int)((box >> 8) & 0xffu), bw = (int)((box >> 16) & 0xffu), bh = (int)(box >> 24);
+        const int n = bw * bh;
+        bool brought_back = false;
+        for (int r = 0, k = 0; r < bh; ++r) {
+            for (int c = 0; c < bw; ++c, ++k) {
+                if (n <= 32 && !((mk >> k) & 1u)) continue;   // (the count / scatter kernels' rule: walk_boxes)
+                const int tile = (y0 + r) * tw + x0 + c;
+                if (!((s_bits[tile >> 5] >> (tile & 31)) & 1u) || db <= Z.tau[tile]) continue;
+                if constexpr (PASS == 0) {
+                    atomicAdd(&Z.far_cnt[tile], 1u);
+                } else {
+                    const int64_t pos = near + (int64_t)Z.far_start[tile] + (int64_t)atomicAdd(&Z.far_cur[tile], 1u);
+                    if (pos < cap) Z.log_keys[pos] = ((uint64_t)db << 32) | (uint32_t)j;
+                    brought_back = true;
+                }
+            }
+        }
+        if constexpr (PASS == 1) {
+            if (brought_back && n <= kCoopThreshold && R.rec) {
+                // did the count kernel keep a pair of this Gaussian (then it wrote the record itself)?
+                bool kept = false;
+                for (int r = 0, k = 0; r < bh; ++r)
+                    for (int c = 0; c < bw; ++c, ++k)
+                        if (((mk >> k) & 1u) && db <= Z.tau[(y0 + r) * tw + x0 + c]) kept = true;
+                if (!kept) {
+                    const uint32_t src = (uint32_t)j;
+                    const ms::ProjOut o = ms::project_one<uint32_t>(src, R.means3d, R.scales, R.quats, R.opacities, R.viewmat, R.P);
+                    float col[3];
+                    if (R.color_f16) {
+                        const __half *cp = reinterpret_cast<const __half *>(R.colors);
+                        col[0] = __half2float(cp[3 * src]); col[1] = __half2float(cp[3 * src + 1]); col[2] = __half2float(cp[3 * src + 2]);
+                    } else {
+                        const ms::F3 c3 = ms::ld_f32x3(reinterpret_cast<const float *>(R.colors), src);
+                        col[0] = c3.x; col[1] = c3.y; col[2] = c3.z;
+                    }
+                    const ms::RasterRecord rr = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(R.opacities, src, 1, 0), col[0], col[1], col[2]);
+                    float4 *out = R.rec + 3 * j;
+                    out[0] = rr.a; out[1] = rr.b; out[2] = rr.c;
+                }
+            }
+        }
+    }
+}
+
+
+}  // namespace
+
+// The two launches (rasterize.hip runs them between a depth-cut frame's rasteriser and its clean-up kernel).
+int ms::far_regen(const ms::LazyLists &lazy, int tw, int n_tiles, int64_t cap, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MS_REQUIRE(lazy.cut_inputs && n_tiles <= kRegenMaxTiles, MS_ERR_INVALID_ARG, "far_regen: a depth-cut frame without its inputs");
+    const ms::CutInputs &I = *lazy.cut_inputs;
+    const RegenProject R{I.means3d, I.scales, I.quats, I.opacities, I.viewmat, I.colors, I.color_f16,
+                         ms::make_proj_params(I.fx, I.fy, I.cx, I.cy, I.W, I.H, I.eps2d, I.near_plane, I.far_plane, 0.0f, I.scales_are_log,
+                                              I.opacities != nullptr),
+                         (float4 *)I.records};
+    hipLaunchKernelGGL(k_far_regen<0>, dim3(256), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
+    hipLaunchKernelGGL(k_far_regen<1>, dim3(256), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
 }
 
 // The band's tiles, heaviest list first, as the count pass leaves them (order[0 .. band tiles), absolute tile ids).
@@ -2008,7 +2162,8 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
         const bool lean = (tight & kLean) && raster_records && masks && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
         const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255 && kLean12Enabled;
         auto kernel = pack ? (lean ? k_project_hist<true, 1> : k_project_hist<true, 0>)
-                           : (lean12 ? k_project_hist<false, 2> : lean ? k_project_hist<false, 1> : k_project_hist<false, 0>);
+                           : (lean12 ? (cut_stamp ? k_project_hist<false, 2, true> : k_project_hist<false, 2>)
+                                     : lean ? k_project_hist<false, 1> : k_project_hist<false, 0>);
         // depth-cut frame: per-tile cut-offs beside the counters (the sort kernel of the previous frame left them)
         const bool cut = cut_stamp != 0u;   // (bit 9 of `tight`: which of the two cut-off buffers to read)
         MS_REQUIRE(!cut || (lean12 && !(tight & kBandCull) && (tight & kDeferTotal)), MS_ERR_INVALID_ARG,

@@ -88,6 +88,17 @@ int project_isect_count(int64_t N, const float *means3d, const float *scales, in
 
 // Lazy sorting (binning.hip): tiles longer than front_threshold have only front_count[tile] sorted
 // entries; the rasteriser appends a tile to redo_list when pixels are still alive at the end of it.
+// what a depth-cut frame's clean-up launches need to bring a dropped Gaussian's record back (host-side: far_regen)
+struct CutInputs {
+    const float *means3d, *scales, *quats, *opacities, *viewmat;
+    const void *colors;
+    int color_f16;
+    float fx, fy, cx, cy;
+    int W, H;
+    float eps2d, near_plane, far_plane;
+    int scales_are_log;
+    void *records;
+};
 struct LazyLists {
     const int32_t *front_count;
     int32_t *redo_flag, *redo_list, *redo_count;
@@ -114,7 +125,9 @@ struct LazyLists {
     int64_t *cut_words;     // the device record's words 8.. : near pairs, far pairs, log cursor
     uint64_t *log_keys;     // == keys, writable
     uint32_t *far_cnt, *far_cur, *far_start;
+    const CutInputs *cut_inputs;   // (a HOST pointer, read when the clean-up launches are enqueued)
 };
+int far_regen(const LazyLists &lazy, int tw, int n_tiles, int64_t cap, void *stream);
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
 bool depth_cut_fits(int64_t N, int tile_w, int tile_h);
 // lazily sorted fronts: depth (entries) of a front, LDS room for it, depth buckets from the camera planes

@@ -579,87 +579,6 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_
 // list is exhausted.  Any list length, no scratch beyond LDS.  Slow and simple by design.
 constexpr int kRedoChunk = 1024, kRedoCap = 2048, kRedoNB = 2048;
 
-// Depth-cut frame (binning.hip, k_project_hist): the pairs behind a tile's cut-off were counted but never written.
-// When the rasteriser put tiles that own such pairs on the redo list, two launches -- between the rasteriser and
-// k_tile_redo, empty otherwise: every workgroup reads the redo count and leaves -- walk the frame's 12-byte box
-// records again: PASS 0 counts the dropped pairs of THOSE tiles (far_cnt), PASS 1 gives every such tile a segment of
-// the free tail of the key array behind the lists (far_start: a prefix over the redo list that every workgroup takes
-// for itself; the size record counted the dropped pairs, so the buffer has room for all of them) and writes the keys.
-// The same pairs the scatter kernel would have written: box, reach mask and depth bits are the record's.
-constexpr int kRegenThreads = 256, kRegenMaxTiles = 65536;
-template <int PASS>
-__global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, int tw, int n_tiles, int64_t cap) {
-    const int n_redo = min(*Z.redo_count, n_tiles);
-    if (n_redo <= 0) return;
-    __shared__ uint32_t s_bits[kRegenMaxTiles / 32];
-    __shared__ uint32_t s_wtot[kRegenThreads / 64];
-    __shared__ int s_any;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < kRegenMaxTiles / 32; i += kRegenThreads) s_bits[i] = 0u;
-    if (tid == 0) s_any = 0;
-    __syncthreads();
-    auto marked = [&](int ri) {
-        const int tile = ri < n_redo ? Z.redo_list[ri] : -1;
-        return (tile >= 0 && tile < n_tiles && Z.has_far[tile] == Z.cut_stamp) ? tile : -1;
-    };
-    for (int ri = tid; ri < n_redo; ri += kRegenThreads) {
-        const int tile = marked(ri);
-        if (tile >= 0) {
-            atomicOr(&s_bits[tile >> 5], 1u << (tile & 31));
-            s_any = 1;
-        }
-    }
-    __syncthreads();
-    if (!s_any) return;
-    if constexpr (PASS == 1) {
-        // far_start[tile] = the dropped pairs of the marked tiles before it on the redo list (the same values in every workgroup)
-        uint32_t running = 0;
-        for (int base = 0; base < n_redo; base += kRegenThreads) {
-            const int tile = marked(base + tid);
-            const uint32_t c = tile >= 0 ? Z.far_cnt[tile] : 0u;
-            uint32_t incl = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-                if (lane >= d) incl += o;
-            }
-            if (lane == 63) s_wtot[w] = incl;
-            __syncthreads();
-            uint32_t before = 0, total = 0;
-#pragma unroll
-            for (int ww = 0; ww < kRegenThreads / 64; ++ww) {
-                if (ww < w) before += s_wtot[ww];
-                total += s_wtot[ww];
-            }
-            if (tile >= 0) Z.far_start[tile] = running + before + incl - c;
-            running += total;
-            __syncthreads();
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    const int64_t near = Z.cut_words[0];
-    const uint32_t *recs = reinterpret_cast<const uint32_t *>(Z.lean);
-    for (int64_t j = (int64_t)blockIdx.x * kRegenThreads + tid; j < Z.n_lean; j += (int64_t)gridDim.x * kRegenThreads) {
-        const uint32_t box = recs[3 * j], db = recs[3 * j + 1], mk = recs[3 * j + 2];
-        const int x0 = (int)(box & 0xffu), y0 = (int)((box >> 8) & 0xffu), bw = (int)((box >> 16) & 0xffu), bh = (int)(box >> 24);
-        const int n = bw * bh;
-        for (int r = 0, k = 0; r < bh; ++r) {
-            for (int c = 0; c < bw; ++c, ++k) {
-                if (n <= 32 && !((mk >> k) & 1u)) continue;   // (the count / scatter kernels' rule: walk_boxes)
-                const int tile = (y0 + r) * tw + x0 + c;
-                if (!((s_bits[tile >> 5] >> (tile & 31)) & 1u) || db <= Z.tau[tile]) continue;
-                if constexpr (PASS == 0) {
-                    atomicAdd(&Z.far_cnt[tile], 1u);
-                } else {
-                    const int64_t pos = near + (int64_t)Z.far_start[tile] + (int64_t)atomicAdd(&Z.far_cur[tile], 1u);
-                    if (pos < cap) Z.log_keys[pos] = ((uint64_t)db << 32) | (uint32_t)j;
-                }
-            }
-        }
-    }
-}
-
 template <int CP, typename ColorT>
 __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     __shared__ uint64_t s_key[kRedoCap];
@@ -945,11 +864,8 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
         // (measured by leaving it out: the launch costs the frame 2.4 us -- 0.1826 -> 0.1802 ms at config 3 -- although
         // rocprofv3 shows the empty kernel at 4.5 us)
         if (A.lazy.front_count) {
-            if (A.lazy.cut_stamp) {
-                const int n_tiles = A.tw * ((A.H + A.ts - 1) / A.ts);
-                hipLaunchKernelGGL(k_far_regen<0>, dim3(256), dim3(kRegenThreads), 0, stream, A.lazy, A.tw, n_tiles, (int64_t)A.max_isects);
-                hipLaunchKernelGGL(k_far_regen<1>, dim3(256), dim3(kRegenThreads), 0, stream, A.lazy, A.tw, n_tiles, (int64_t)A.max_isects);
-            }
+            // (depth-cut frame: the pairs -- and records -- the redone bins are short of, first: binning.hip, k_far_regen)
+            if (A.lazy.cut_stamp) (void)ms::far_regen(A.lazy, A.tw, A.tw * ((A.H + A.ts - 1) / A.ts), (int64_t)A.max_isects, stream);
             hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(redo_grid(A)), dim3(256), 0, stream, A);
         }
     }
