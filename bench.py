@@ -584,7 +584,7 @@ def orbit_leg(ms, _fused, render_mod, g, cam, bg, stagewise, static_ms, frames=2
            "bin_rule_switches": int(switches),
            "misses": {k: int(stats.get(k, 0)) for k in ("frames", "speculated", "redone_exact", "overflow", "light_bet_lost",
                                                        "other_miss", "buffer_grown", "redo_tiles", "front_level_up",
-                                                       "full_sort_on")},
+                                                       "full_sort_on", "depth_cut", "cut_redo_tiles")},
            "sampled_frames": sorted(kept), "sampled_frames_bit_identical_to_stagewise": same}
     return out
 

@@ -28,7 +28,8 @@
  *     per-scene state.  What it does keep, process-wide and thread-safe: the thread-local
  *     error string, the environment switches it reads once (MOJOSPLAT_LAZY_SORT, MOJOSPLAT_SPLIT,
  *     MOJOSPLAT_SPLIT_MAX_ENTRIES, MOJOSPLAT_LEAN, MOJOSPLAT_DEFER_TOTAL and the measurement knobs listed in
- *     INTEGRATION.md) and a mutex-guarded table of the (device, kernel) pairs whose dynamic-LDS ceiling it has
+ *     INTEGRATION.md; MOJOSPLAT_DEPTH_CUT / MOJOSPLAT_DEPTH_CUT_MIN_PAIRS are read per frame: DEPTH CUT-OFFS below),
+ *     a counter that stamps depth-cut frames, and a mutex-guarded table of the (device, kernel) pairs whose dynamic-LDS ceiling it has
  *     already raised (hipFuncSetAttribute);
  *   - all pointers are DEVICE pointers unless a parameter says "host"; tensors are
  *     contiguous row-major with the layouts written next to each parameter;
@@ -309,6 +310,18 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  * the 48-byte records the count kernel leaves per Gaussian, its scatter kernel a 12-byte (tile box, depth bits, reach
  * mask) record; means2d / conics / depths / radii are only written for frames that are asked for render_alphas or
  * last_ids (what a backward needs), for other channel counts, or with MOJOSPLAT_LEAN=0 in the environment.
+ * DEPTH CUT-OFFS.  A lean sync-free frame over the whole grid of plain bins (tile_size 32 / 64, up to 255 bins a side)
+ * whose predecessor ON THE SAME host_info / workspace / grid was such a frame too, and held at least 6 M pairs
+ * (MOJOSPLAT_DEPTH_CUT_MIN_PAIRS), takes that predecessor's per-bin depth cut-offs -- the depth at which each bin's
+ * lazily sorted front ended, plus 1/16 octave -- and neither counts into the lists, scatters, sorts nor writes records
+ * for the (Gaussian, bin) pairs behind them: host_info[0] still counts every pair (the buffer keeps room for them),
+ * the lists hold the near ones.  The frame is exact whatever the cut-offs are: a bin whose pixels outlive its list
+ * gets its dropped pairs -- and their Gaussians' records -- back from the 12-byte box records in the clean-up
+ * launches, and its cut-off is lifted for the next frame.  host_info[5] of the next record reports such bins in its
+ * high 32 bits (the low 32: bins whose sorted FRONT was too short, as before); bits 6-8 and 16-31 of host_info[7]
+ * are the library's bookkeeping for it (this frame took the cut; it left cut-offs, in which of two buffers, for which
+ * grid).  MOJOSPLAT_DEPTH_CUT=0 in the environment (read per frame) switches it off, =2 takes the cut whatever the
+ * previous frame held.  A frame that fails its speculation is started over without the cut.
  * SPLIT FRAMES.  A plain forward frame (no render_alphas / last_ids, CDIM <= 4) at tile_size 16 over the
  * whole image or a band of >= 16 tile rows is binned on 32-px bins with block masks (see `tight`), and
  * the sort kernels cut every bin's sorted list into the lists of its four 16x16 blocks, which is what

@@ -519,7 +519,8 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     uint32_t *__restrict__ wg_on_grid, unsigned long long *__restrict__ masks,
     const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
     LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth, const uint32_t *__restrict__ tau,
-    uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp, LeanRec *__restrict__ near_recs) {
+    uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp, LeanRec *__restrict__ near_recs,
+    int keep_arrays) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes]
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
@@ -604,7 +605,11 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             const int64_t i = j;
             gi = (int)i;
             const ms::ProjOut o = ms::project_one<uint32_t>(src, means3d + 3 * b0, scales + 3 * b0, quats + 4 * b0, opac_b, viewmat, P);
-            if constexpr (LEAN == 0) {
+            // (a lean frame whose caller reads the projected arrays all the same -- a differentiable frame: its backward
+            // and its intermediates -- writes both: the scatter kernel then still walks 12-byte records)
+            bool arrays = LEAN == 0;
+            if constexpr (LEAN != 0) arrays = keep_arrays != 0;
+            if (arrays) {
                 reinterpret_cast<float2 *>(means2d)[i] = make_float2(o.m0, o.m1);
                 conics[3 * i] = o.c0;
                 conics[3 * i + 1] = o.c1;
@@ -2017,8 +2022,11 @@ int ms::far_regen(const ms::LazyLists &lazy, int tw, int n_tiles, int64_t cap, v
                          ms::make_proj_params(I.fx, I.fy, I.cx, I.cy, I.W, I.H, I.eps2d, I.near_plane, I.far_plane, 0.0f, I.scales_are_log,
                                               I.opacities != nullptr),
                          (float4 *)I.records};
-    hipLaunchKernelGGL(k_far_regen<0>, dim3(256), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
-    hipLaunchKernelGGL(k_far_regen<1>, dim3(256), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
+    // (empty launches on almost every frame: 16 workgroups while recent frames needed no clean-up at all -- an empty
+    // 256-workgroup launch costs the frame 4.7 us, a small one about 2.5 -- the whole chip after a frame that did)
+    const unsigned grid = lazy.redo_grid >= 64 ? 512u : 16u;
+    hipLaunchKernelGGL(k_far_regen<0>, dim3(grid), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
+    hipLaunchKernelGGL(k_far_regen<1>, dim3(grid), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -2177,7 +2185,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                            colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand,
                            (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg),
                            cut ? (const uint32_t *)(ws + p.off_tau) + (size_t)((tight >> 9) & 1) * p.T : nullptr, (uint32_t *)(ws + p.off_wg_far),
-                           (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near));
+                           (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near), (tight & ms::kTightKeepArrays) ? 1 : 0);
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,

@@ -177,7 +177,8 @@ struct DeferredTotal {
     uint32_t cut_stamp;   // != 0: a depth-cut frame; the value its tiles with dropped pairs are marked with (unique per frame)
 };
 // bits of the `tight` flags that only ms_render_fwd sets (the C entry points mask them off)
-constexpr int kTightLean = 64, kTightDeferTotal = 128, kTightDepthCutBuf = 512;   // (bit 9: a depth-cut frame reads its cut-offs from buffer 1)
+constexpr int kTightLean = 64, kTightDeferTotal = 128, kTightDepthCutBuf = 512, kTightKeepArrays = 1024;   // (bit 10: a lean frame writes the projected arrays too)
+//   // (bit 9: a depth-cut frame reads its cut-offs from buffer 1)
 // DEPTH CUT (sync-free lean frames on plain bins; binning.hip, k_project_hist): pairs behind their tile's cut-off
 // are counted but never written; a tile that outlives its list gets them back from the clean-up launch.
 // (project_isect_count: cut_stamp; the emit and the rasteriser: DeferredTotal::cut_stamp / LazyLists::cut_stamp)

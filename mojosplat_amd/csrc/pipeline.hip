@@ -72,6 +72,14 @@ static int ms_lean_enabled() {
     return v;
 }
 
+static int ms_lean_aux_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_LEAN_AUX");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+
 // MOJOSPLAT_DEFER_TOTAL=0: the scans' total pass as a pass of its own on sync-free frames too
 static int ms_defer_enabled() {
     static const int v = [] {
@@ -232,7 +240,10 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
     // band's candidate list, which index the workspace's dense projected arrays and records, not the caller's)
     // lean frame: nobody reads the projected arrays (the rasteriser and the clean-up pass stage from the records,
     // the scatter kernel from the 16-byte box + depth records the count kernel leaves instead)
-    const int lean = (use_records && !aux_frame && ((uintptr_t)records & 15) == 0 && ms_lean_enabled()) ? ms::kTightLean : 0;
+    // (a differentiable frame keeps its arrays -- the backward and the caller's intermediates read them -- and leaves the
+    // records for its scatter kernel as well: MOJOSPLAT_LEAN_AUX=0 switches that off)
+    const int lean = (use_records && ((uintptr_t)records & 15) == 0 && ms_lean_enabled() && (!aux_frame || ms_lean_aux_enabled()))
+                         ? ms::kTightLean | (aux_frame ? ms::kTightKeepArrays : 0) : 0;
     const int cull = ((use_records && !aux_frame && N >= 32768 && N < (1ll << 28) && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0) | lean;
     const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0) | cull;
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
