@@ -92,6 +92,10 @@ def _grow(st, key, nbytes, dev, slack=1.0):
         st[key] = buf
         if key == "ws":
             st["shape"] = None   # fresh memory: the clean-up count the next frame reports is garbage
+            if st.get("host_np") is not None:
+                # ... and so are the per-bin depth cut-offs the library keeps in it: the record must not vouch for them
+                # (bits 6-8 and 16-31 of its flag word; a frame that took them anyway would still be exact, only slow)
+                st["host_np"][7] = int(st["host_np"][7]) & 0x3f
     return buf
 
 

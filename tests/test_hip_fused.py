@@ -631,6 +631,9 @@ def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, 
         "orbit": [(sc, _orbit(cam, 0.004 * i)) for i in range(8)],
         "swap": [(sc, cam)] * 3 + [(faint, cam)] * 3 + [(sc, cam)] * 2,
     }
+    if px == 32:   # a larger scene on the same grid: the lane's scratch is reallocated, its cut-offs with it
+        big, _ = randscene_v1(N + N // 2, W, H, ell=ell, seed=43, device=device)
+        sequences["grow"] = [(sc, cam)] * 3 + [(big, cam)] * 4
 
     def run(mode, seq):
         monkeypatch.setenv("MOJOSPLAT_DEPTH_CUT", mode)
@@ -648,12 +651,12 @@ def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, 
         ref, st0 = run("0", seq)
         got, st = run("2", seq)
         # (the faint scene's fronts do not saturate its pixels either: the lane ends up on full sorts, which take no cut)
-        assert st0.get("depth_cut", 0) == 0 and st.get("depth_cut", 0) >= (len(seq) - 4 if label != "swap" else 1), (label, st)
+        assert st0.get("depth_cut", 0) == 0 and st.get("depth_cut", 0) >= (len(seq) - 4 if label in ("still", "orbit") else 1), (label, st)
         for k, (a, b) in enumerate(zip(ref, got)):
             assert torch.equal(a, b), (label, k, float((a - b).abs().max()))
-        if label != "swap":
+        if label in ("still", "orbit"):
             assert st.get("cut_redo_tiles", 0) == 0, (label, st)   # the cut-offs hold while the view changes slowly
-        else:
+        elif label == "swap":
             assert st.get("cut_redo_tiles", 0) > 0, st                # ... and the swap is what the fallback is for
     # the first frame of a sequence is the per-stage path's (an uncut frame of the fused path is tested to be)
     assert torch.equal(ref[0], stagewise(sc, cam, bg, 16))
