@@ -303,6 +303,8 @@ def main():
         img = render_gaussians_sharded(*g, cam, background_color=bg)    # blocking form of the same frame
     max_abs = float((img.float() - ref_img.float()).abs().max())
     verified = bool(torch.equal(img, ref_img))
+    # (bit 6 of the size record's flag word: the frame dropped the pairs behind its bins' depth cut-offs)
+    depth_cut = bool(world == 1 and (dev, 0) in _fused._state and int(_fused._state[(dev, 0)]["host_np"][7]) & 64)
     # the lists the timed kernel was given: the frame's tile (or block) ranges still sit in lane 0's workspace
     m_lists = None
     if world == 1:
@@ -496,6 +498,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearse else ""),
             "config": {"workload": f"{args.workload}: randscene-v1 N={N} {W}x{H} ell={ell} seed=42 forward",
+                       # (whether the timed frames dropped the pairs behind their bins' depth cut-offs: csrc/binning.hip,
+                       # k_project_hist<.., CUT>; from 6 M pairs per frame by default -- config 3 runs uncut)
+                       "depth_cut": depth_cut,
                        "gaussians": N, "intersections": M, "tiles": T, "tile_size": 16, "binning": binning,
                        "colour_dtype": "f16" if fp16 else "f32",
                        "parallelism": "single GPU" if world == 1 else f"{world} tile-row bands + RCCL all-gather" + (", gather of frame k overlapped with render of frame k+1" if mode["async"] else " (blocking)")},

@@ -661,3 +661,44 @@ def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, 
     # the first frame of a sequence is the per-stage path's (an uncut frame of the fused path is tested to be)
     assert torch.equal(ref[0], stagewise(sc, cam, bg, 16))
     _fused._state.clear()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed):
+    """Random scenes, image sizes, plain bin sizes, near / far planes and opacity scales, from a camera that drifts a
+    little every frame, with the depth cut forced on every frame that can take it: every frame equals the per-stage
+    path (fully sorted gsplat-exact lists) bit for bit -- whether its cut-offs held, bins got their pairs back from the
+    clean-up launches, or the lane gave up on lazily sorted fronts altogether."""
+    import math
+    from mojosplat_amd.utils import Camera
+    monkeypatch.setenv("MOJOSPLAT_DEPTH_CUT", "2")
+    g = torch.Generator().manual_seed(31000 + seed)
+    r = lambda lo, hi: lo + (hi - lo) * torch.rand(1, generator=g).item()
+    N = int(10 ** r(4.3, 5.6))
+    W, H = int(r(300, 1400)), int(r(200, 900))
+    px = [32, 64][seed % 2]
+    sc, cam = randscene_v1(N, W, H, ell=r(-4.2, -2.8), seed=900 + seed, device=device)
+    cam.near, cam.far = r(0.05, 2.0), r(8.0, 200.0)
+    sc["opacities"] = (sc["opacities"] * r(0.3, 1.0)).clamp(max=1.0)
+    bg = torch.tensor([r(0, 1), r(0, 1), r(0, 1)], device=device)
+    args = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    _fused._state.clear()
+    _fused.FRAME_STATS = {}
+    try:
+        for k in range(7):
+            a = 0.01 * k * (1 if seed % 3 else -1)
+            c, s = math.cos(a), math.sin(a)
+            ry = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], device=device)
+            cm = Camera(R=cam.R @ ry, T=cam.T + torch.tensor([0.0, 0.0, 0.02 * k], device=device), H=H, W=W, fx=cam.fx, fy=cam.fy,
+                        cx=cam.cx, cy=cam.cy, near=cam.near, far=cam.far)
+            got = ms.render_gaussians(*args, cm, background_color=bg, bin_size=px)
+            want = stagewise(sc, cm, bg, 16)
+            assert torch.equal(got, want), (seed, k, N, W, H, px, dict(_fused.FRAME_STATS), float((got - want).abs().max()))
+    finally:
+        LAST_CUT_FUZZ_STATS.clear()
+        LAST_CUT_FUZZ_STATS.update(_fused.FRAME_STATS or {})
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
+
+
+LAST_CUT_FUZZ_STATS = {}   # (scripts/fuzz_cut.py sums these up: how many frames took the cut, how many bins were regenerated)
