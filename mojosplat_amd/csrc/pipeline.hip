@@ -11,6 +11,33 @@
 #include "ms_common.hpp"
 #include <atomic>
 
+#ifdef MS_DIAG
+#include <chrono>
+#include <stdio.h>
+namespace {
+// MS_HOST_PROF=1 (diagnostic build): where the HOST time of ms_render_fwd's enqueueing half goes, printed every 1000 frames
+struct HostProf {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long frames = 0;
+    bool on = getenv("MS_HOST_PROF") != nullptr;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void frame_done() {
+        if (on && ++frames % 1000 == 0) {
+            fprintf(stderr, "[host prof] per frame, us: setup %.2f | mirror lookup %.2f | count launches %.2f | events %.2f | emit launches %.2f | raster launches %.2f | total %.2f\n",
+                    t[0] / 1000, t[1] / 1000, t[2] / 1000, t[3] / 1000, t[4] / 1000, t[5] / 1000, t[6] / 1000);
+            for (double &x : t) x = 0;
+        }
+    }
+};
+thread_local HostProf g_hp;
+}  // namespace
+#define MS_HP_T(var) const double var = g_hp.on ? HostProf::now() : 0.0
+#define MS_HP_ADD(slot, a, b) do { if (g_hp.on) g_hp.t[slot] += (b) - (a); } while (0)
+#else
+#define MS_HP_T(var) do {} while (0)
+#define MS_HP_ADD(slot, a, b) do {} while (0)
+#endif
+
 namespace {
 
 struct WsLayout {
@@ -164,6 +191,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                              float *render_colors, float *render_alphas, int32_t *last_ids,
                              void **stage_events, void *sync_event, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    MS_HP_T(hp_t0);
     // restart: bit 0 = this frame again without the split, bit 1 = without the depth cut
     int no_split = restart & 1;
     const int no_cut = (restart >> 1) & 1;
@@ -261,10 +289,14 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         // the size record reaches the host by a zero-copy store from the scan kernel when host_info
         // is mapped pinned memory (what the header asks for); else by a copy
         void *mirror = nullptr;
+        MS_HP_T(hp_t1);
+        MS_HP_ADD(0, hp_t0, hp_t1);
         if (hipHostGetDevicePointer(&mirror, host_info, 0) != hipSuccess) {
             (void)hipGetLastError();
             mirror = nullptr;
         }
+        MS_HP_T(hp_t2);
+        MS_HP_ADD(1, hp_t1, hp_t2);
         // Sync-free frame (see below) -- decided here because such a frame also DEFERS the scans' total pass into
         // its scatter launch (binning.hip, deferred_total): the size record then reaches the host behind that launch
         const int64_t cap = split ? (isect_bytes > 768 ? (int64_t)((isect_bytes - 768) / 28) : 0)
@@ -307,6 +339,8 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                                              use_records ? colors : nullptr, color_dtype, records, stream, cut_stamp))
             return rc;
         mark(1);
+        MS_HP_T(hp_t3);
+        MS_HP_ADD(2, hp_t2, hp_t3);
         host_info[7] = no_split ? 16 : 0;
         if (!mirror) MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         if (sync_event && !deferred) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));   // (deferred: behind the scatter launch)
@@ -315,6 +349,8 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         // then wait for the size record -- the GPU never idles on the hand-off.  Every kernel
         // clamps to `cap`, so an overflowing frame writes nothing out of bounds; it is detected
         // in the finishing half and redone on the exact path.
+        MS_HP_T(hp_t4);
+        MS_HP_ADD(3, hp_t3, hp_t4);
         if (speculate) {
             const int64_t cmax = split ? ms_split_max_entries() : 0x7fffffffll;
             const int64_t c = cap > cmax ? cmax : cap;
@@ -344,6 +380,8 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                                                     near_plane, far_plane, keys, ids, deferred ? &defer : nullptr, stream))
                 return rc;
             mark(2);
+            MS_HP_T(hp_t5);
+            MS_HP_ADD(4, hp_t4, hp_t5);
             lazy_lists.keys = keys;
             if (lazy) {
                 uint32_t *cutoffs = const_cast<uint32_t *>(lazy_lists.tau);   // (two buffers of tw * th words)
@@ -362,6 +400,14 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                                            records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits;
+#ifdef MS_DIAG
+            {
+                MS_HP_T(hp_t6);
+                MS_HP_ADD(5, hp_t5, hp_t6);
+                MS_HP_ADD(6, hp_t0, hp_t6);
+                g_hp.frame_done();
+            }
+#endif
             }
         }
         if (phase == MS_RENDER_BEGIN) return MS_OK;

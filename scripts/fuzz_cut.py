@@ -1,4 +1,5 @@
-"""More seeds of tests/test_hip_fused.py::test_depth_cut_fuzz_against_stagewise: python scripts/fuzz_cut.py [first] [count]"""
+"""More seeds of tests/test_hip_fused.py::test_depth_cut_fuzz_against_stagewise: python scripts/fuzz_cut.py [first] [count] [dense]
+(dense: 250 k - 1 M Gaussians at 1000-1920 x 600-1080, opaque enough for lazily sorted fronts: most frames take the cut)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,12 +9,13 @@ import test_hip_fused as T
 dev = torch.device("cuda", 0)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+dense = len(sys.argv) > 3 and sys.argv[3] == 'dense'
 bad = 0
 total = {}
 mp = pytest.MonkeyPatch()
 for seed in range(first, first + count):
     try:
-        T.test_depth_cut_fuzz_against_stagewise(dev, mp, seed)
+        T.test_depth_cut_fuzz_against_stagewise(dev, mp, seed, dense)
     except AssertionError as e:
         bad += 1
         print("FAIL", seed, str(e)[:300], flush=True)

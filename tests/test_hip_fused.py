@@ -664,7 +664,7 @@ def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, 
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed):
+def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed, dense=False):
     """Random scenes, image sizes, plain bin sizes, near / far planes and opacity scales, from a camera that drifts a
     little every frame, with the depth cut forced on every frame that can take it: every frame equals the per-stage
     path (fully sorted gsplat-exact lists) bit for bit -- whether its cut-offs held, bins got their pairs back from the
@@ -674,12 +674,14 @@ def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed):
     monkeypatch.setenv("MOJOSPLAT_DEPTH_CUT", "2")
     g = torch.Generator().manual_seed(31000 + seed)
     r = lambda lo, hi: lo + (hi - lo) * torch.rand(1, generator=g).item()
-    N = int(10 ** r(4.3, 5.6))
-    W, H = int(r(300, 1400)), int(r(200, 900))
+    if dense:   # (scripts/fuzz_cut.py: scenes whose fronts saturate their pixels, so that most frames do take the cut)
+        N, W, H, ell = int(10 ** r(5.4, 6.0)), int(r(1000, 1920)), int(r(600, 1080)), r(-3.8, -3.0)
+    else:
+        N, W, H, ell = int(10 ** r(4.3, 5.6)), int(r(300, 1400)), int(r(200, 900)), r(-4.2, -2.8)
     px = [32, 64][seed % 2]
-    sc, cam = randscene_v1(N, W, H, ell=r(-4.2, -2.8), seed=900 + seed, device=device)
+    sc, cam = randscene_v1(N, W, H, ell=ell, seed=900 + seed, device=device)
     cam.near, cam.far = r(0.05, 2.0), r(8.0, 200.0)
-    sc["opacities"] = (sc["opacities"] * r(0.3, 1.0)).clamp(max=1.0)
+    sc["opacities"] = (sc["opacities"] * r(0.7 if dense else 0.3, 1.0)).clamp(max=1.0)
     bg = torch.tensor([r(0, 1), r(0, 1), r(0, 1)], device=device)
     args = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     _fused._state.clear()
