@@ -128,6 +128,11 @@ struct LazyLists {
     const CutInputs *cut_inputs;   // (a HOST pointer, read when the clean-up launches are enqueued)
 };
 int far_regen(const LazyLists &lazy, int tw, int n_tiles, int64_t cap, void *stream);
+// project_bwd.hip: the backward projection straight from the backward rasteriser's packed gradient rows
+int project_bwd_from_rows(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
+                          const float *viewmat, float fx, float fy, float cx, float cy, int W, int H, float eps2d,
+                          const int32_t *radii, const float *rows, int CDIM, float *v_means3d, float *v_scales,
+                          float *v_quats, float *v_colors, float *v_opacities, void *stream);
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
 bool depth_cut_fits(int64_t N, int tile_w, int tile_h);
 // lazily sorted fronts: depth (entries) of a front, LDS room for it, depth buckets from the camera planes

@@ -577,14 +577,20 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     char *bw = (char *)bwd_workspace;
     const size_t rb = ms::align_up(ms_rasterize_bwd_workspace_bytes(N, CDIM), 256);
     float *v_means2d = (float *)(bw + rb), *v_conics = (float *)(bw + rb + ms::align_up((size_t)N * 8, 256));
+    // (the rasteriser's packed 64-byte rows go straight into the backward projection, which unpacks v_colors / v_opacities
+    // on its way: no k_unpack_grads pass -- whenever the packed path runs: <= 4 channels, M > 0)
+    const bool packed_rows = CDIM <= 4 && rb > 0 && M > 0 && N <= 0x7fffffffll;
     if (int rc = ms::rasterize_bwd(N, M, means2d, conics, colors, CDIM, opacities, backgrounds, W, H, tile_size, ranges, ids,
                                    render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors,
-                                   v_opacities, rb ? bw : nullptr, rb, /*overwrite=*/1, records,
+                                   v_opacities, rb ? bw : nullptr, rb, /*overwrite: 2 = leave the rows packed=*/packed_rows ? 2 : 1, records,
                                    // (a whole-image frame on 16-px tiles: its count pass ordered exactly these blocks)
                                    (tile_size == 16 && ms_order_enabled()) ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr,
                                    stream_))
         return rc;
     if (mid_event) MS_HIP(hipEventRecord((hipEvent_t)mid_event, stream));   // (in-situ timing: between the two stages)
+    if (packed_rows)
+        return ms::project_bwd_from_rows(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, radii,
+                                         (const float *)bw, CDIM, v_means3d, v_scales, v_quats, v_colors, v_opacities, stream_);
     return ms_project_gaussians_bwd(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, radii,
                                     v_means2d, v_conics, nullptr, v_means3d, v_scales, v_quats, stream_);
 }

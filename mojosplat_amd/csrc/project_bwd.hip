@@ -16,14 +16,28 @@ struct ProjBwdParams {
     int scales_are_log;
 };
 
+// ROWS: the upstream gradients come as the backward rasteriser's packed 64-byte rows (rasterize_bwd.hip: mx my ca cb cc
+// op c0 c1 c2 c3 ...) instead of v_means2d / v_conics; the kernel then also writes v_opacities and v_colors from the row
+// (what k_unpack_grads would have done in a pass of its own).
+template <bool ROWS>
 __global__ __launch_bounds__(256) void k_project_ewa_bwd(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ viewmat, ProjBwdParams P,
     const int32_t *__restrict__ radii, const float *__restrict__ v_means2d,
     const float *__restrict__ v_conics, const float *__restrict__ v_depths,
-    float *__restrict__ v_means3d, float *__restrict__ v_scales, float *__restrict__ v_quats) {
+    float *__restrict__ v_means3d, float *__restrict__ v_scales, float *__restrict__ v_quats,
+    const float *__restrict__ rows, int cdim, float *__restrict__ v_colors, float *__restrict__ v_opacities) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    float4 row0 = make_float4(0.f, 0.f, 0.f, 0.f), row1 = row0;
+    if constexpr (ROWS) {
+        const float4 *row = reinterpret_cast<const float4 *>(rows + i * 16);
+        row0 = row[0]; row1 = row[1];
+        const float4 row2 = row[2];
+        v_opacities[i] = row1.y;
+        const float c[4] = {row1.z, row1.w, row2.x, row2.y};
+        for (int k = 0; k < cdim && k < 4; ++k) v_colors[i * cdim + k] = c[k];
+    }
     float o_p[3] = {0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f}, o_q[4] = {0.f, 0.f, 0.f, 0.f};
     const int2 rad = reinterpret_cast<const int2 *>(radii)[i];
     if (rad.x > 0 && rad.y > 0) {
@@ -82,8 +96,9 @@ __global__ __launch_bounds__(256) void k_project_ewa_bwd(
         const float ka = c * inv_det, kb = -b * inv_det, kc = a * inv_det;  // conic
 
         // ---- backward --------------------------------------------------------------------
-        const float vm0 = v_means2d[2 * i], vm1 = v_means2d[2 * i + 1];
-        const float vka = v_conics[3 * i], vkb = v_conics[3 * i + 1] * 0.5f, vkc = v_conics[3 * i + 2];
+        const float vm0 = ROWS ? row0.x : v_means2d[2 * i], vm1 = ROWS ? row0.y : v_means2d[2 * i + 1];
+        const float vka = ROWS ? row0.z : v_conics[3 * i], vkb = (ROWS ? row0.w : v_conics[3 * i + 1]) * 0.5f,
+                    vkc = ROWS ? row1.x : v_conics[3 * i + 2];
         const float vd = v_depths ? v_depths[i] : 0.f;
         // conic = inverse(cov2d): v_cov2d = -K vK K  (K symmetric; off-diagonal grad halved)
         const float t00 = ka * vka + kb * vkb, t01 = ka * vkb + kb * vkc;
@@ -196,9 +211,38 @@ extern "C" int ms_project_gaussians_bwd(int64_t N, const float *means3d, const f
     P.scales_are_log = scales_are_log;
     const int64_t grid = ms::ceil_div(N, 256);
     MS_REQUIRE(grid <= 0x7fffffff, MS_ERR_INVALID_ARG, "project_bwd: N too large");
-    hipLaunchKernelGGL(k_project_ewa_bwd, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
+    hipLaunchKernelGGL(k_project_ewa_bwd<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
                        scales, quats, viewmat, P, radii, v_means2d, v_conics, v_depths, v_means3d, v_scales,
-                       v_quats);
+                       v_quats, nullptr, 0, nullptr, nullptr);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ms_render_bwd: the same backward straight from the backward rasteriser's packed rows (which it also unpacks into
+// v_colors / v_opacities)
+int ms::project_bwd_from_rows(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
+                              const float *viewmat, float fx, float fy, float cx, float cy, int W, int H, float eps2d,
+                              const int32_t *radii, const float *rows, int CDIM, float *v_means3d, float *v_scales,
+                              float *v_quats, float *v_colors, float *v_opacities, void *stream) {
+    if (N == 0) return MS_OK;
+    MS_REQUIRE(means3d && scales && quats && viewmat && radii && rows && v_means3d && v_scales && v_quats && v_colors && v_opacities,
+               MS_ERR_INVALID_ARG, "project_bwd: null pointer");
+    MS_REQUIRE(W > 0 && H > 0 && fx != 0.f && fy != 0.f && CDIM >= 1 && CDIM <= 4, MS_ERR_INVALID_ARG, "project_bwd: bad camera / channels");
+    MS_REQUIRE(((uintptr_t)quats & 15) == 0 && ((uintptr_t)v_quats & 15) == 0 && ((uintptr_t)radii & 7) == 0 && ((uintptr_t)rows & 15) == 0,
+               MS_ERR_INVALID_ARG, "project_bwd: quats / v_quats / rows must be 16-byte, radii 8-byte aligned");
+    ProjBwdParams P;
+    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.eps2d = eps2d;
+    const float tan_fovx = 0.5f * (float)W / fx, tan_fovy = 0.5f * (float)H / fy;
+    P.lim_x_pos = ((float)W - cx) / fx + 0.3f * tan_fovx;
+    P.lim_x_neg = cx / fx + 0.3f * tan_fovx;
+    P.lim_y_pos = ((float)H - cy) / fy + 0.3f * tan_fovy;
+    P.lim_y_neg = cy / fy + 0.3f * tan_fovy;
+    P.scales_are_log = scales_are_log;
+    const int64_t grid = ms::ceil_div(N, 256);
+    MS_REQUIRE(grid <= 0x7fffffff, MS_ERR_INVALID_ARG, "project_bwd: N too large");
+    hipLaunchKernelGGL(k_project_ewa_bwd<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
+                       scales, quats, viewmat, P, radii, nullptr, nullptr, nullptr, v_means3d, v_scales, v_quats, rows, CDIM,
+                       v_colors, v_opacities);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }

@@ -655,6 +655,9 @@ int ms::rasterize_bwd(
         else MS_LAUNCH_BWD(4, false);
 #undef MS_LAUNCH_BWD
         MS_LAUNCH_CHECK();
+        // overwrite == 2 (ms_render_bwd): the rows stay packed -- the backward projection reads them as they are and
+        // writes v_colors / v_opacities itself (project_bwd.hip, k_project_ewa_bwd<true>): one pass over them fewer
+        if (overwrite == 2) return MS_OK;
         if (overwrite)
             hipLaunchKernelGGL(k_unpack_grads<true>, dim3((unsigned)ms::ceil_div(N, 256)), dim3(256), 0, st, N, CDIM,
                                (const float *)workspace, v_means2d, v_conics, v_colors, v_opacities);
