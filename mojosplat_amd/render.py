@@ -52,13 +52,16 @@ _STAGE_HOOK = None
 # synchronisation, same answer for the same sequence of scenes: with M pairs on a g-px grid and n
 # Gaussians on the grid, p = M / n pairs per Gaussian give the mean footprint diameter
 # d = g (sqrt(p) - 1) px (the same within 2 % whichever grid the frame ran on):
-#   d < 9 px: split frame;   9 <= d < 17 px: 32 px;   d >= 17 px: 64 px.
+#   d < 9 px: split frame;   9 <= d < 17 px: 32 px;   d >= 17 px: 64 px;
+# round 3: from 9 px on also 64 px when the scene is DENSE -- an estimated 1 500 entries or more per 16-px tile
+# (n (d / 16 + 1)^2 over the tiles): config 4, see _rule.
 # A frame is binned by the rule applied to the PREVIOUS frame of the same (device, N class, image
 # size); the first one is a split frame.  Thresholds carry a +-10 % dead band so that a scene sitting
 # on one does not flip every frame.  `bin_size=` (or MOJOSPLAT_BIN_PX) overrides the rule;
 # `tune_binning()` measures instead, for callers who want that.
 _BIN_MODES = (16, 32, 64)
 _D_SPLIT, _D_COARSE = 9.0, 17.0
+_E_DENSE = 1500.0         # entries per 16-px tile (estimated) from which a whole frame takes 64-px bins whatever its footprints
 _DEAD_BAND = 0.10
 _MIN_SETTLED = 64
 _bin_mode = {}            # (device, N to ~9 %, W, H) -> bin px of the next frame
@@ -69,6 +72,12 @@ _bin_lock = threading.Lock()
 def _rule(d, e, k=1.0, coarse=1.0):
     if d < _D_SPLIT * k:
         return 16
+    if e >= _E_DENSE * k and coarse == 1.0:
+        # lists several times deeper than a quad's wave ever reads (it stops after ~300-450 entries): the grid moves
+        # nothing but the binning cost, which follows the pairs -- and such a scene's frames drop the pairs behind
+        # their bins' depth cut-offs (csrc/binning.hip), so the rasteriser is not handed longer lists for it either.
+        # Config 4 (6 M Gaussians, 12-px footprints, ~2 700 entries per 16-px tile): 0.291 ms on 32-px bins, 0.265 on 64.
+        return 64
     return 32 if d < _D_COARSE * k * coarse else 64
 
 
