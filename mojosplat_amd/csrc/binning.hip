@@ -1869,7 +1869,7 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->packed = 0;
     out->row_lo = 0;
     out->row_hi = 0x7fffffff;
-    out->redo_grid = 64;
+    out->redo_grid = 256;
     out->cut_stamp = 0;   // (a depth-cut frame's caller sets the stamp, the cut-off buffers, the record's words and the log)
     out->tau = (uint32_t *)(ws + p.off_tau);   // (buffer 0; buffer 1 follows T words on: the caller picks)
     out->tau_next = nullptr;
@@ -2022,9 +2022,9 @@ int ms::far_regen(const ms::LazyLists &lazy, int tw, int n_tiles, int64_t cap, v
                          ms::make_proj_params(I.fx, I.fy, I.cx, I.cy, I.W, I.H, I.eps2d, I.near_plane, I.far_plane, 0.0f, I.scales_are_log,
                                               I.opacities != nullptr),
                          (float4 *)I.records};
-    // (empty launches on almost every frame: 16 workgroups while recent frames needed no clean-up at all -- an empty
-    // 256-workgroup launch costs the frame 4.7 us, a small one about 2.5 -- the whole chip after a frame that did)
-    const unsigned grid = lazy.redo_grid >= 64 ? 512u : 16u;
+    // (empty launches on almost every frame -- every workgroup reads the redo count and leaves; the frame costs the same
+    // whatever their number: pipeline.hip, ms_redo_grid)
+    const unsigned grid = 512u;
     hipLaunchKernelGGL(k_far_regen<0>, dim3(grid), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
     hipLaunchKernelGGL(k_far_regen<1>, dim3(grid), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
     MS_LAUNCH_CHECK();

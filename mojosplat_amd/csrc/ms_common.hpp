@@ -110,8 +110,7 @@ struct LazyLists {
     int bin_w;
     int packed;             // key / list words are id << 4 | block bits
     int row_lo, row_hi;     // split frames: the band in 16-px block rows (the clean-up leaves other rows alone)
-    int redo_grid;          // workgroups of the clean-up launch: 1 while recent frames needed none (an empty
-                            // 64-workgroup launch costs 4.5 us, a one-workgroup one 2), 64 after a frame that did
+    int redo_grid;          // workgroups of the clean-up launch (256: an empty launch costs the frame the same whatever their number)
     // depth-cut frame (cut_stamp != 0): the tiles marked has_far[tile] == cut_stamp own pairs that were never written
     // (depth bits > tau[tile]); the clean-up launches regenerate them for the tiles on the redo list from the frame's
     // 12-byte box records (`lean`, n_lean of them) into the free tail of the key array behind the cut_words[0] entries

@@ -128,6 +128,19 @@ static int64_t ms_depth_cut_min_pairs() {
     const long long n = e ? atoll(e) : -1;
     return (int64_t)(n >= 0 ? n : 6000000ll);
 }
+// workgroups of the clean-up launch (MOJOSPLAT_REDO_GRID: measurements).  Rounds 1-2 launched ONE while recent frames had
+// needed no clean-up ("an empty 64-workgroup launch costs 4.5 us, a one-workgroup one 2"): measured again in round 3 the
+// frame costs the same with 1, 8, 16, 64, 128 or 256 of them (0.1678-0.1681 ms at config 3) -- what costs is the kernel
+// boundary -- while the first frames that DO need the pass (the count reaches the host a frame late) ran their hundreds
+// of bins through one workgroup: 7-14 s a frame at configs 4 / 5 after a scene swap.  256, always.
+static int ms_redo_grid() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_REDO_GRID");
+        const int n = e ? atoi(e) : 0;
+        return (n >= 1 && n <= 256) ? n : 256;
+    }();
+    return v;
+}
 static int ms_merged_sort_enabled() {   // (binning.hip reads the same variable)
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_MERGED_SORT");
@@ -279,7 +292,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
     if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, split ? bw : tw, split ? bh : th, &lazy_lists);
     // (host_info[5] of the record left by the previous frame: the clean-up count it reported, or the buffer size
     // an exact-path frame asked for -- either way "not a quiet run of frames")
-    if (lazy && (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN)) lazy_lists.redo_grid = host_info[5] > 0 ? 64 : 1;
+    if (lazy) lazy_lists.redo_grid = ms_redo_grid();
     bool speculated = false;
     if (phase == MS_RENDER_WHOLE || phase == MS_RENDER_BEGIN) {
         mark(0);

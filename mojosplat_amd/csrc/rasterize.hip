@@ -577,12 +577,19 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_
 // inside their buckets, and (3) composites them, one wave per 8x8 quad and one pixel per lane, with
 // exactly the arithmetic of k_rasterize_fwd's generic loop, until every pixel is finished or the
 // list is exhausted.  Any list length, no scratch beyond LDS.  Slow and simple by design.
-constexpr int kRedoChunk = 1024, kRedoCap = 2048, kRedoNB = 2048;
+// Round 3: ... but not quadratic.  Selecting every chunk from the WHOLE list costs n^2 / 1024 key reads per 16x16
+// block: a scene swap that left 262 bins of 26-69 thousand entries short of their fronts (config 4) took 14 SECONDS
+// a frame.  Lists of more than kRedoPartMin entries are therefore partitioned once per tile: their entries' indices are
+// written in the order of 2 048 key buckets into the tile's slots of the id array (nobody reads the ids of a redone
+// tile any more: the rasteriser is done, the clean-up stages from the keys), the buckets' starts stay in LDS, and
+// every chunk is then selected from the buckets that hold the next ~1 024 keys alone.
+constexpr int kRedoChunk = 1024, kRedoCap = 2048, kRedoNB = 2048, kRedoPartMin = 4096;
 
 template <int CP, typename ColorT>
 __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     __shared__ uint64_t s_key[kRedoCap];
     __shared__ uint32_t s_cnt[kRedoNB];
+    __shared__ uint32_t s_bstart[kRedoNB + 1];   // a partitioned list: where each key bucket's indices begin
     __shared__ unsigned long long s_red[16];
     __shared__ int s_sel[4];                 // b*, F, first bucket, first bucket's count
     __shared__ float4 s_pa[256], s_pb[256];  // staged entries: mean.x mean.y a' b' | c' log2(o) - -
@@ -608,9 +615,75 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
         const int64_t far_base = far_tile ? min((int64_t)A.lazy.cut_words[0] + (int64_t)A.lazy.far_start[tile], (int64_t)A.max_isects) : 0;
         const int n_far = far_tile ? (int)min((int64_t)A.lazy.far_cnt[tile], (int64_t)A.max_isects - far_base) : 0;
         const uint64_t *fkeys = A.lazy.keys + far_base;
+        // A long list is partitioned once (see above): perm = the entries' indices (0 .. n: the list; n ..: the
+        // regenerated segment) in key-bucket order, in the id slots of the same two ranges
+        const int m_all = n + n_far;
+        const bool part = !A.lazy.packed && m_all > kRedoPartMin;
+        int32_t *perm_near = const_cast<int32_t *>(A.flatten_ids) + start;
+        int32_t *perm_far = const_cast<int32_t *>(A.flatten_ids) + far_base;
+        auto key_of = [&](int e) __attribute__((always_inline)) { return e < n ? kin[e] : fkeys[e - n]; };
+        unsigned long long pk_min = 0ull;
+        int pshift = 0;
+        if (part) {
+            unsigned long long mn = ~0ull, mx = 0ull;
+            for (int e = tid; e < m_all; e += 256) {
+                const unsigned long long k = key_of(e);
+                mn = k < mn ? k : mn; mx = k > mx ? k : mx;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const unsigned long long omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+                mn = omn < mn ? omn : mn;
+                mx = omx > mx ? omx : mx;
+            }
+            __syncthreads();   // (the previous tile is done with the LDS arrays)
+            if (lane == 0) { s_red[w] = mn; s_red[4 + w] = mx; }
+            for (int b = tid; b < kRedoNB; b += 256) s_cnt[b] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) { mn = s_red[ww] < mn ? s_red[ww] : mn; mx = s_red[4 + ww] > mx ? s_red[4 + ww] : mx; }
+            pk_min = mn;
+            const unsigned long long span = mx - mn;
+            pshift = max(0, (span ? 64 - __clzll((long long)span) : 0) - 11);
+            for (int e = tid; e < m_all; e += 256) atomicAdd(&s_cnt[(unsigned int)((key_of(e) - pk_min) >> pshift)], 1u);
+            __syncthreads();
+            {   // exclusive scan of the 2 048 counters: thread t owns buckets 8 t .. 8 t + 7
+                unsigned int c[8], sum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { c[j] = s_cnt[8 * tid + j]; sum += c[j]; }
+                unsigned int incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned int o = (unsigned int)__shfl_up((int)incl, d);
+                    if (lane >= d) incl += o;
+                }
+                __syncthreads();
+                if (lane == 63) s_red[12 + w] = incl;
+                __syncthreads();
+                unsigned int run = incl - sum;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+                    if (ww < w) run += (unsigned int)s_red[12 + ww];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s_bstart[8 * tid + j] = run; s_cnt[8 * tid + j] = run; run += c[j]; }
+                if (tid == 255) s_bstart[kRedoNB] = run;
+            }
+            __syncthreads();
+            for (int e = tid; e < m_all; e += 256) {
+                const int pos = (int)atomicAdd(&s_cnt[(unsigned int)((key_of(e) - pk_min) >> pshift)], 1u);
+                if (pos < n) perm_near[pos] = e; else perm_far[pos - n] = e;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        int w0 = 0, w1 = m_all;   // (a partitioned list: the slice of perm the current chunk is selected from)
         auto each_key = [&](auto &&fn) __attribute__((always_inline)) {
-            for (int i = tid; i < n; i += 256) fn(kin[i]);
-            for (int i = tid; i < n_far; i += 256) fn(fkeys[i]);
+            if (part) {
+                for (int i = w0 + tid; i < w1; i += 256) fn(key_of(i < n ? perm_near[i] : perm_far[i - n]));
+            } else {
+                for (int i = tid; i < n; i += 256) fn(kin[i]);
+                for (int i = tid; i < n_far; i += 256) fn(fkeys[i]);
+            }
         };
         // the next frame keeps every pair of a tile that outlived its front (k_tile_front, which ran before this
         // launch, has just set the cut-off where that front ended)
@@ -638,6 +711,19 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                 // ---- (1) next chunk: window [wlo, whi] over eligible keys
                 if (!first && lower == ~0ull) break;   // nothing can follow the largest key (and lower + 1 would wrap)
                 unsigned long long wlo = first ? 0ull : lower + 1ull, whi = ~0ull;
+                if (part) {
+                    // the buckets the next chunk can come from: the one the last consumed key lies in (its remaining
+                    // keys pass the `wlo` filter) and as many after it as hold kRedoChunk keys (or all that are left)
+                    const int cb = first ? 0 : (int)min((unsigned long long)(kRedoNB - 1), (lower - pk_min) >> pshift);
+                    const unsigned int want_to = s_bstart[cb + 1] + (unsigned int)kRedoChunk;
+                    int lo_b = cb, hi_b = kRedoNB - 1;   // smallest ce >= cb with s_bstart[ce + 1] >= want_to (else the last bucket)
+                    while (lo_b < hi_b) {
+                        const int mid = (lo_b + hi_b) >> 1;
+                        if (s_bstart[mid + 1] >= want_to) hi_b = mid; else lo_b = mid + 1;
+                    }
+                    w0 = (int)s_bstart[cb];
+                    w1 = (int)s_bstart[lo_b + 1];
+                }
                 int bstar = -1, F = 0;
                 unsigned long long kmin = 0ull;
                 int shift = 0;
@@ -828,7 +914,7 @@ static int raster_parts_override() {
     return v;
 }
 
-static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 64 ? A.lazy.redo_grid : 64); }
+static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 256 ? A.lazy.redo_grid : 64); }
 
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
