@@ -113,6 +113,7 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 #   cut_redo_tiles    ... because their depth cut-off was: their dropped pairs were regenerated (likewise)
 #   depth_cut         frames that dropped the pairs behind their bins' depth cut-offs
 #   front_level_up / full_sort_on   the lane's lazy-sorting mode escalated
+#   lazy_sort_retry   a lane on full sorts tried lazily sorted fronts again
 FRAME_STATS = None
 
 
@@ -143,6 +144,7 @@ def _count_frame(stats, frame, host, grew):
 
 
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
+RETRY_FULL_SORT = 64   # frames a lane stays on full sorts before it tries lazily sorted fronts again (doubling each time)
 FULL_SORT = 0x100
 FRONT_LEVEL = 0x200  # x level (0..3): deeper lazily sorted fronts
 ROWS16 = 0x800       # row_range counts rows of 16 px whatever the tile size (a band keeps its rows, the bins follow the scene)
@@ -291,6 +293,17 @@ class _Frame:
                     st["front_level"] = st.get("front_level", 0) + 1
                     if FRAME_STATS is not None:
                         FRAME_STATS["front_level_up"] = FRAME_STATS.get("front_level_up", 0) + 1
+            # ... and giving up is not for ever: a view through fog ends.  After RETRY_FULL_SORT frames on full sorts the
+            # lane tries lazily sorted fronts again, at the depth it last used; if they fail again (the library reports
+            # it one frame later, above) it is back on full sorts with twice the patience, up to 4096 frames.  (A failed
+            # retry costs one or two frames of the clean-up pass: 40-100 ms on the heaviest scenes since round 3.)
+            if st.get("full_sort") and same_shape:
+                st["full_sort_frames"] = st.get("full_sort_frames", 0) + 1
+                if st["full_sort_frames"] >= st.get("retry_after", RETRY_FULL_SORT):
+                    st["full_sort"], st["full_sort_frames"] = False, 0
+                    st["retry_after"] = min(2 * st.get("retry_after", RETRY_FULL_SORT), 4096)
+                    if FRAME_STATS is not None:
+                        FRAME_STATS["lazy_sort_retry"] = FRAME_STATS.get("lazy_sort_retry", 0) + 1
             st["shape"], st["prev_level"] = self.shape, (self.level if not self.mode & FULL_SORT else None)
             memo[self.shape] = (bool(st.get("full_sort")), int(st.get("front_level", 0)))
             if len(memo) > 64:

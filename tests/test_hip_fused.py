@@ -704,3 +704,43 @@ def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed, dense=False
 
 
 LAST_CUT_FUZZ_STATS = {}   # (scripts/fuzz_cut.py sums these up: how many frames took the cut, how many bins were regenerated)
+
+
+def test_a_lane_on_full_sorts_tries_lazy_sorting_again(device, default_grid_only, monkeypatch):
+    """A lane whose lazily sorted fronts kept failing sorts fully -- but not for ever: after RETRY_FULL_SORT frames it
+    tries fronts again (here 2 frames, on a scene that fails them every time: back to full sorts with twice the patience),
+    and a scene that has become opaque again stays on the fast path.  Every frame equals the per-stage path."""
+    from mojosplat_amd.rasterization import rasterize_gaussians_hip
+    monkeypatch.setattr(_fused, "RETRY_FULL_SORT", 2)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+
+    def reference(sc, cam):
+        g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+        m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
+        ids, ranges = ms.bin_gaussians_to_tiles(m2, rad, dep, cam.H, cam.W, 16, backend="hip")
+        return g, rasterize_gaussians_hip(m2, con, g[4], g[3], bg, ranges, ids, cam, 16)
+
+    faint, cam = _stack_scene(4000, 4.0, 6.0, 0.005, device)
+    solid = dict(faint)
+    solid["opacities"] = torch.full_like(faint["opacities"], 0.9)
+    solid["scales"] = faint["scales"] + 2.0   # (wide enough for the corner pixels to saturate within a front as well)
+    (gf, ref_f), (gs, ref_s) = reference(faint, cam), reference(solid, cam)
+    _fused._state.clear()
+    _fused.FRAME_STATS = {}
+    try:
+        modes = []
+        for k in range(12):
+            assert torch.equal(ms.render_gaussians(*gf, cam, background_color=bg, backend="hip"), ref_f), k
+            modes.append(bool(_fused._dev_state(device, 0).get("full_sort")))
+        st = dict(_fused.FRAME_STATS)
+        assert st.get("full_sort_on", 0) >= 2 and st.get("lazy_sort_retry", 0) >= 2, (st, modes)
+        assert _fused._dev_state(device, 0).get("retry_after", 0) >= 8, _fused._dev_state(device, 0).get("retry_after")
+        left = None
+        for k in range(80):   # the fog lifts: the next retry (within the patience reached above: <= 64 frames) sticks
+            assert torch.equal(ms.render_gaussians(*gs, cam, background_color=bg, backend="hip"), ref_s), k
+            if left is None and not _fused._dev_state(device, 0).get("full_sort"):
+                left = k
+        assert left is not None and not _fused._dev_state(device, 0).get("full_sort"), (left, _fused._dev_state(device, 0).get("retry_after"))
+    finally:
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
