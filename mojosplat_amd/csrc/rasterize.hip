@@ -849,8 +849,36 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                                 // the band's candidate list there, not indices into the caller's arrays)
                                 const float4 *rec = A.records + 3 * (size_t)g;
                                 const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                                // which of the block's four 8x8 quads the entry can reach at all: the forward kernel's
+                                // exact ellipse-vs-quad test on the record's three numbers (log2 units) -- a wave skips
+                                // what cannot blend in its quad (a 64-px bin's list is ~94 % misses for any one quad)
+                                int hit = 0;
+                                const float smax = rc.y, nb_c = rc.z, nb_a = rc.w;
+                                if (smax == kInf) {
+                                    hit = 0xf;
+                                } else if (smax > -kInf) {
+                                    const float fbx = (float)(tile_x * A.ts + sub_x * 16) + 0.5f, fby = (float)(tile_y * A.ts + sub_y * 16) + 0.5f;
+#pragma unroll
+                                    for (int qq = 0; qq < 4; ++qq) {
+                                        const float xl = fbx + (float)((qq & 1) * 8) - ra.x, xh = xl + 7.0f;
+                                        const float yl = fby + (float)((qq >> 1) * 8) - ra.y, yh = yl + 7.0f;
+                                        const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
+                                        float best = (in_x && in_y) ? 0.f : 3.0e38f;
+                                        if (!in_x) {
+                                            const float ddx = xl > 0.f ? xl : xh;
+                                            const float ddy = fminf(fmaxf(nb_c * ddx, yl), yh);
+                                            best = -(ra.z * ddx * ddx + rb.x * ddy * ddy + ra.w * ddx * ddy);
+                                        }
+                                        if (!in_y) {
+                                            const float ddy = yl > 0.f ? yl : yh;
+                                            const float ddx = fminf(fmaxf(nb_a * ddy, xl), xh);
+                                            best = fminf(best, -(ra.z * ddx * ddx + rb.x * ddy * ddy + ra.w * ddx * ddy));
+                                        }
+                                        hit |= (best <= smax) ? (1 << qq) : 0;
+                                    }
+                                }
                                 s_pa[tid] = ra;
-                                s_pb[tid] = make_float4(rb.x, rc.y > -kInf && listed ? rb.y : -kInf, 0.f, 0.f);
+                                s_pb[tid] = make_float4(rb.x, rc.y > -kInf && listed ? rb.y : -kInf, __int_as_float(hit), 0.f);
                                 s_pc[tid * CP] = rb.z; s_pc[tid * CP + 1] = rb.w; s_pc[tid * CP + 2] = rc.x;
                                 from_records = true;
                             }
@@ -860,7 +888,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                             const float ca = A.conics[3 * g], cb = A.conics[3 * g + 1], cc = A.conics[3 * g + 2];
                             const float op = A.opacities[g];
                             s_pa[tid] = make_float4(m.x, m.y, -0.5f * kLog2e * ca, -kLog2e * cb);
-                            s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold && listed ? __log2f(op) : -kInf, 0.f, 0.f);
+                            s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold && listed ? __log2f(op) : -kInf, __int_as_float(0xf), 0.f);
 #pragma unroll
                             for (int k = 0; k < CP; ++k)
                                 s_pc[tid * CP + k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
@@ -868,8 +896,11 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                     }
                     __syncthreads();
                     const int m = min(256, F - e0);
-                    for (int t = 0; t < m; ++t) {
-                        const float4 ra = s_pa[t], rb = s_pb[t];
+                    const bool wave_alive = __any(kq != 0.f);   // (a wave whose pixels are all finished has nothing to blend)
+                    for (int t = 0; wave_alive && t < m; ++t) {
+                        const float4 rb = s_pb[t];
+                        if (!((__float_as_int(rb.z) >> w) & 1)) continue;   // (wave-uniform: this wave's quad is out of the entry's reach)
+                        const float4 ra = s_pa[t];
                         const float dx = ra.x - px, dy = ra.y - py;
                         const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
                         // k_rasterize_fwd's generic (CHECK) arithmetic, operation for operation
