@@ -154,6 +154,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef MS_RASTER_MINW_AUX
 #define MS_RASTER_MINW_AUX 7   // variants that keep per-pixel records: 8 waves per SIMD made them spill (two quads per wave: 5)
 #endif
+#ifndef MS_RASTER_MINW2
+#define MS_RASTER_MINW2 5   // two quads per wave (96 VGPRs)
+#endif
 #ifndef MS_RASTER_MINW
 #define MS_RASTER_MINW 8
 #endif
@@ -523,7 +526,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
 }
 
 template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
-__global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? 5 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
+__global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
     // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
     // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
     // ...: dealt round-robin over the 8 XCDs, they land on ONE XCD back to back and share its L2 for the list they
