@@ -297,8 +297,13 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     th = -(-H // tile_size)
     # the background takes the colours' dtype first, as in render_gaussians (reference render.py:55): with
     # fp16 colours 0.1 is 0.09998 on every path
-    bg = torch.zeros(C, device=dev, dtype=torch.float32) if background_color is None else \
-        torch.as_tensor(background_color, device=dev).to(features.dtype).to(torch.float32)
+    if background_color is None:
+        bg = torch.zeros(C, device=dev, dtype=torch.float32)
+    elif isinstance(background_color, torch.Tensor):
+        from .render import _background_as
+        bg = _background_as(background_color, dev, features.dtype, True)   # (kept per tensor: no conversion kernels per frame)
+    else:
+        bg = torch.as_tensor(background_color, device=dev).to(features.dtype).to(torch.float32)
     if bg.shape[0] != C:
         raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color channels ({C})")
 

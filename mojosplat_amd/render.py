@@ -14,6 +14,7 @@ render.py:83 carried out.
 import math
 import os
 import threading
+import weakref
 from typing import Optional
 
 import torch
@@ -134,6 +135,31 @@ def _settle(key, mode, nxt):
         _bin_mode[key] = nxt
 
 
+_bg_cache = {}
+
+
+def _background_as(background, device, dtype, fp32_after):
+    """The background in the colours' dtype (the reference's order of conversions, render.py:55: with fp16 colours 0.1
+    is 0.09998 on every path) -- and, for the HIP path, back in fp32, which is what the library takes.  Two one-element
+    kernels per frame otherwise (each a ~4 us bubble in the frame's stream: 2-3 % of a 0.25 ms frame with fp16 colours),
+    so the converted tensor is kept per (storage, version, dtypes)."""
+    if background.device == device and background.dtype == dtype and (dtype == torch.float32 or not fp32_after):
+        return background
+    # (keyed by the tensor OBJECT -- a weak reference, checked for identity -- and its version counter: a new tensor at
+    # a recycled address, or an in-place update of this one, is converted afresh)
+    key = (id(background), str(device), dtype, fp32_after)
+    hit = _bg_cache.get(key)
+    if hit is not None and hit[0]() is background and hit[1] == background._version:
+        return hit[2]
+    out = background.to(device=device, dtype=dtype)
+    if fp32_after:
+        out = out.to(torch.float32)
+    if len(_bg_cache) >= 64:
+        _bg_cache.clear()
+    _bg_cache[key] = (weakref.ref(background), background._version, out)
+    return out
+
+
 def _bin_key(means3d, camera):
     n = means3d.shape[0]
     return (means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H)
@@ -204,7 +230,7 @@ def render_gaussians(
     elif not isinstance(background_color, torch.Tensor):
         bg = torch.tensor(background_color, device=means3d.device, dtype=features.dtype)
     else:
-        bg = background_color.to(device=means3d.device, dtype=features.dtype)
+        bg = _background_as(background_color, means3d.device, features.dtype, backend == "hip")
     if bg.shape[0] != num_channels:
         raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color "
                          f"channels ({num_channels})")
