@@ -645,7 +645,10 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 // (a depth-cut frame: only Gaussians that keep a pair stretch the range the sort kernel's buckets cover)
                 if (n > 0 && !CUT) { dmin = min(dmin, __float_as_uint(o.d)); dmax = max(dmax, __float_as_uint(o.d)); }
             }
-            if constexpr (LEAN == 2) {
+            // (a depth-cut frame's scatter kernel walks the compacted records of the Gaussians that keep a pair, and its
+            // clean-up launches project what they bring back themselves: nobody would read a box record -- 12 bytes a
+            // Gaussian, a sixth of what this kernel moves, not written)
+            if constexpr (LEAN == 2 && !CUT) {
                 uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(reinterpret_cast<Lean12 *>(lean) + base) + 12u * (uint32_t)threadIdx.x);
                 const uint32_t box = n > 0 ? ((uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24)) : 0u;
                 q[0] = box; q[1] = __float_as_uint(o.d); q[2] = (uint32_t)mask;
@@ -1909,6 +1912,7 @@ struct RegenProject {
     int color_f16;
     ms::ProjParams P;
     float4 *rec;
+    Grid g;
 };
 constexpr int kRegenThreads = 256, kRegenMaxTiles = 65536;
 template <int PASS>
@@ -1963,10 +1967,22 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
         __syncthreads();
     }
     const int64_t near = Z.cut_words[0];
-    const uint32_t *recs = reinterpret_cast<const uint32_t *>(Z.lean);
     for (int64_t j = (int64_t)blockIdx.x * kRegenThreads + tid; j < Z.n_lean; j += (int64_t)gridDim.x * kRegenThreads) {
-        const uint32_t box = recs[3 * j], db = recs[3 * j + 1], mk = recs[3 * j + 2];
-        const int x0 = (int)(box & 0xffu), y0 = (int)((box >> 8) & 0xffu), bw = (int)((box >> 16) & 0xffu), bh = (int)(box >> 24);
+        // the Gaussian's box, reach mask and depth bits as the count kernel had them (it keeps no box records on a
+        // depth-cut frame): the same functions on the same inputs, in the same translation unit
+        uint32_t db = 0u, mk = 0u;
+        int x0 = 0, y0 = 0, bw = 0, bh = 0;
+        const ms::ProjOut o = ms::project_one<uint32_t>((uint32_t)j, R.means3d, R.scales, R.quats, R.opacities, R.viewmat, R.P);
+        if (o.r0 > 0 && o.r1 > 0) {
+            int bx1, by1, be;
+            (void)bin_box<false>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), R.g, x0, bx1, y0, by1, be);
+            bw = bx1 - x0; bh = by1 - y0;
+            if (bw * bh > 0) {
+                mk = bw * bh > 32 ? 0xffffffffu
+                                  : (uint32_t)reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(R.opacities, (uint32_t)j, 1, 0), x0, bx1, y0, by1, R.g.ts);
+                db = __float_as_uint(o.d);
+            }
+        }
         const int n = bw * bh;
         bool brought_back = false;
         for (int r = 0, k = 0; r < bh; ++r) {
@@ -1992,7 +2008,6 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
                         if (((mk >> k) & 1u) && db <= Z.tau[(y0 + r) * tw + x0 + c]) kept = true;
                 if (!kept) {
                     const uint32_t src = (uint32_t)j;
-                    const ms::ProjOut o = ms::project_one<uint32_t>(src, R.means3d, R.scales, R.quats, R.opacities, R.viewmat, R.P);
                     float col[3];
                     if (R.color_f16) {
                         const __half *cp = reinterpret_cast<const __half *>(R.colors);
@@ -2021,7 +2036,7 @@ int ms::far_regen(const ms::LazyLists &lazy, int tw, int n_tiles, int64_t cap, v
     const RegenProject R{I.means3d, I.scales, I.quats, I.opacities, I.viewmat, I.colors, I.color_f16,
                          ms::make_proj_params(I.fx, I.fy, I.cx, I.cy, I.W, I.H, I.eps2d, I.near_plane, I.far_plane, 0.0f, I.scales_are_log,
                                               I.opacities != nullptr),
-                         (float4 *)I.records};
+                         (float4 *)I.records, Grid{I.tile_size, tw, n_tiles / (tw > 0 ? tw : 1), 0, n_tiles / (tw > 0 ? tw : 1), 0, 0, 0}};
     // (empty launches on almost every frame -- every workgroup reads the redo count and leaves; the frame costs the same
     // whatever their number: pipeline.hip, ms_redo_grid)
     const unsigned grid = 512u;

@@ -98,6 +98,7 @@ struct CutInputs {
     float eps2d, near_plane, far_plane;
     int scales_are_log;
     void *records;
+    int tile_size;
 };
 struct LazyLists {
     const int32_t *front_count;

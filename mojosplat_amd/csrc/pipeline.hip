@@ -341,7 +341,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         const ms::DeferredTotal defer{1, info, (int64_t *)mirror, sync_event, cut_stamp};
         const int defer_bit = (deferred ? ms::kTightDeferTotal : 0) | (cut && cut_in ? ms::kTightDepthCutBuf : 0);
         const ms::CutInputs cut_inputs{means3d, scales, quats, opacities, viewmat, colors, color_dtype == MS_COLOR_F16 ? 1 : 0, fx, fy, cx, cy, W, H,
-                                       eps2d, near_plane, far_plane, scales_are_log, records};
+                                       eps2d, near_plane, far_plane, scales_are_log, records, tile_size};
         const int64_t cut_bits = (cut ? 64 : 0) | (leaves_cutoffs ? (128 | (cut_out << 8) | cut_grid) : 0);
         if (int rc = ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
                                              cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,
