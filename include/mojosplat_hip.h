@@ -316,8 +316,8 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  * lazily sorted front ended, plus 1/16 octave -- and neither counts into the lists, scatters, sorts nor writes records
  * for the (Gaussian, bin) pairs behind them: host_info[0] still counts every pair (the buffer keeps room for them),
  * the lists hold the near ones.  The frame is exact whatever the cut-offs are: a bin whose pixels outlive its list
- * gets its dropped pairs -- and their Gaussians' records -- back from the 12-byte box records in the clean-up
- * launches, and its cut-off is lifted for the next frame.  host_info[5] of the next record reports such bins in its
+ * gets its dropped pairs -- and their Gaussians' records -- back in the clean-up launches (which project the
+ * Gaussians again), and its cut-off is lifted for the next frame.  host_info[5] of the next record reports such bins in its
  * high 32 bits (the low 32: bins whose sorted FRONT was too short, as before); bits 6-8 and 16-31 of host_info[7]
  * are the library's bookkeeping for it (this frame took the cut; it left cut-offs, in which of two buffers, for which
  * grid).  MOJOSPLAT_DEPTH_CUT=0 in the environment (read per frame) switches it off, =2 takes the cut whatever the
