@@ -1020,9 +1020,12 @@ namespace {
 // gathers + the folding arithmetic) 4 waves up to 150 entries per block, 2 up to 1 500, else 1.
 int choose_parts(int64_t blocks, int64_t density_hint, bool records, bool plain32 = false) {
     if (const int forced = raster_parts_override()) return forced;
-    // (plain forward frames on 32-px bins holding 150-600 entries per 16x16 block -- config 3: 241 -- run 1 % faster with
-    // two waves a block, each staging the bin's list once for two quads: 0.1640 against 0.1657 ms in three alternating
-    // pairs of runs; lighter frames (config 2: 24 a block) and the dense ones on 64-px bins keep a wave per quad)
+    // (plain forward frames on 32- / 64-px bins whose size record counts 150-600 pairs per 16x16 block -- config 3: 241,
+    // config 5: 303 -- run 2 % faster with two waves a block, each staging the bin's list once for two quads: 0.1656
+    // against 0.1686 ms and 0.4570 against 0.4670 ms in three alternating pairs of runs each; lighter frames (config 2:
+    // 24 a block) and denser ones (config 4: 1 200) keep a wave per quad: 0.0750 against 0.0787, 0.2459 against 0.2514 --
+    // and so do 64-px bins on images of fewer than 16 384 blocks: 1 M Gaussians at l = -3 on 1080p, 302 a block, 0.1639
+    // with four waves against 0.1669 with two)
     if (records && plain32 && blocks > 0 && density_hint / blocks >= 150 && density_hint / blocks <= 600) return 2;
     if (records) return 4;
     if (blocks >= 16384) return 1;   // many-round launches gain nothing
@@ -1078,7 +1081,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     }
     const int64_t blocks = (int64_t)band_tiles * A.nsub;
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
-    A.parts = choose_parts(blocks, density_hint, A.records != nullptr, tile_size == 32 && !render_alphas && !last_ids && lazy != nullptr);
+    A.parts = choose_parts(blocks, density_hint, A.records != nullptr, (tile_size == 32 || (tile_size == 64 && blocks >= 16384)) && !render_alphas && !last_ids && lazy != nullptr);
     A.nblocks = (int)blocks;
     A.ngrid = (int)blocks;
 #ifndef MS_RASTER_SUBS_APART
