@@ -1025,7 +1025,8 @@ int choose_parts(int64_t blocks, int64_t density_hint, bool records, bool plain3
     // against 0.1686 ms and 0.4570 against 0.4670 ms in three alternating pairs of runs each; lighter frames (config 2:
     // 24 a block) and denser ones (config 4: 1 200) keep a wave per quad: 0.0750 against 0.0787, 0.2459 against 0.2514 --
     // and so do 64-px bins on images of fewer than 16 384 blocks: 1 M Gaussians at l = -3 on 1080p, 302 a block, 0.1639
-    // with four waves against 0.1669 with two)
+    // with four waves against 0.1669 with two; and a multi-GPU rank's band -- an eighth of config 3: 1 020 blocks -- wants
+    // every wave it can get: 28 us against 48.  Hence the block counts: a whole 1080p frame on 32-px bins, 4K on 64)
     if (records && plain32 && blocks > 0 && density_hint / blocks >= 150 && density_hint / blocks <= 600) return 2;
     if (records) return 4;
     if (blocks >= 16384) return 1;   // many-round launches gain nothing
@@ -1081,7 +1082,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     }
     const int64_t blocks = (int64_t)band_tiles * A.nsub;
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
-    A.parts = choose_parts(blocks, density_hint, A.records != nullptr, (tile_size == 32 || (tile_size == 64 && blocks >= 16384)) && !render_alphas && !last_ids && lazy != nullptr);
+    A.parts = choose_parts(blocks, density_hint, A.records != nullptr, ((tile_size == 32 && blocks >= 8000) || (tile_size == 64 && blocks >= 16384)) && !render_alphas && !last_ids && lazy != nullptr);
     A.nblocks = (int)blocks;
     A.ngrid = (int)blocks;
 #ifndef MS_RASTER_SUBS_APART
