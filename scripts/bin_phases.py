@@ -36,11 +36,18 @@ def main():
     sc, cam = randscene_v1(N, W, H, ell=ell, device=dev)
     bg = torch.tensor(BACKGROUND_V1, device=dev)
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    # python scripts/bin_phases.py cfg3 8 3: rank 3's band of the frame cut 8 ways (the sharded entry point, rehearsed)
+    if len(sys.argv) > 3:
+        from mojosplat_amd.distributed import render_gaussians_sharded
+        world, rank = int(sys.argv[2]), int(sys.argv[3])
+        frame = lambda: render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(rank, world))
+    else:
+        frame = lambda: ms.render_gaussians(*g, cam, background_color=bg)
     for _ in range(8):
-        ms.render_gaussians(*g, cam, background_color=bg)
+        frame()
     buf = torch.zeros(4 * 1024 * 8, dtype=torch.int64, device=dev)
     _hip.check(L.ms_diag_set_bin_stamps(ctypes.c_void_p(buf.data_ptr())), "diag")
-    ms.render_gaussians(*g, cam, background_color=bg)
+    frame()
     torch.cuda.synchronize()
     _hip.check(L.ms_diag_set_bin_stamps(None), "diag")
     raw = buf.cpu().numpy()
