@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 1
+#define MS_ABI_VERSION 2   /* 2: ms_render_bwd takes the frame's image (render_colors) */
 
 typedef enum ms_status {
     MS_OK = 0,
@@ -233,7 +233,10 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  * One call runs the backward rasteriser -- staging from the frame's ready-made records -- and the backward
  * projection: what a training loop's backward() does between two Python statements (the reference has no backward:
  * render.py:11, README.md:145).
- *   in : the forward's inputs; v_render_colors f32[H,W,CDIM], v_render_alphas f32[H,W] or NULL.
+ *   in : the forward's inputs; v_render_colors f32[H,W,CDIM], v_render_alphas f32[H,W] or NULL;
+ *        render_colors f32[H,W,CDIM]: the image that frame returned, or NULL.  With it a 3-channel frame's backward
+ *        rasteriser walks the lists front to back, one wave per 8x8 quad (csrc/rasterize_bwdq.hip), and last_ids may
+ *        be NULL; without it the older back-to-front kernel runs and needs last_ids.
  *   out: v_means3d f32[N,3], v_scales f32[N,3] (w.r.t. the log-scales when scales_are_log), v_quats f32[N,4],
  *        v_opacities f32[N], v_colors f32[N,CDIM] -- all OVERWRITTEN.
  *   bwd_workspace: ms_render_bwd_workspace_bytes(N, CDIM) bytes of scratch.
@@ -243,10 +246,10 @@ int ms_render_bwd(int64_t N, const float *means3d, const float *scales, int scal
                   const float *opacities, const float *colors, int CDIM, const float *viewmat, float fx, float fy,
                   float cx, float cy, int W, int H, float eps2d, int tile_size, const float *backgrounds,
                   const void *workspace, size_t workspace_bytes, const void *isect_buf, size_t isect_bytes,
-                  const int64_t *host_info, const float *render_alphas, const int32_t *last_ids,
-                  const float *v_render_colors, const float *v_render_alphas, float *v_means3d, float *v_scales,
-                  float *v_quats, float *v_opacities, float *v_colors, void *bwd_workspace, size_t bwd_workspace_bytes,
-                  void *mid_event, void *stream);
+                  const int64_t *host_info, const float *render_colors, const float *render_alphas,
+                  const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, float *v_means3d,
+                  float *v_scales, float *v_quats, float *v_opacities, float *v_colors, void *bwd_workspace,
+                  size_t bwd_workspace_bytes, void *mid_event, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Spherical-harmonic colours (view dependent).  The reference leaves SH evaluation as a TODO

@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get("MOJOSPLAT_HIP_LIB") or \
     os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmojosplat_hip.so")
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); mirrors include/mojosplat_hip.h one to one
 _SIGNATURES = {
@@ -59,7 +59,7 @@ _SIGNATURES = {
     "ms_render_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ms_render_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
                               c_float, c_float, c_float, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t,
-                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "ms_isect_tiles_emit_speculative": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int64,

@@ -125,7 +125,8 @@ class _RenderFusedHip(torch.autograd.Function):
         # ms_render_bwd reads them where the forward call left them
         import numpy as np
         ctx.scratch = (frame.ws, frame.isect, np.array(frame.st["host_np"], dtype=np.int64, copy=True))
-        ctx.save_for_backward(m3, sc, qu, op, col, bg, frame.alphas, frame.last)
+        # (the image itself is saved too: the quad-wave backward rasteriser takes what lies behind an entry from it)
+        ctx.save_for_backward(m3, sc, qu, op, col, bg, frame.alphas, frame.last, img)
         return img
 
     @staticmethod
@@ -135,7 +136,7 @@ class _RenderFusedHip(torch.autograd.Function):
             m3, sc, qu, op, col, bg = ctx.saved_tensors
             return (torch.zeros_like(m3), torch.zeros_like(sc), torch.zeros_like(qu), torch.zeros_like(op),
                     torch.zeros_like(col), None if bg is None else torch.zeros_like(bg), None, None)
-        m3, sc, qu, op, col, bg, alphas, last = ctx.saved_tensors
+        m3, sc, qu, op, col, bg, alphas, last, img = ctx.saved_tensors
         ws, isect, host = ctx.scratch
         L = _hip.lib()
         N, C = col.shape
@@ -155,7 +156,8 @@ class _RenderFusedHip(torch.autograd.Function):
             _hip.check(L.ms_render_bwd(
                 N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(op), _hip.ptr(col), C, _hip.ptr(vm), cam.fx, cam.fy,
                 cam.cx, cam.cy, cam.W, cam.H, EPS2D, ts, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
-                0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(alphas), _hip.ptr(last), _hip.ptr(v_img),
+                0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(img) if C == 3 else None, _hip.ptr(alphas),
+                _hip.ptr(last), _hip.ptr(v_img),
                 None, _hip.ptr(v_means3d), _hip.ptr(v_scales), _hip.ptr(v_quats), _hip.ptr(v_opac), _hip.ptr(v_colors),
                 _hip.ptr(bws), bws_bytes, ctypes.c_void_p(bev[1].cuda_event) if bev else None, _hip.stream(dev)),
                 "ms_render_bwd")

@@ -9,11 +9,11 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "project.hip", "binning.hip", "rasterize.hip", "rasterize_bwd.hip",
+SOURCES = ["api.hip", "project.hip", "binning.hip", "rasterize.hip", "rasterize_bwd.hip", "rasterize_bwdq.hip",
            "project_bwd.hip", "pipeline.hip", "sh.hip"]
 # per-source flags.  rasterize.hip: fp32 denormals flushed -- its blend loop selects by underflow
 # (ms::kFlushK in ms_common.hpp; scripts/ubench/flush_select.hip)
-SOURCE_FLAGS = {"rasterize.hip": ["-fgpu-flush-denormals-to-zero"]}
+SOURCE_FLAGS = {"rasterize.hip": ["-fgpu-flush-denormals-to-zero"], "rasterize_bwdq.hip": ["-fgpu-flush-denormals-to-zero"]}
 HEADERS = ["ms_common.hpp", os.path.join("..", "..", "include", "mojosplat_hip.h")]
 LIB = os.path.join(HERE, "libmojosplat_hip.so")
 ARCH = "gfx950"

@@ -132,7 +132,8 @@ int far_regen(const LazyLists &lazy, int tw, int n_tiles, int64_t cap, void *str
 int project_bwd_from_rows(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
                           const float *viewmat, float fx, float fy, float cx, float cy, int W, int H, float eps2d,
                           const int32_t *radii, const float *rows, int CDIM, float *v_means3d, float *v_scales,
-                          float *v_quats, float *v_colors, float *v_opacities, void *stream);
+                          float *v_quats, float *v_colors, float *v_opacities, void *stream,
+                          const float *raw_rows_opacities = nullptr);   // non-null: rasterize_bwdq.hip's raw sums (radii may be null)
 void isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, LazyLists *out);
 bool depth_cut_fits(int64_t N, int tile_w, int tile_h);
 // lazily sorted fronts: depth (entries) of a front, LDS room for it, depth buckets from the camera planes
@@ -163,6 +164,17 @@ int rasterize_bwd(int64_t N, int64_t M, const float *means2d, const float *conic
                   const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas, float *v_means2d,
                   float *v_conics, float *v_colors, float *v_opacities, void *workspace, size_t workspace_bytes,
                   int overwrite, const void *records, const int32_t *block_order, void *stream);
+
+// rasterize_bwdq.hip: the backward rasteriser of a 3-channel differentiable frame -- one wave per 8x8 quad walking the
+// frame's own lists front to back (fully sorted, or lazily sorted fronts: front_count / front_threshold as the forward
+// took them), per-entry sums on the matrix pipe, raw sums into 64-byte rows (zeroed by the caller; finished by
+// project_bwd_from_rows with raw_rows_opacities).  ids: Gaussian index per entry, id_stride ints apart; skip_flag: tiles
+// to leave alone (or null); order: the binning grid's tiles heaviest first (or null).
+int rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const float *backgrounds, int W, int H, int tile_size,
+                        const int32_t *tile_ranges, const int32_t *ids, int id_stride, const int32_t *front_count,
+                        int front_threshold, const int32_t *skip_flag, const float *render_colors,
+                        const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
+                        float *packed_rows, const int32_t *order, void *stream);
 
 // Block lists of a split frame (ms_render_fwd): what the sort kernels of 32-px bins write instead of
 // flatten_ids.  Bin `b` with list [start, start + n) owns block_ids[4 start, 4 (start + n)): its block q

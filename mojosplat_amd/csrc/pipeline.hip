@@ -540,10 +540,10 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
                              const float *opacities, const float *colors, int CDIM, const float *viewmat, float fx, float fy,
                              float cx, float cy, int W, int H, float eps2d, int tile_size, const float *backgrounds,
                              const void *workspace, size_t workspace_bytes, const void *isect_buf, size_t isect_bytes,
-                             const int64_t *host_info, const float *render_alphas, const int32_t *last_ids,
-                             const float *v_render_colors, const float *v_render_alphas, float *v_means3d, float *v_scales,
-                             float *v_quats, float *v_opacities, float *v_colors, void *bwd_workspace,
-                             size_t bwd_workspace_bytes, void *mid_event, void *stream_) {
+                             const int64_t *host_info, const float *render_colors, const float *render_alphas,
+                             const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+                             float *v_means3d, float *v_scales, float *v_quats, float *v_opacities, float *v_colors,
+                             void *bwd_workspace, size_t bwd_workspace_bytes, void *mid_event, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "render_bwd: bad sizes");
     MS_REQUIRE(host_info && v_means3d && v_scales && v_quats && v_opacities && v_colors, MS_ERR_INVALID_ARG,
@@ -562,7 +562,7 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     }
     MS_REQUIRE(M > 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_bwd: bad intersection count %lld", (long long)M);
     MS_REQUIRE(means3d && scales && quats && opacities && colors && viewmat && workspace && isect_buf && render_alphas &&
-                   last_ids && v_render_colors && bwd_workspace,
+                   (last_ids || render_colors) && v_render_colors && bwd_workspace,
                MS_ERR_INVALID_ARG, "render_bwd: null pointer");
     MS_REQUIRE(!(host_info[7] & 8), MS_ERR_INVALID_ARG, "render_bwd: the frame's lists are block lists of a split frame");
     const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
@@ -593,6 +593,21 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     // (the rasteriser's packed 64-byte rows go straight into the backward projection, which unpacks v_colors / v_opacities
     // on its way: no k_unpack_grads pass -- whenever the packed path runs: <= 4 channels, M > 0)
     const bool packed_rows = CDIM <= 4 && rb > 0 && M > 0 && N <= 0x7fffffffll;
+    // a 3-channel frame whose image the caller still holds: the quad-wave kernel (rasterize_bwdq.hip) walks the frame's own
+    // lists front to back from the records and leaves raw sums, which the backward projection finishes
+    // (MOJOSPLAT_BWD_QUADS=0: the older kernel, which needs last_ids)
+    static const int quads_on = [] { const char *e = getenv("MOJOSPLAT_BWD_QUADS"); return e ? atoi(e) != 0 : 1; }();
+    if (render_colors && records && packed_rows && tile_size % 16 == 0 && (quads_on || !last_ids)) {
+        MS_HIP(hipMemsetAsync(bw, 0, (size_t)N * 16 * sizeof(float), stream));
+        if (int rc = ms::rasterize_bwd_quads(N, M, records, backgrounds, W, H, tile_size, ranges, ids, 1, nullptr, 0, nullptr,
+                                             render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw,
+                                             ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr, stream_))
+            return rc;
+        if (mid_event) MS_HIP(hipEventRecord((hipEvent_t)mid_event, stream));
+        return ms::project_bwd_from_rows(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, nullptr,
+                                         (const float *)bw, CDIM, v_means3d, v_scales, v_quats, v_colors, v_opacities, stream_, opacities);
+    }
+    MS_REQUIRE(last_ids, MS_ERR_INVALID_ARG, "render_bwd: this frame needs last_ids");
     if (int rc = ms::rasterize_bwd(N, M, means2d, conics, colors, CDIM, opacities, backgrounds, W, H, tile_size, ranges, ids,
                                    render_alphas, last_ids, v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors,
                                    v_opacities, rb ? bw : nullptr, rb, /*overwrite: 2 = leave the rows packed=*/packed_rows ? 2 : 1, records,

@@ -19,18 +19,25 @@ struct ProjBwdParams {
 // ROWS: the upstream gradients come as the backward rasteriser's packed 64-byte rows (rasterize_bwd.hip: mx my ca cb cc
 // op c0 c1 c2 c3 ...) instead of v_means2d / v_conics; the kernel then also writes v_opacities and v_colors from the row
 // (what k_unpack_grads would have done in a pass of its own).
-template <bool ROWS>
+// ROWS == 2: the rows of the quad-wave rasteriser (rasterize_bwdq.hip) -- RAW sums over the Gaussian's pixels,
+//   gx gy s1 s2 s3 m0 c0 c1 c2  =  sum vs dx, sum vs dy, sum vs dx^2, sum vs dx dy, sum vs dy^2, sum vs, colour gradients
+// (vs = dL/dsigma of a pixel-Gaussian pair, dx = mean - pixel): with the conic (a, b, c) this kernel recomputes anyway,
+// v_mean = (a gx + b gy, b gx + c gy), v_conic = (s1 / 2, s2, s3 / 2), v_opacity = -m0 / opacity.  A Gaussian whose row is
+// all zero was never blended (or culled): zero gradients, no radii needed.
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_project_ewa_bwd(
     int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
     const float *__restrict__ quats, const float *__restrict__ viewmat, ProjBwdParams P,
     const int32_t *__restrict__ radii, const float *__restrict__ v_means2d,
     const float *__restrict__ v_conics, const float *__restrict__ v_depths,
     float *__restrict__ v_means3d, float *__restrict__ v_scales, float *__restrict__ v_quats,
-    const float *__restrict__ rows, int cdim, float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    const float *__restrict__ rows, int cdim, float *__restrict__ v_colors, float *__restrict__ v_opacities,
+    const float *__restrict__ opacities) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     float4 row0 = make_float4(0.f, 0.f, 0.f, 0.f), row1 = row0;
-    if constexpr (ROWS) {
+    bool visible;
+    if constexpr (ROWS == 1) {
         const float4 *row = reinterpret_cast<const float4 *>(rows + i * 16);
         row0 = row[0]; row1 = row[1];
         const float4 row2 = row[2];
@@ -38,9 +45,20 @@ __global__ __launch_bounds__(256) void k_project_ewa_bwd(
         const float c[4] = {row1.z, row1.w, row2.x, row2.y};
         for (int k = 0; k < cdim && k < 4; ++k) v_colors[i * cdim + k] = c[k];
     }
+    if constexpr (ROWS == 2) {
+        const float4 *row = reinterpret_cast<const float4 *>(rows + i * 16);
+        row0 = row[0]; row1 = row[1];
+        const float c2 = rows[i * 16 + 8];
+        const float op = opacities[i];
+        v_opacities[i] = row1.y != 0.f ? -row1.y / op : 0.f;
+        v_colors[i * 3] = row1.z; v_colors[i * 3 + 1] = row1.w; v_colors[i * 3 + 2] = c2;
+        visible = row0.x != 0.f || row0.y != 0.f || row0.z != 0.f || row0.w != 0.f || row1.x != 0.f || row1.y != 0.f;
+    } else {
+        const int2 rad = reinterpret_cast<const int2 *>(radii)[i];
+        visible = rad.x > 0 && rad.y > 0;
+    }
     float o_p[3] = {0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f}, o_q[4] = {0.f, 0.f, 0.f, 0.f};
-    const int2 rad = reinterpret_cast<const int2 *>(radii)[i];
-    if (rad.x > 0 && rad.y > 0) {
+    if (visible) {
         float V[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) V[k] = viewmat[k];
@@ -96,9 +114,16 @@ __global__ __launch_bounds__(256) void k_project_ewa_bwd(
         const float ka = c * inv_det, kb = -b * inv_det, kc = a * inv_det;  // conic
 
         // ---- backward --------------------------------------------------------------------
-        const float vm0 = ROWS ? row0.x : v_means2d[2 * i], vm1 = ROWS ? row0.y : v_means2d[2 * i + 1];
-        const float vka = ROWS ? row0.z : v_conics[3 * i], vkb = (ROWS ? row0.w : v_conics[3 * i + 1]) * 0.5f,
-                    vkc = ROWS ? row1.x : v_conics[3 * i + 2];
+        float vm0, vm1, vka, vkb, vkc;
+        if constexpr (ROWS == 2) {
+            vm0 = ka * row0.x + kb * row0.y;
+            vm1 = kb * row0.x + kc * row0.y;
+            vka = 0.5f * row0.z; vkb = 0.5f * row0.w; vkc = 0.5f * row1.x;
+        } else {
+            vm0 = ROWS ? row0.x : v_means2d[2 * i]; vm1 = ROWS ? row0.y : v_means2d[2 * i + 1];
+            vka = ROWS ? row0.z : v_conics[3 * i]; vkb = (ROWS ? row0.w : v_conics[3 * i + 1]) * 0.5f;
+            vkc = ROWS ? row1.x : v_conics[3 * i + 2];
+        }
         const float vd = v_depths ? v_depths[i] : 0.f;
         // conic = inverse(cov2d): v_cov2d = -K vK K  (K symmetric; off-diagonal grad halved)
         const float t00 = ka * vka + kb * vkb, t01 = ka * vkb + kb * vkc;
@@ -211,9 +236,9 @@ extern "C" int ms_project_gaussians_bwd(int64_t N, const float *means3d, const f
     P.scales_are_log = scales_are_log;
     const int64_t grid = ms::ceil_div(N, 256);
     MS_REQUIRE(grid <= 0x7fffffff, MS_ERR_INVALID_ARG, "project_bwd: N too large");
-    hipLaunchKernelGGL(k_project_ewa_bwd<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
+    hipLaunchKernelGGL(k_project_ewa_bwd<0>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
                        scales, quats, viewmat, P, radii, v_means2d, v_conics, v_depths, v_means3d, v_scales,
-                       v_quats, nullptr, 0, nullptr, nullptr);
+                       v_quats, nullptr, 0, nullptr, nullptr, nullptr);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -223,10 +248,12 @@ extern "C" int ms_project_gaussians_bwd(int64_t N, const float *means3d, const f
 int ms::project_bwd_from_rows(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
                               const float *viewmat, float fx, float fy, float cx, float cy, int W, int H, float eps2d,
                               const int32_t *radii, const float *rows, int CDIM, float *v_means3d, float *v_scales,
-                              float *v_quats, float *v_colors, float *v_opacities, void *stream) {
+                              float *v_quats, float *v_colors, float *v_opacities, void *stream, const float *raw_rows_opacities) {
     if (N == 0) return MS_OK;
-    MS_REQUIRE(means3d && scales && quats && viewmat && radii && rows && v_means3d && v_scales && v_quats && v_colors && v_opacities,
+    const bool raw = raw_rows_opacities != nullptr;   // the quad-wave rasteriser's raw sums (ROWS == 2)
+    MS_REQUIRE(means3d && scales && quats && viewmat && (radii || raw) && rows && v_means3d && v_scales && v_quats && v_colors && v_opacities,
                MS_ERR_INVALID_ARG, "project_bwd: null pointer");
+    MS_REQUIRE(!raw || CDIM == 3, MS_ERR_INVALID_ARG, "project_bwd: raw rows carry three channels");
     MS_REQUIRE(W > 0 && H > 0 && fx != 0.f && fy != 0.f && CDIM >= 1 && CDIM <= 4, MS_ERR_INVALID_ARG, "project_bwd: bad camera / channels");
     MS_REQUIRE(((uintptr_t)quats & 15) == 0 && ((uintptr_t)v_quats & 15) == 0 && ((uintptr_t)radii & 7) == 0 && ((uintptr_t)rows & 15) == 0,
                MS_ERR_INVALID_ARG, "project_bwd: quats / v_quats / rows must be 16-byte, radii 8-byte aligned");
@@ -240,9 +267,14 @@ int ms::project_bwd_from_rows(int64_t N, const float *means3d, const float *scal
     P.scales_are_log = scales_are_log;
     const int64_t grid = ms::ceil_div(N, 256);
     MS_REQUIRE(grid <= 0x7fffffff, MS_ERR_INVALID_ARG, "project_bwd: N too large");
-    hipLaunchKernelGGL(k_project_ewa_bwd<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
-                       scales, quats, viewmat, P, radii, nullptr, nullptr, nullptr, v_means3d, v_scales, v_quats, rows, CDIM,
-                       v_colors, v_opacities);
+    if (raw)
+        hipLaunchKernelGGL(k_project_ewa_bwd<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
+                           scales, quats, viewmat, P, radii, nullptr, nullptr, nullptr, v_means3d, v_scales, v_quats, rows, CDIM,
+                           v_colors, v_opacities, raw_rows_opacities);
+    else
+        hipLaunchKernelGGL(k_project_ewa_bwd<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, N, means3d,
+                           scales, quats, viewmat, P, radii, nullptr, nullptr, nullptr, v_means3d, v_scales, v_quats, rows, CDIM,
+                           v_colors, v_opacities, nullptr);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }

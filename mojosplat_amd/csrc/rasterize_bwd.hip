@@ -194,6 +194,9 @@ __global__ __launch_bounds__(256) void k_rasterize_bwd(RasterBwdArgs A) {
 #ifndef MS_BWD_WAVES
 #define MS_BWD_WAVES 4
 #endif
+#ifndef MS_BWD_ABLATE
+#define MS_BWD_ABLATE 0
+#endif
 constexpr int kRow = 16;  // floats per packed gradient row: mx my ca cb cc op c0 c1 c2 c3 - - - - - -
 
 struct RasterBwd2Args {
@@ -502,6 +505,11 @@ __global__ __launch_bounds__(64, MS_BWD_WAVES) void k_rasterize_bwd_v2(RasterBwd
             if (anyv == 0ull) continue;
             // raw sums Sx Sy S1 S2 S3 op c0 c1 -> lanes 0..7; remaining colour channel(s) -> lane 63
             const float first8[8] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]};
+#if MS_BWD_ABLATE & 2   // (measurement builds only, profiles/r04_bwd_pmc.md: the walk without its wave reductions)
+            const float y = first8[0] + first8[1] + first8[2] + first8[3] + first8[4] + first8[5] + first8[6] + first8[7];
+            if (lane < 8) s_grad[t * kRow + lane] = y;
+            if (lane == 63) s_grad[t * kRow + 8] = acc[8];
+#else
             const float y = wave_allreduce8(first8, lane);
             if (lane < 8) s_grad[t * kRow + lane] = y;
 #pragma unroll
@@ -509,6 +517,7 @@ __global__ __launch_bounds__(64, MS_BWD_WAVES) void k_rasterize_bwd_v2(RasterBwd
                 const float tj = wave_sum_to_lane63(acc[j]);
                 if (lane == 63) s_grad[t * kRow + j] = tj;
             }
+#endif
             flush |= 1ull << t;
         }
         wave_lds_sync_bwd();
@@ -531,7 +540,11 @@ __global__ __launch_bounds__(64, MS_BWD_WAVES) void k_rasterize_bwd_v2(RasterBwd
                 } else if (colm == 2 || colm == 4) {
                     val *= 0.5f;
                 }
+#if MS_BWD_ABLATE & 1   // (measurement builds only: the kernel without its global atomics)
+                if (val == 1.2345678e-30f) B2.packed[(size_t)gid * kRow + colm] = val;
+#else
                 atomicAdd(B2.packed + (size_t)gid * kRow + colm, val);
+#endif
             }
         }
     }

@@ -199,7 +199,7 @@ def test_c_abi_argument_validation_returns_status_codes():
 
     def bwd(n=N, cdim=3, wsb=1 << 30, isb=1 << 20, bwsb=None, hinfo=host, ws=P):
         return L.ms_render_bwd(n, P, P, 1, P, P, P, cdim, P, 1., 1., 0., 0., 16, 16, .3, 16, None, ws, wsb, P, isb, hinfo,
-                               P, P, P, None, P, P, P, P, P, P, bws if bwsb is None else bwsb, None, None)
+                               P, P, P, P, None, P, P, P, P, P, P, bws if bwsb is None else bwsb, None, None)
     assert bwd(cdim=40) == INVALID and "sizes" in err()
     assert bwd(hinfo=None) == INVALID and "null" in err()
     assert bwd(ws=None) == INVALID and "null" in err()
