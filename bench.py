@@ -609,7 +609,7 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
         for l in leaves:
             l.grad = None
         img = ag.render_gaussians_trainable(*leaves, cam, background_color=bg)
-        (img * v_img).sum().backward()
+        img.backward(v_img)           # dL/dimage = v_img; no loss kernels inside the step
 
     for _ in range(warm):
         step()
@@ -654,7 +654,7 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
           "bwd_project": mean([e[1].elapsed_time(e[2]) for e in bev]) * 1e3}
     b_rbwd = 40 * m_lists + 24 * H * W + 36 * N
     b_pbwd = 108 * N
-    return {"what": "render_gaussians_trainable forward + (img * v).sum().backward(), grads for means3d / scales / quats / "
+    return {"what": "render_gaussians_trainable forward + img.backward(dL/dimage = rand(H, W, 3) seed 43), grads for means3d / scales / quats / "
                     "opacities / colours; every step synchronised (a training step ends with its gradients)",
             "steps": steps, "ms_per_step_mean": round(dt / steps * 1e3, 4),
             "ms_per_step_median": round(periods[len(periods) // 2] * 1e3, 4),

@@ -155,11 +155,13 @@ class _Frame:
     `run(phase)` makes the library call; `finish()` completes a frame that was only begun."""
 
     def __init__(self, means3d, scales, quats, opacities, colors, camera, background, tile_size,
-                 stage_events, row_range, out, lane, stream=None, own=False, rows16=False, out_y0=None):
+                 stage_events, row_range, out, lane, stream=None, own=False, rows16=False, out_y0=None, own_last=True):
         """own=True: the frame gets FRESH scratch (workspace, intersection buffer) and the per-pixel
         records of the backward pass instead of the lane's cached buffers -- a differentiable frame
         keeps them until its backward has run.  Only the size hint, the pinned record and the event
-        come from the lane."""
+        come from the lane.  own_last=False: render_alphas only -- the frame is then binned and sorted like an
+        inference frame (lazily sorted fronts, no projected arrays) and its backward is the quad-wave rasteriser,
+        which needs no last_ids (3 channels)."""
         self.L = L = _hip.lib()
         self.dev = dev = means3d.device
         N = means3d.shape[0]
@@ -187,7 +189,7 @@ class _Frame:
             hint = st.get("own_isect_bytes", 0)
             self.isect = torch.empty(hint, dtype=torch.uint8, device=dev) if hint else None
             self.alphas = torch.empty((H, W), dtype=torch.float32, device=dev)
-            self.last = torch.empty((H, W), dtype=torch.int32, device=dev)
+            self.last = torch.empty((H, W), dtype=torch.int32, device=dev) if own_last else None
         else:
             ws = _grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
         self.ws, self.grid = ws, (N, tw, th)

@@ -11,6 +11,7 @@ expose the gfx950 backward kernels so the same three stages can sit inside a tra
 Binning is index work and carries no gradient.
 """
 import ctypes
+import os
 
 import torch
 
@@ -111,10 +112,25 @@ class _RenderFusedHip(torch.autograd.Function):
         from ._fused import WHOLE, _Frame
         from . import render as _render   # bench.py's in-situ stage timing hook (None otherwise)
         evs = _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None
+        # three float32 channels: the frame keeps its alphas only and runs the inference frame's binning (lazily sorted
+        # fronts on the grid the binning rule picks: the image and the gradients do not depend on it); its backward is
+        # the quad-wave rasteriser.  Anything else keeps last_ids and fully sorted lists for the older kernel.
+        lean = colors.shape[1] == 3 and colors.dtype == torch.float32 and os.environ.get("MOJOSPLAT_BWD_QUADS", "1") != "0"
+        key = None
+        if lean and tile_size == _render.TILE_SIZE and "MOJOSPLAT_TRAIN_BIN_PX" not in os.environ:
+            explicit = _render._env_bin_px()
+            if explicit is not None:
+                tile_size = max(explicit, 16)
+            else:
+                key = _render._bin_key(means3d, camera)
+                with _render._bin_lock:
+                    tile_size = _render._bin_mode.get(key, 32)
         frame = _Frame(means3d.detach(), scales.detach(), quats.detach(), opacities.detach(), colors.detach(),
-                       camera, background, tile_size, evs, None, None, 0, own=True)
+                       camera, background, tile_size, evs, None, None, 0, own=True, own_last=not lean)
         info = {}
         img, M = frame.finish(WHOLE, info)
+        if key is not None:
+            _render._settle(key, tile_size, _render.bin_rule(tile_size, M, info["on_grid"], camera.W, camera.H, grid_px=tile_size))
         ctx.empty = info["on_grid"] == 0
         ctx.camera, ctx.tile_size = camera, tile_size
         m3, sc, qu, op, col, bg = frame.keep[:6]
@@ -215,7 +231,6 @@ def render_gaussians_trainable(means3d, scales, quats, opacities, features, came
     # 16-px tiles (measurements; default: the tile size as given).
     bin_px = tile_size
     if tile_size == 16:
-        import os
         v = os.environ.get("MOJOSPLAT_TRAIN_BIN_PX")
         if v and int(v) in (16, 32, 64):
             bin_px = int(v)

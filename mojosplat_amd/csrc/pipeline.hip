@@ -253,17 +253,20 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
 
     // host_info[7] belongs to the library between the two halves of a frame: bit 0 = emit +
     // rasterise were enqueued speculatively, bit 1 = the large sort class was among them
-    // lazy sorting (binning.hip, k_tile_front): not for a differentiable frame, whose backward walks
-    // the full lists by position
+    // lazy sorting (binning.hip, k_tile_front): not for a differentiable frame that asks for last_ids -- the older
+    // backward rasteriser walks the full lists by position; a frame that only keeps render_alphas (round 4: the
+    // quad-wave backward, rasterize_bwdq.hip, walks whatever lists the forward walked, front to back) is lazily sorted
+    // like any other
     // (bits 1-2 of `lazy`: the front level the caller asked for, see MS_RENDER_FRONT_LEVEL)
-    const int lazy = (render_alphas || last_ids || !opacities || CDIM > 4 || (resume & MS_RENDER_FULL_SORT))
+    const int lazy = (last_ids || !opacities || CDIM > 4 || (resume & MS_RENDER_FULL_SORT))
                          ? 0 : (ms_lazy_enabled() ? 1 | (((resume >> 9) & 3) << 1) : 0);
     // split frame (binning.hip, emit_block_lists): bin on 32-px bins, rasterise the 16x16-block lists cut
     // from them (a band that starts or ends inside a bin row bins that whole row).  The frame is the same
     // either way.
     // Thin bands (a rank's share of a frame cut 8 ways) stay on 16-px bins: their cost is the walk over all
     // Gaussians and the largest bin's front, which 32-px bins make longer (1080p, 9 rows: 151 vs 163 us).
-    const bool split = lazy && tile_size == 16 && N > 0 && N < (1ll << 28) && r1 > r0 &&
+    // (not for a differentiable frame: its backward walks the binning grid's own lists)
+    const bool split = lazy && tile_size == 16 && N > 0 && N < (1ll << 28) && r1 > r0 && !render_alphas &&
                        (r1 - r0 >= 16 || (r0 == 0 && r1 == th)) && !no_split && ms_split_enabled();
     const int bw = (tw + 1) / 2, bh = (th + 1) / 2, b0 = r0 / 2, b1 = (r1 + 1) / 2;
     // the rasteriser's ready-made records (3-channel forward frames): written by the projection kernel
@@ -283,8 +286,10 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
     // the scatter kernel from the 16-byte box + depth records the count kernel leaves instead)
     // (a differentiable frame keeps its arrays -- the backward and the caller's intermediates read them -- and leaves the
     // records for its scatter kernel as well: MOJOSPLAT_LEAN_AUX=0 switches that off)
+    // (the projected arrays are for the OLDER backward -- last_ids frames -- and the caller's intermediates; the quad-wave
+    // backward stages from the records and its backward projection takes the raw sums: nothing reads them)
     const int lean = (use_records && ((uintptr_t)records & 15) == 0 && ms_lean_enabled() && (!aux_frame || ms_lean_aux_enabled()))
-                         ? ms::kTightLean | (aux_frame ? ms::kTightKeepArrays : 0) : 0;
+                         ? ms::kTightLean | (last_ids ? ms::kTightKeepArrays : 0) : 0;
     const int cull = ((use_records && !aux_frame && N >= 32768 && N < (1ll << 28) && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0) | lean;
     const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0) | cull;
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
@@ -324,8 +329,9 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         // next frame on this record -- a lean one on plain bins with enough pairs to matter -- counts the pairs
         // behind them but never writes or sorts them (bit 6).  Whatever the cut-offs are, the frame is exact: a bin
         // that outlives its list gets its dropped pairs back in the clean-up launches (rasterize.hip, k_far_regen).
+        // (not a differentiable frame: it owns fresh scratch, nobody would read what it left)
         const bool leaves_cutoffs = speculate && !split && lazy && !bet_light && r0 == 0 && r1 == th && ms_merged_sort_enabled() &&
-                                    ms_depth_cut_mode() != 0;
+                                    ms_depth_cut_mode() != 0 && !aux_frame;
         const int cut_in = (prev[7] & 128) ? (int)((prev[7] >> 8) & 1) : 0, cut_out = (prev[7] & 128) ? 1 - cut_in : 0;
         // (bits 16-31: the grid those cut-offs belong to -- the record may have served another grid since; a frame whose
         // predecessor had to regenerate the pairs of more than a handful of bins takes no cut: its cut-offs are fresh)
@@ -412,7 +418,10 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                                            lazy && !bet_light ? &lazy_lists : nullptr,
                                            records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream))
                 return rc;
-            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits;
+            // (bit 9: the rasteriser was given lazily sorted fronts -- front counts and redo flags are this frame's; bit 10: a
+            // lazily sorted frame -- no merge scratch in the exact layout.  ms_render_bwd reads both.)
+            host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits |
+                           (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0);
 #ifdef MS_DIAG
             {
                 MS_HP_T(hp_t6);
@@ -472,6 +481,10 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
     const size_t need = split ? split_isect_bytes(M) : ms_render_isect_bytes(M, n_xl > 0 && !lazy);
     host_info[5] = (int64_t)need;
     host_info[7] |= 4;  // the lists the caller may read back are in the EXACT layout (below)
+    {
+        const bool fronts = !split && lazy && host_info[2] + host_info[3] + host_info[4] > 0;
+        host_info[7] = (host_info[7] & ~(512ll | 1024ll)) | (fronts ? 512 : 0) | (lazy ? 1024 : 0);
+    }
     MS_REQUIRE(isect_buf && isect_bytes >= need, MS_ERR_WORKSPACE,
                "render_fwd: intersection buffer %zu < %zu (grow it and call again with resume=1)", isect_bytes,
                need);
@@ -576,7 +589,7 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     // where the frame left its sorted ids (the layout rules of ms_render_fwd: exact, or sized by the buffer's capacity)
     size_t ids_off;
     if (host_info[7] & 4) {
-        ids_off = ms::align_up((size_t)M * 8, 256) * (n_xl > 0 ? 2 : 1);
+        ids_off = ms::align_up((size_t)M * 8, 256) * (n_xl > 0 && !(host_info[7] & 1024) ? 2 : 1);
     } else {
         MS_REQUIRE(isect_bytes > 512, MS_ERR_WORKSPACE, "render_bwd: intersection buffer too small");
         int64_t cap = (int64_t)((isect_bytes - 512) / 12);
@@ -599,10 +612,21 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     static const int quads_on = [] { const char *e = getenv("MOJOSPLAT_BWD_QUADS"); return e ? atoi(e) != 0 : 1; }();
     if (render_colors && records && packed_rows && tile_size % 16 == 0 && (quads_on || !last_ids)) {
         MS_HIP(hipMemsetAsync(bw, 0, (size_t)N * 16 * sizeof(float), stream));
-        if (int rc = ms::rasterize_bwd_quads(N, M, records, backgrounds, W, H, tile_size, ranges, ids, 1, nullptr, 0, nullptr,
-                                             render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw,
-                                             ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr, stream_))
+        // a lazily sorted frame: the lists are sorted as deep as the forward rasteriser walked them -- the tiles whose
+        // front ran out were redone by the forward's clean-up pass and are this call's second launch (normally empty)
+        ms::LazyLists ll;
+        ms::isect_lazy_arrays(const_cast<char *>(ws) + L.off_isect, N, tw, th, &ll);
+        const bool fronts = (host_info[7] & 512) != 0;
+        const int32_t *order = ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr;
+        if (int rc = ms::rasterize_bwd_quads(N, M, records, backgrounds, W, H, tile_size, ranges, ids, 1,
+                                             fronts ? ll.front_count : nullptr, ll.front_threshold, fronts ? ll.redo_flag : nullptr,
+                                             render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw, order, stream_))
             return rc;
+        if (fronts)
+            if (int rc = ms::rasterize_bwd_redo(N, M, records, backgrounds, W, H, tile_size, ranges,
+                                                (uint64_t *)const_cast<void *>(isect_buf), ll.redo_list, ll.redo_count,
+                                                render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw, stream_))
+                return rc;
         if (mid_event) MS_HIP(hipEventRecord((hipEvent_t)mid_event, stream));
         return ms::project_bwd_from_rows(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, nullptr,
                                          (const float *)bw, CDIM, v_means3d, v_scales, v_quats, v_colors, v_opacities, stream_, opacities);

@@ -518,8 +518,10 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         for (int k = 0; k < CP; ++k)
             if (k < A.cdim)
                 A.render_colors[p * A.cdim + k] = finish_channel(pix[qi][k], T[qi], A.backgrounds ? A.backgrounds[k] : 0.f);
+        // (round 4: the alphas alone need no AUX variant -- a differentiable frame whose backward is the quad-wave kernel
+        // asks for nothing else, and runs the plain kernel)
+        if (A.render_alphas) A.render_alphas[p] = 1.0f - T[qi] * ms::kTUnscale;
         if constexpr (AUX) {
-            if (A.render_alphas) A.render_alphas[p] = 1.0f - T[qi] * ms::kTUnscale;
             if (A.last_ids) A.last_ids[p] = last[qi];
         }
     }
@@ -932,6 +934,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
 #pragma unroll
                 for (int k = 0; k < CP; ++k)
                     if (k < A.cdim) A.render_colors[p * A.cdim + k] = finish_channel(pix[k], T, A.backgrounds ? A.backgrounds[k] : 0.f);
+                if (A.render_alphas) A.render_alphas[p] = 1.0f - T * ms::kTUnscale;   // (a differentiable frame keeps them)
             }
             __syncthreads();
         }
@@ -952,7 +955,7 @@ static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_g
 
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
-    const bool aux = A.render_alphas || A.last_ids;
+    const bool aux = A.last_ids != nullptr;   // (the per-entry index bookkeeping; render_alphas alone costs the plain kernel one store)
     // parts single-wave workgroups per block, the block count rounded up to the 8 XCDs
     const dim3 grid(A.parts > 1 ? (unsigned)(((A.ngrid + 7) / 8) * 8 * A.parts) : (unsigned)A.ngrid);
 #define MS_LAUNCH_RASTER(AUXV, NQV, PK) \
@@ -1082,7 +1085,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     }
     const int64_t blocks = (int64_t)band_tiles * A.nsub;
     MS_REQUIRE(blocks <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_fwd: too many tiles");
-    A.parts = choose_parts(blocks, density_hint, A.records != nullptr, ((tile_size == 32 && blocks >= 8000) || (tile_size == 64 && blocks >= 16384)) && !render_alphas && !last_ids && lazy != nullptr);
+    A.parts = choose_parts(blocks, density_hint, A.records != nullptr, ((tile_size == 32 && blocks >= 8000) || (tile_size == 64 && blocks >= 16384)) && !last_ids && lazy != nullptr);
     A.nblocks = (int)blocks;
     A.ngrid = (int)blocks;
 #ifndef MS_RASTER_SUBS_APART

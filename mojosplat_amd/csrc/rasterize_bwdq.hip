@@ -472,6 +472,60 @@ __global__ __launch_bounds__(64, MS_BWDQ_WAVES) void k_rasterize_bwd_quads(BwdQA
     bwd_quad(A, tile, sub, part, s_stage);
 }
 
+// ---- the tiles the forward's clean-up pass redid ------------------------------------------------------------------
+// A lazily sorted frame's rasteriser stops at the end of a heavy tile's sorted front; a tile whose pixels outlive it
+// is redone by k_tile_redo (rasterize.hip) from the tile's unsorted keys, and left out by the launch above (skip_flag).
+// Here, per such tile: one workgroup sorts the tile's (depth bits << 32 | index) keys IN PLACE -- the frame is
+// finished, nothing else reads them; a sorting network whose compare-exchanges all point the same way, so that the
+// virtual +inf padding up to a power of two never moves -- and its eight waves then walk the WHOLE list quad by quad,
+// taking the indices from the keys' low words.  Slow and simple: no benchmark scene comes here (the launch finds an empty
+// list), tests force it with stacks of faint Gaussians.
+constexpr int kRedoThreads = 512;
+
+struct BwdRedoArgs {
+    BwdQArgs a;
+    uint64_t *keys;
+    const int32_t *redo_list, *redo_count;
+};
+
+__global__ __launch_bounds__(kRedoThreads) void k_rasterize_bwd_redo(BwdRedoArgs R) {
+    __shared__ BwdQStage s_stage[kRedoThreads / 64];
+    const int n_redo = *R.redo_count;
+    const int tid = threadIdx.x, w = tid >> 6;
+    for (int ri = blockIdx.x; ri < n_redo; ri += gridDim.x) {
+        const int tile = R.redo_list[ri];
+        const int end_all = min(R.a.tile_ranges[2 * tile + 1], R.a.max_isects);
+        const int start = min(R.a.tile_ranges[2 * tile], end_all);
+        const int n = end_all - start;
+        uint64_t *k = R.keys + start;
+        for (int size = 2; (size >> 1) < n; size <<= 1) {
+            // first step of a merge: i against its mirror image inside the block of `size`
+            for (int t = tid; t < (n + 1) / 2 + size; t += kRedoThreads) {   // (t indexes pairs; the bound only needs to cover them)
+                const int blk = t / (size >> 1), off = t - blk * (size >> 1);
+                const int i = blk * size + off, j = blk * size + size - 1 - off;
+                if (j < n) {
+                    const uint64_t a = k[i], b = k[j];
+                    if (a > b) { k[i] = b; k[j] = a; }
+                }
+            }
+            __syncthreads();
+            for (int stride = size >> 2; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (n + 1) / 2 + stride; t += kRedoThreads) {
+                    const int i = 2 * stride * (t / stride) + (t % stride), j = i + stride;
+                    if (j < n) {
+                        const uint64_t a = k[i], b = k[j];
+                        if (a > b) { k[i] = b; k[j] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        for (int qi = w; qi < R.a.nsub * 4; qi += kRedoThreads / 64) bwd_quad(R.a, tile, qi >> 2, qi & 3, s_stage[w]);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // host side: ms::rasterize_bwd_quads (declared in ms_common.hpp)
@@ -508,6 +562,39 @@ int ms::rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const flo
     // workgroup index space: ngrid blocks padded to a multiple of 8, four waves each
     const unsigned grid = (unsigned)(((A.ngrid + 7) / 8) * 8 * 4);
     hipLaunchKernelGGL(k_rasterize_bwd_quads, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+int ms::rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const float *backgrounds, int W, int H, int tile_size,
+                           const int32_t *tile_ranges, uint64_t *keys, const int32_t *redo_list, const int32_t *redo_count,
+                           const float *render_colors, const float *render_alphas, const float *v_render_colors,
+                           const float *v_render_alphas, float *packed_rows, void *stream) {
+    MS_REQUIRE(N > 0 && M > 0 && M <= 0x7fffffffll && N <= 0x3ffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd_redo: bad N/M");
+    MS_REQUIRE(W > 0 && H > 0 && tile_size > 0 && tile_size % 16 == 0, MS_ERR_INVALID_ARG,
+               "rasterize_bwd_redo: the tile size must be a multiple of 16");
+    MS_REQUIRE(records && tile_ranges && keys && redo_list && redo_count && render_colors && render_alphas && v_render_colors &&
+                   packed_rows, MS_ERR_INVALID_ARG, "rasterize_bwd_redo: null pointer");
+    BwdRedoArgs R;
+    BwdQArgs &A = R.a;
+    A.records = (const float4 *)records;
+    A.tile_ranges = tile_ranges;
+    A.ids = reinterpret_cast<const int32_t *>(keys);   // the sorted keys' low words
+    A.id_stride = 2;
+    A.front_count = nullptr; A.front_threshold = 0; A.skip_flag = nullptr;
+    A.render_colors = render_colors; A.render_alphas = render_alphas; A.v_render_colors = v_render_colors;
+    A.v_render_alphas = v_render_alphas; A.backgrounds = backgrounds;
+    A.packed = packed_rows; A.order = nullptr;
+    A.W = W; A.H = H; A.ts = tile_size;
+    A.tw = (W + tile_size - 1) / tile_size;
+    A.nsx = tile_size / 16;
+    A.nsub = A.nsx * A.nsx;
+    A.ntiles = A.tw * ((H + tile_size - 1) / tile_size);
+    A.ngrid = 0;
+    A.max_isects = (int)M;
+    A.n_gauss = (int)N;
+    R.keys = keys; R.redo_list = redo_list; R.redo_count = redo_count;
+    hipLaunchKernelGGL(k_rasterize_bwd_redo, dim3(64), dim3(kRedoThreads), 0, (hipStream_t)stream, R);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }

@@ -200,3 +200,31 @@ def test_differentiable_frame_edge_cases(device):
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert_grad_close("grad", a, b, rel=1e-4)
+
+
+@pytest.mark.parametrize("n,z_lo,z_hi,opacity", [(4000, 4.0, 6.0, 0.005), (3000, 4.0, 4.0001, 0.02), (16000, 5.0, 5.0, 0.0055)])
+def test_differentiable_frame_whose_sorted_fronts_run_out(device, n, z_lo, z_hi, opacity):
+    """Round 4: a 3-channel differentiable frame is binned and sorted like an inference frame -- lazily sorted fronts --
+    and its backward walks the same lists.  On these stacks of faint Gaussians the fronts cannot saturate the pixels:
+    the forward's clean-up pass redoes the bins (alphas included) and the backward's second launch sorts their keys
+    in place and walks the whole lists.  Image bit for bit, gradients within the float atomics' order of the
+    per-stage autograd functions on fully sorted 16-px tiles -- on the first frame (exact path) and on a repeated,
+    sync-free one."""
+    from mojosplat_amd import _fused
+    from test_hip_fused import _stack_scene
+    sc, cam = _stack_scene(n, z_lo, z_hi, opacity, device)
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    bg = torch.tensor([0.2, 0.1, 0.3], device=device)
+    v_img = torch.rand(cam.H, cam.W, 3, generator=torch.Generator().manual_seed(5)).to(device)
+    _fused._state.clear()
+    res = []
+    for stagewise in (True, False, False):
+        leaves = [sc[k].clone().requires_grad_(True) for k in names]
+        img = render_gaussians_trainable(*leaves, cam, background_color=bg, stagewise=stagewise)
+        img.backward(v_img)
+        res.append((img.detach(), [l.grad for l in leaves]))
+    _fused._state.clear()
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0])
+        for name, a, b in zip(names, r[1], res[0][1]):
+            assert_grad_close(name, a, b, rel=2e-3)
