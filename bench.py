@@ -307,9 +307,11 @@ def main():
     depth_cut = bool(world == 1 and (dev, 0) in _fused._state and int(_fused._state[(dev, 0)]["host_np"][7]) & 64)
     # the lists the timed kernel was given: the frame's tile (or block) ranges still sit in lane 0's workspace
     m_lists = None
+    pairs_on_grid = None   # every (Gaussian, bin) pair of the frame's own binning grid, kept or dropped (the size record's word 0)
     if world == 1:
         try:
             px = binning["chosen_bin_px"]   # 16 = split frame: the ranges are those of the 16x16-block lists
+            pairs_on_grid = int(_fused._state[(dev, 0)]["host_np"][0])
             m_lists = _fused.last_frame_list_entries(dev, N, -(-W // px), -(-H // px))
         except Exception as e:  # noqa: BLE001
             print(f"[bench] list-entry count unavailable: {e!r}", file=sys.stderr)
@@ -449,7 +451,15 @@ def main():
         b_raster_gsplat = per_m * M + 8 * T + 12 * H * W
         if band_stats is not None:   # N > 1: the kernel timed is rank 0's band
             b_raster = b_raster_gsplat = per_m * band_stats["M"] + 8 * band_stats["T"] + 12 * band_stats["px"]
-        b_frame = 96 * N + (84 - (6 if fp16 else 0)) * M + 12 * T + 12 * H * W
+        b_frame_survey = 96 * N + (84 - (6 if fp16 else 0)) * M + 12 * T + 12 * H * W
+        # A depth-cut frame (configs 4 / 5) never writes, sorts or rasterises the pairs behind its bins' cut-offs: SURVEY's
+        # 84 bytes per pair price work that is legitimately not done (the frame is bit-identical to the full path).  The
+        # frame's own figure therefore counts the pairs it KEPT -- gsplat's M scaled by the share of its grid's pairs that
+        # are on the lists the rasteriser was given -- and the SURVEY model's figure is printed beside it, labelled.
+        kept_share = 1.0
+        if depth_cut and m_lists is not None and pairs_on_grid:
+            kept_share = min(1.0, m_lists / pairs_on_grid)
+        b_frame = 96 * N + int((84 - (6 if fp16 else 0)) * M * kept_share) + 12 * T + 12 * H * W
         roofline = None
         if "raster" in stage_us:
             ach = b_raster / (stage_us["raster"] * 1e-6) / 1e9
@@ -459,13 +469,14 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and world == 1:   # measured on the whole frame
                 rec = json.load(open(tpath)).get(args.workload, {})
-                have = csrc_sha16()
-                if rec.get("csrc_sha16") == have:
+                have = raster_sha16()
+                if rec.get("raster_sha16") == have:
                     traffic = rec.get("rasterize_fwd_bytes")
-                    traffic_note = f"PMC passes on csrc {have} (commit {rec.get('commit', '?')}), profiles/{rec.get('source', 'traffic.json')}"
+                    traffic_note = (f"PMC passes on rasterize.hip + its headers {have} (written by scripts/collect_profiles.sh at commit "
+                                    f"{rec.get('commit', '?')}), profiles/{rec.get('source', 'traffic.json')}")
                 else:
-                    traffic_note = (f"null: profiles/traffic.json was measured on csrc {rec.get('csrc_sha16')}, "
-                                    f"this library is built from csrc {have}")
+                    traffic_note = (f"null: profiles/traffic.json was measured on rasterize.hip + headers {rec.get('raster_sha16')}, "
+                                    f"this library is built from {have}")
             roofline = {"bound": "hbm", "kernel": "k_rasterize_fwd" + ("" if world == 1 else " (rank 0's band)"),
                         "achieved": round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -476,8 +487,15 @@ def main():
                         "avg_kernel_us": round(stage_us["raster"], 1), "instrumented_launches": len(stage_events),
                         "alpha_evals": 256 * m_kernel,
                         "frame": {"algorithmic_bytes": b_frame, "on": "ms_per_step_mean (wall time of the K steps / K)",
+                                  "pairs": "kept pairs only: gsplat's M x %.4f (depth-cut frame)" % kept_share if kept_share < 1.0
+                                           else "gsplat's M (every pair is written, sorted and offered to the rasteriser)",
                                   "achieved": round(b_frame / (ms_mean * 1e-3) / 1e9, 1),
                                   "frac": round(b_frame / (ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "frame_survey_model": {"algorithmic_bytes": b_frame_survey,
+                                               "what": "SURVEY 8(d)'s 96 N + 84 M + 12 T + 12 HW on gsplat's M whatever the frame "
+                                                       "skipped: a MODEL of a full frame's traffic, not bytes this frame moved -- "
+                                                       "not a fraction of anything when pairs are dropped",
+                                               "model_GBps": round(b_frame_survey / (ms_mean * 1e-3) / 1e9, 1)},
                         "stage_us": {k: round(v, 1) for k, v in stage_us.items()}}
         cpu = None
         verification = {"bit_identical_to_stagewise": verified, "max_abs_vs_stagewise": max_abs}
@@ -671,14 +689,15 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
                                          "unit": "GB/s", "frac": round(b_pbwd / (us["bwd_project"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}}
 
 
-def csrc_sha16():
-    """sha256[:16] over the kernel sources the library is built from (csrc/*.hip, *.hpp, the C header)."""
+def raster_sha16():
+    """sha256[:16] over the forward rasteriser's translation unit: rasterize.hip and the headers it includes.  What
+    profiles/traffic.json's rasteriser figure is tied to (an edit to binning.hip cannot void it; nobody re-stamps it by
+    hand: scripts/collect_profiles.sh writes it with the measurement)."""
     import hashlib
     d = os.path.join(ROOT, "mojosplat_amd", "csrc")
-    files = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".hpp")))
     h = hashlib.sha256()
-    for f in files + [os.path.join("..", "..", "include", "mojosplat_hip.h")]:
-        h.update(f.encode())
+    for f in ("rasterize.hip", "ms_common.hpp", os.path.join("..", "..", "include", "mojosplat_hip.h")):
+        h.update(os.path.basename(f).encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

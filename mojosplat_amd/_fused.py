@@ -285,6 +285,13 @@ class _Frame:
             if not same_shape:                   # shapes (render.py's race between grids) does not learn them anew
                 st["full_sort"], st["front_level"] = memo.get(self.shape, (False, 0))
             # (low 32 bits: a bin redone because of its depth cut-off -- the high bits -- says nothing about the fronts)
+            # (round 4: ... unless nearly every heavy bin had to be regenerated: that is a scene swap, the fronts of the new
+            # scene's bins are as stale as the cut-offs were -- measured: the frame after such a one fails its fronts as
+            # well, 70 ms at config 4 -- so the lane goes to full sorts one frame earlier)
+            elif (rc == 0 and not (int(host[7]) & 4) and not st.get("full_sort") and (int(host[5]) >> 32) > max(8, heavy // 2)):
+                st["full_sort"] = True
+                if FRAME_STATS is not None:
+                    FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
             elif (rc == 0 and not (int(host[7]) & 4) and (int(host[5]) & 0xffffffff) > 0 and not st.get("full_sort")
                   and st.get("prev_level") == st.get("front_level", 0)):
                 if (int(host[5]) & 0xffffffff) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:

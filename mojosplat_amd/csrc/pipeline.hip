@@ -137,7 +137,7 @@ static int ms_redo_grid() {
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_REDO_GRID");
         const int n = e ? atoi(e) : 0;
-        return (n >= 1 && n <= 256) ? n : 256;
+        return (n >= 1 && n <= 4096) ? n : 256;
     }();
     return v;
 }

@@ -951,7 +951,7 @@ static int raster_parts_override() {
     return v;
 }
 
-static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 256 ? A.lazy.redo_grid : 64); }
+static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 4096 ? A.lazy.redo_grid : 64); }
 
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {

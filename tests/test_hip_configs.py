@@ -1,5 +1,5 @@
-"""GPU: the BASELINE configs at FULL size against the C oracle (configs 3, 4, 5; config 2 lives in
-test_hip_parity.py), through the calls a user makes.
+"""GPU: the BASELINE configs at FULL size against the C oracle (configs 2, 3, 4, 5; config 2's per-stage kernels on the
+oracle's inputs also live in test_hip_parity.py), through the calls a user makes.
 
 Per config:
   * the frame of `render_gaussians(backend="hip")` -- the fused path: tight binning, lazily sorted lists,
@@ -36,6 +36,7 @@ pytestmark = pytest.mark.gpu
 
 CONFIGS = {
     # name: (N, W, H, ell, fp16 colours)
+    "cfg2": (100_000, 1920, 1080, -4.0, False),   # (round 4: the fused "light frame" path -- short sorts only, no clean-up launch)
     "cfg3": (1_000_000, 1920, 1080, -4.0, False),
     "cfg4": (6_000_000, 1600, 1063, -4.0, True),
     "cfg5": (5_000_000, 3840, 2160, -4.0, False),
@@ -63,8 +64,27 @@ def test_config_forward_full_size_vs_oracle(device, name):
     # ---- the user's call (fused path, rule-chosen grid), three frames: first frame split, then the rule's
     _fused._state.clear()
     ms.render._bin_mode.clear(); ms.render._bin_left.clear()
-    frames = [ms.render_gaussians(*g, cam, background_color=bg, backend="hip") for _ in range(3)]
+    _fused.FRAME_STATS = stats = {}
+    try:
+        # (a fresh lane's first frame is a split frame on the exact path, the second moves to the rule's grid, the third
+        # finds a clean-up count left by another grid's layout and takes no cut, the fourth leaves cut-offs, the FIFTH
+        # is the first that can take them: scripts/cut_when.py)
+        frames = [ms.render_gaussians(*g, cam, background_color=bg, backend="hip") for _ in range(5)]
+        before_last = dict(stats)
+        frames.append(ms.render_gaussians(*g, cam, background_color=bg, backend="hip"))
+    finally:
+        _fused.FRAME_STATS = None
     chosen = next(iter(ms.render._bin_mode.values()))
+    # which shortcuts the frames that are compared below really took (the comparison is only worth what ran):
+    # config 2's later frames bet on "no heavy tile" and launch the short sorts alone; configs 4 / 5 hold > 6 M pairs,
+    # so the LAST frame drops the pairs behind its bins' depth cut-offs (and no speculation was lost on the way)
+    last_cut = stats.get("depth_cut", 0) - before_last.get("depth_cut", 0)
+    print(f"{name}: frame stats {stats}, last frame depth-cut: {last_cut}")
+    assert stats.get("speculated", 0) >= 4 and stats.get("overflow", 0) <= 1
+    if name in ("cfg4", "cfg5"):
+        assert last_cut == 1, f"{name}: the frame compared with the oracle did not take the depth cut ({stats})"
+    else:
+        assert stats.get("depth_cut", 0) == 0
     # ---- per-stage HIP path
     m2, con, dep, rad = ms.project_gaussians(*g[:4], cam, backend="hip")
     ids, ranges = bin_gaussians_to_tiles_hip(m2, rad, dep, 16, tw, th)
@@ -149,15 +169,17 @@ def test_config3_backward_full_size(device):
         assert float((a - c).abs().max()) <= 1e-4 * scale + 1e-6, f"{name}: fused != per-stage"
 
 
-def test_config3_crop_backward_vs_float64_autograd(device):
-    """A 20k-Gaussian crop of config 3's scene (the Gaussians nearest the image centre, on a 320x192 window of
-    the same camera): HIP gradients against float64 autograd of the restatement, 5e-3 of each tensor's max."""
+@pytest.mark.parametrize("x0,y0", [(640, 348), (960, 348), (640, 540), (960, 540)])
+def test_config3_crop_backward_vs_float64_autograd(device, x0, y0):
+    """Four disjoint 20k-Gaussian crops of config 3's scene (the Gaussians nearest the centre of a 320x192 window of
+    the full frame at (x0, y0): same camera, principal point moved): HIP gradients against float64 autograd of the
+    restatement, 5e-3 of each tensor's max."""
     from mojosplat_amd.autograd import project_gaussians_autograd, render_gaussians_trainable
     from mojosplat_amd.utils import Camera
     from oracle import torch_oracle
     sc, cam0, _ = _scene("cfg3", device)
     W, H = 320, 192
-    cam = Camera(R=cam0.R, T=cam0.T, H=H, W=W, fx=cam0.fx, fy=cam0.fy, cx=W / 2.0, cy=H / 2.0, near=cam0.near,
+    cam = Camera(R=cam0.R, T=cam0.T, H=H, W=W, fx=cam0.fx, fy=cam0.fy, cx=cam0.cx - x0, cy=cam0.cy - y0, near=cam0.near,
                  far=cam0.far)
     with torch.no_grad():
         m2, _, _, rad = ms.project_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], cam, backend="hip")
@@ -170,7 +192,7 @@ def test_config3_crop_backward_vs_float64_autograd(device):
     bg = torch.tensor(BACKGROUND_V1, device=device)
     v_img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(43)).to(device)
     img = render_gaussians_trainable(*leaves, cam, background_color=bg)
-    (img * v_img).sum().backward()
+    img.backward(v_img)
 
     with torch.no_grad():
         m2h, conh, deph, radh = project_gaussians_autograd(*[l.detach() for l in leaves[:4]], cam)
@@ -186,3 +208,47 @@ def test_config3_crop_backward_vs_float64_autograd(device):
         got, ref = a.grad.double().cpu(), b.grad
         err, scale = float((got - ref).abs().max()), float(ref.abs().max())
         assert err <= 5e-3 * scale + 1e-6, f"{name}: max err {err:.3g} vs scale {scale:.3g}"
+
+
+def test_scene_swap_at_config4_is_exact_and_bounded(device):
+    """The worst frame the lazy machinery can meet (scripts/cut_miss_cost.py): config 4 on 64-px bins with depth cut-offs,
+    then the same Gaussians with the near half all but transparent -- every bin outlives both its cut-off and its sorted
+    front.  Each frame on the way must be bit-identical to the per-stage path of ITS scene; the clean-up pass is slow by
+    design (one workgroup per bin), so the bound here is on what the lane learns: the swapped scene's first frame within
+    150 ms (round 2: 14 s), full sorts from its third frame on at the latest (<= 8 ms: the fully sorted path), and the
+    original scene again within two frames of the swap back."""
+    import time
+    sc, cam, g = _scene("cfg4", device)
+    bg = torch.tensor(BACKGROUND_V1, device=device).to(sc["features"].dtype)
+    depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
+    other = dict(sc)
+    other["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.02, sc["opacities"])
+    tup = lambda s_: (s_["means3d"], s_["scales"], s_["quats"], s_["opacities"], s_["features"])
+    th, tw = -(-cam.H // 16), -(-cam.W // 16)
+
+    def stagewise_frame(s_):
+        m2, con, dep, rad = ms.project_gaussians(*tup(s_)[:4], cam, backend="hip")
+        ids, ranges = bin_gaussians_to_tiles_hip(m2, rad, dep, 16, tw, th)
+        return rasterize_gaussians_hip(m2, con, s_["features"], s_["opacities"], bg, ranges, ids, cam)
+    ref = {id(sc): stagewise_frame(sc), id(other): stagewise_frame(other)}
+    _fused._state.clear()
+    _fused.FRAME_STATS = stats = {}
+    times = []
+    try:
+        for k in range(12):
+            s_ = sc if k < 5 or k >= 9 else other
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = ms.render_gaussians(*tup(s_), cam, background_color=bg, backend="hip", bin_size=64)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+            assert torch.equal(img, ref[id(s_)]), f"frame {k} differs from the per-stage path"
+    finally:
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
+    print("scene swap at config 4, ms per synchronised frame:", [round(t, 2) for t in times], stats)
+    assert stats.get("depth_cut", 0) >= 2            # the steady frames before the swap were cut
+    assert stats.get("redo_tiles", 0) + stats.get("cut_redo_tiles", 0) > 100   # ... and the swap did strand the bins
+    assert max(times[5:9]) <= 150.0
+    assert times[7] <= 8.0 and times[8] <= 8.0       # full sorts by the swapped scene's third frame
+    assert max(times[10:]) <= 3.0
