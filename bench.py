@@ -446,7 +446,9 @@ def main():
     rc = 0
     if rank == 0:
         per_m = 40 - (6 if fp16 else 0)
-        m_kernel = m_lists if m_lists is not None else M
+        # the lists the timed kernel is given: N = 1 the frame's own (read back); N > 1 rank 0's BAND (what the stage events
+        # time), never the whole frame's
+        m_kernel = m_lists if m_lists is not None else (band_stats["M"] if band_stats is not None else M)
         b_raster = per_m * m_kernel + 8 * T + 12 * H * W
         b_raster_gsplat = per_m * M + 8 * T + 12 * H * W
         if band_stats is not None:   # N > 1: the kernel timed is rank 0's band

@@ -360,7 +360,8 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         mark(1);
         MS_HP_T(hp_t3);
         MS_HP_ADD(2, hp_t2, hp_t3);
-        host_info[7] = no_split ? 16 : 0;
+        // (bit 11: the band's Gaussians were pre-culled -- host_info[6] counts the band's candidates on the grid, not all Gaussians')
+        host_info[7] = (no_split ? 16 : 0) | ((cull & 32) ? 2048 : 0);
         if (!mirror) MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         if (sync_event && !deferred) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));   // (deferred: behind the scatter launch)
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
@@ -389,7 +390,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                                                      bin_ranges, &lists, render_colors, &lazy_lists, records, order,
                                                      stage_events ? stage_events[3] : nullptr, stream))
                     return rc;
-                host_info[7] = 1 | 8;
+                host_info[7] = 1 | 8 | ((cull & 32) ? 2048 : 0);
                 if (phase == MS_RENDER_BEGIN) return MS_OK;
             } else {
             if (int rc = ms::isect_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
@@ -421,7 +422,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
             // (bit 9: the rasteriser was given lazily sorted fronts -- front counts and redo flags are this frame's; bit 10: a
             // lazily sorted frame -- no merge scratch in the exact layout.  ms_render_bwd reads both.)
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits |
-                           (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0);
+                           (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0) | ((cull & 32) ? 2048 : 0);
 #ifdef MS_DIAG
             {
                 MS_HP_T(hp_t6);

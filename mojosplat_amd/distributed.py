@@ -106,17 +106,27 @@ _plans = {}   # plan key -> dict(bounds, frame): the bands of the next frame of 
 _CHECK_EVERY, _CHECK_SETTLED, _SPREAD_OK = 8, 64, 1.08
 
 
-def _plan_key(means3d, camera, tile_size, world):
+def _plan_key(means3d, camera, tile_size, world, group=None):
+    """(round 4: the GROUP is part of the key -- a rank that sits in two groups of one size keeps a plan and a frame
+    counter per group, so that the ranks of either group count the same frames)"""
     import math
     n = means3d.shape[0]
-    return (means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H, tile_size, world)
+    return (means3d.device, round(math.log2(n) * 8) if n > 0 else -1, camera.W, camera.H, tile_size, world,
+            None if group is None else id(group))
 
 
-def band_bounds(means3d, camera, tile_size, world):
+def _bounds_hash(bounds):
+    h = 1469598103934665603
+    for b in bounds:
+        h = ((h ^ int(b)) * 1099511628211) & 0x7fffffff
+    return h
+
+
+def band_bounds(means3d, camera, tile_size, world, group=None):
     """The band boundaries (tile rows) the next sharded frame of this scene uses -- equal bands until the ranks'
     pair counts say otherwise."""
     th = -(-camera.H // tile_size)
-    p = _plans.get(_plan_key(means3d, camera, tile_size, world))
+    p = _plans.get(_plan_key(means3d, camera, tile_size, world, group))
     if p is not None:
         return list(p["bounds"])
     rows, bands = band_plan(th, world)
@@ -204,7 +214,8 @@ def _band_learn(key, mode, m, info, camera, band):
 
 def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size, band, out, out_y0=None):
     """Render tile rows `band` into `out` (the full framebuffer, or -- out_y0 given -- a slab whose first row is image
-    row out_y0); -> (Gaussians touching the full grid (0 = empty frame), pairs in the band)."""
+    row out_y0); -> (Gaussians touching the full grid (0 = empty frame), pairs in the band, whether the library
+    pre-culled the band -- the first number then counts the Gaussians that reach THIS band)."""
     r0, r1 = band
     H, W = camera.H, camera.W
     th, tw = -(-H // tile_size), -(-W // tile_size)
@@ -218,12 +229,12 @@ def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg
         _, m = render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, mode,
                               row_range=b, out=out, info=info, rows16=(tile_size == 16), out_y0=out_y0)
         _band_learn(key, mode, m, info, camera, b)
-        return info["on_grid"], m
+        return info["on_grid"], m, bool(info["flags"] & 2048)
     means2d, conics, depths, radii = stages.project(means3d, scales, quats, opacities, camera)
     ids, ranges = stages.bin(means2d, radii, depths, tile_size, tw, th, band)
     if r1 > r0:
         stages.raster(means2d, conics, features, opacities, bg, ranges, ids, camera, tile_size, band, out)
-    return _on_grid_count(means2d, radii, tile_size, tw, th), int(ids.numel())
+    return _on_grid_count(means2d, radii, tile_size, tw, th), int(ids.numel()), False
 
 
 class PendingFrame:
@@ -309,9 +320,9 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
 
     # ---- this frame's bands: equal until the ranks' pair counts say otherwise (rebalance, module docstring)
     live = world > 1 and rehearse is None                 # a real process group: status records are exchanged
-    pkey = _plan_key(means3d, camera, tile_size, world)
+    pkey = _plan_key(means3d, camera, tile_size, world, group)
     if bounds is None:
-        bounds = band_bounds(means3d, camera, tile_size, world)
+        bounds = band_bounds(means3d, camera, tile_size, world, group)
     assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == th and all(a <= b for a, b in zip(bounds, bounds[1:]))
     bands = [(bounds[r], bounds[r + 1]) for r in range(world)]
     rows_max = max(b - a for a, b in bands)
@@ -332,7 +343,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     # 16-byte status record per rank -- (Gaussians on the grid, pairs in the band) -- beside the framebuffer; every
     # rank always takes part in both collectives.  (Injected CPU stages count the on-grid Gaussians over ALL of
     # them, but exchange the record all the same: the pair counts steer the band boundaries.)
-    def exchange(buf, on_grid, m_band):
+    def exchange(buf, on_grid, m_band, culled=False):
         """-> (image or a callable that yields it, [works]): the exchange step, or the frame-level zeros rule."""
         if not live:
             if rehearse is not None and stages is None and world > 1:
@@ -343,11 +354,19 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
             if on_grid == 0:
                 return torch.zeros(H, W, C, device=dev, dtype=torch.float32), []   # zeros, not background (render.py:73-76)
             return buf[:H], []
-        # (the weight the plan balances on: a pre-culled HIP band reports the Gaussians that reach IT -- comparable
-        # across ranks whatever bin size each one runs on, which pair counts are not; else the band's pairs)
-        culled = stages is None and C == 3 and means3d.shape[0] >= 32768 and 10 * (bands[rank][1] - bands[rank][0]) < 6 * th
-        status = torch.tensor([on_grid, on_grid if culled else m_band], dtype=torch.int64, device=dev)
-        status_all = torch.empty((world, 2), dtype=torch.int64, device=dev)
+        # The status record, 32 bytes per rank: Gaussians on the grid (the zeros-image rule's OR); the Gaussians that reach
+        # the band if the LIBRARY pre-culled it (it says so in the size record's flag word: bit 11), else -1; the band's
+        # pairs; and this rank's frame counter of the plan with a hash of the bounds it rendered with.  Round 3 sent one
+        # weight whose unit each rank chose from a Python copy of the library's pre-cull test: ragged bands could make one
+        # rank report Gaussians and another pairs, and the plan oscillated.  Now the unit is chosen from what ALL ranks
+        # report (Gaussians only if every band was pre-culled).  The plans and their counters are kept per GROUP (a rank in
+        # two groups of one size counted both groups' frames on one counter and re-planned on other frames than its
+        # peers); the stamps are compared on the frames that re-plan and a mismatch raises instead of drifting on.
+        plan = _plans.setdefault(pkey, dict(bounds=list(bounds), frame=0))
+        plan["frame"] += 1
+        stamp = (plan["frame"] << 32) | _bounds_hash(bounds)
+        status = torch.tensor([on_grid, on_grid if culled else -1, m_band, stamp], dtype=torch.int64, device=dev)
+        status_all = torch.empty((world, 4), dtype=torch.int64, device=dev)
         works = [dist.all_gather_into_tensor(status_all.view(-1), status, group=group, async_op=True)]
         if mode == "direct":
             ops = []
@@ -365,8 +384,6 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         else:
             works.append(dist.all_gather_into_tensor(buf[:world * slab], buf[rank * slab:(rank + 1) * slab],
                                                      group=group, async_op=True))
-        plan = _plans.setdefault(pkey, dict(bounds=list(bounds), frame=0))
-        plan["frame"] += 1
         check = _balance_enabled() and plan["bounds"] == list(bounds) and \
             plan["frame"] % (_CHECK_SETTLED if plan.get("settled") else _CHECK_EVERY) == 0
 
@@ -378,8 +395,17 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                 return frame
             rec = status_all.cpu()
             if check:
+                stamps = [int(v) for v in rec[:, 3]]
+                if any(v != stamps[0] for v in stamps):
+                    # (cannot happen while every rank of the group makes the same sequence of sharded calls -- the plans
+                    # and their frame counters are kept per group -- so this is a caller's bug, and silence would end in
+                    # collectives of different sizes)
+                    raise RuntimeError(f"render_gaussians_sharded: the ranks of this group lost step (frame counter / "
+                                       f"band bounds stamps {stamps}); every rank must make the same sharded calls")
                 # identical numbers on every rank -> identical new bounds on every rank, from the next frame on
-                nb, spread = rebalance(list(bounds), [int(v) for v in rec[:, 1]])
+                by_gaussians = all(int(v) >= 0 for v in rec[:, 1])
+                weights = [int(v) for v in (rec[:, 1] if by_gaussians else rec[:, 2])]
+                nb, spread = rebalance(list(bounds), weights)
                 plan["settled"] = spread <= _SPREAD_OK
                 if not plan["settled"]:
                     plan["bounds"] = nb
@@ -403,13 +429,13 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         buf = framebuffer()
         if padded and stages is not None:
             tmp = torch.empty((H, W, C), dtype=torch.float32, device=dev)     # (CPU test stages address the full image)
-            on_grid, m_band = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                                           bands[rank], tmp)
+            on_grid, m_band, culled = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                                                   bands[rank], tmp)
             buf[rank, :y1s[rank] - y0s[rank]] = tmp[y0s[rank]:y1s[rank]]
         else:
-            on_grid, m_band = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
-                                           bands[rank], buf[rank] if padded else buf, y0s[rank] if padded else None)
-        img, works = exchange(buf, on_grid, m_band)
+            on_grid, m_band, culled = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                                                   bands[rank], buf[rank] if padded else buf, y0s[rank] if padded else None)
+        img, works = exchange(buf, on_grid, m_band, culled)
         if not async_op:
             return resolve(img, works)
         return PendingFrame(finalize=lambda: resolve(img, works))
@@ -454,7 +480,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         now = _current_stream(dev)
         ev_out.record(s)
         now.wait_event(ev_out)       # the band is complete before the exchange starts
-        img, works = exchange(buf, info["on_grid"], m)   # the collectives' stream waits for `now`
+        img, works = exchange(buf, info["on_grid"], m, bool(info["flags"] & 2048))   # the collectives' stream waits for `now`
         return resolve(img, works)                       # ... and `now` for the exchange
     return PendingFrame(finalize=finalize)
 
