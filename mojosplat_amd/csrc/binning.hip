@@ -66,11 +66,6 @@ constexpr int kMaxG = 512;
 constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
 constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
 constexpr int kBandCull = 32;      // bit of the `tight` flags: the band's Gaussians were pre-culled (k_band_precull)
-#ifdef MS_NO_LEAN12
-constexpr bool kLean12Enabled = false;   // (variant builds: A/B against the 16 + 8 byte form)
-#else
-constexpr bool kLean12Enabled = true;
-#endif
 constexpr int kLightBucket = 32;   // length bucket (4 per octave) of the longest LIGHT list: 255 entries
 constexpr int kLightCap = 256;     // ... sorted by ONE wave (sort_segment_lds<64, 4>), eight lists to a workgroup
 constexpr int kLean = 64;          // ... the frame keeps LeanRecs instead of the projected arrays (internal: ms_render_fwd)
@@ -157,12 +152,8 @@ __device__ __forceinline__ unsigned long long reach_mask(float mx, float my, flo
 // EIGHTH of the chunks makes one L2 own whole stretches of every segment, so lines are completed before they are
 // written back.  Any bijection is correct (both kernels use the same one); the XCD placement is speed only.
 __device__ __forceinline__ int chunk_of_block(int b, int G) {
-#ifdef MS_NO_CHUNK_REMAP
-    return b;
-#else
     const int n8 = G >> 3, rem = G & 7, x = b & 7, k = b >> 3;
     return x * n8 + min(x, rem) + k;
-#endif
 }
 
 __device__ __forceinline__ int clampi(float v, int lo, int hi) {
@@ -687,11 +678,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             }, dbits_of_step);
             // (boxes the whole wave walked: kept whatever the cut-offs say -- their owner does not know)
             const bool keep = near32 != 0u || n > kCoopThreshold;
-#ifndef MS_K1_ALL_RECORDS
             if (rec_pending && keep) write_record(base, (uint32_t)threadIdx.x, rec_m0, rec_m1, rec_c0, rec_c1, rec_c2);
-#else
-            if (rec_pending) write_record(base, (uint32_t)threadIdx.x, rec_m0, rec_m1, rec_c0, rec_c1, rec_c2);
-#endif
             const unsigned long long kb = __ballot(keep);
             if (kb) {
                 const int lane = threadIdx.x & 63;
@@ -1891,7 +1878,7 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
 bool ms::depth_cut_fits(int64_t N, int tile_w, int tile_h) {
     Plan p;
     if (!make_plan(N, tile_w, tile_h, 0, tile_h, p)) return false;
-    return kLean12Enabled && tile_w <= 255 && tile_h <= 255 && N > 0 && N < (1ll << 28) &&
+    return tile_w <= 255 && tile_h <= 255 && N > 0 && N < (1ll << 28) &&
            p.lds_bytes + (size_t)p.T_local * 5 + 16 <= kMaxLds;
 }
 
@@ -2183,7 +2170,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
         // scans read must exist
         // lean frame: LeanRecs instead of the projected arrays (the caller vouches that nobody reads those)
         const bool lean = (tight & kLean) && raster_records && masks && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
-        const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255 && kLean12Enabled;
+        const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255;
         auto kernel = pack ? (lean ? k_project_hist<true, 1> : k_project_hist<true, 0>)
                            : (lean12 ? (cut_stamp ? k_project_hist<false, 2, true> : k_project_hist<false, 2>)
                                      : lean ? k_project_hist<false, 1> : k_project_hist<false, 0>);
@@ -2241,7 +2228,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
 
     {
         const bool lean = (tight & kLean) && masks && tile_w <= 0xffff && tile_h <= 0xffff && N < (1ll << 28);
-        const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255 && kLean12Enabled;
+        const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255;
         const bool deferred = defer && p.T_local > 0;
         ScanTotalArgs A{};
         if (deferred) {
@@ -2320,8 +2307,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
             const int fixed_shift = fp.fixed_shift, front_k = fp.front_k, front_cap = fp.front_cap;
             size_t front_lds = kFrontLds - (size_t)(kFrontCap - front_cap) * 8;
             // (merged launch: room for eight waves' private sorts of light lists)
-            static const bool light_env = [] { const char *e = getenv("MOJOSPLAT_LIGHT_SORT"); return !e || atoi(e) != 0; }();
-            const bool light = merged && light_env;
+            const bool light = merged;
             if (light && front_lds < 8 * SortCfg<64, kLightCap / 64>::LDS) front_lds = 8 * SortCfg<64, kLightCap / 64>::LDS;
             hipLaunchKernelGGL(front, dim3(merged ? (unsigned)p.T_local : grid), dim3(kFrontThreads), front_lds, stream,
                                medium, large, xl,

@@ -90,32 +90,6 @@ static int ms_order_enabled() {
     return v;
 }
 
-// MOJOSPLAT_LEAN=0: keep writing the projected arrays on frames whose rasteriser reads the ready-made records
-static int ms_lean_enabled() {
-    static const int v = [] {
-        const char *e = getenv("MOJOSPLAT_LEAN");
-        return e ? atoi(e) != 0 : 1;
-    }();
-    return v;
-}
-
-static int ms_lean_aux_enabled() {
-    static const int v = [] {
-        const char *e = getenv("MOJOSPLAT_LEAN_AUX");
-        return e ? atoi(e) != 0 : 1;
-    }();
-    return v;
-}
-
-// MOJOSPLAT_DEFER_TOTAL=0: the scans' total pass as a pass of its own on sync-free frames too
-static int ms_defer_enabled() {
-    static const int v = [] {
-        const char *e = getenv("MOJOSPLAT_DEFER_TOTAL");
-        return e ? atoi(e) != 0 : 1;
-    }();
-    return v;
-}
-
 // MOJOSPLAT_DEPTH_CUT=0: never drop the pairs behind a bin's depth cut-off (binning.hip, k_project_hist); 2: take the
 // cut on every frame that can, however few pairs it holds (measurements, tests)
 static int ms_depth_cut_mode() {   // (read per frame: tests and measurements switch it inside one process)
@@ -128,19 +102,12 @@ static int64_t ms_depth_cut_min_pairs() {
     const long long n = e ? atoll(e) : -1;
     return (int64_t)(n >= 0 ? n : 6000000ll);
 }
-// workgroups of the clean-up launch (MOJOSPLAT_REDO_GRID: measurements).  Rounds 1-2 launched ONE while recent frames had
-// needed no clean-up ("an empty 64-workgroup launch costs 4.5 us, a one-workgroup one 2"): measured again in round 3 the
-// frame costs the same with 1, 8, 16, 64, 128 or 256 of them (0.1678-0.1681 ms at config 3) -- what costs is the kernel
-// boundary -- while the first frames that DO need the pass (the count reaches the host a frame late) ran their hundreds
-// of bins through one workgroup: 7-14 s a frame at configs 4 / 5 after a scene swap.  256, always.
-static int ms_redo_grid() {
-    static const int v = [] {
-        const char *e = getenv("MOJOSPLAT_REDO_GRID");
-        const int n = e ? atoi(e) : 0;
-        return (n >= 1 && n <= 4096) ? n : 256;
-    }();
-    return v;
-}
+// workgroups of the clean-up launch: 256, always.  (Rounds 1-2 launched ONE while recent frames had needed no clean-up;
+// measured in round 3, the frame costs the same with 1 ... 256 of them -- 0.1678-0.1681 ms at config 3: what costs is the
+// kernel boundary -- while the first frames that DO need the pass ran their hundreds of bins through one workgroup: 7-14 s
+// a frame at configs 4 / 5 after a scene swap.  Round 4: 1024 change nothing either -- 70 against 72 ms for that frame: its
+// time is the heaviest bin's sixteen blocks, one after the other in one workgroup.)
+static int ms_redo_grid() { return 256; }
 static int ms_merged_sort_enabled() {   // (binning.hip reads the same variable)
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_MERGED_SORT");
@@ -284,11 +251,9 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
     // band's candidate list, which index the workspace's dense projected arrays and records, not the caller's)
     // lean frame: nobody reads the projected arrays (the rasteriser and the clean-up pass stage from the records,
     // the scatter kernel from the 16-byte box + depth records the count kernel leaves instead)
-    // (a differentiable frame keeps its arrays -- the backward and the caller's intermediates read them -- and leaves the
-    // records for its scatter kernel as well: MOJOSPLAT_LEAN_AUX=0 switches that off)
     // (the projected arrays are for the OLDER backward -- last_ids frames -- and the caller's intermediates; the quad-wave
     // backward stages from the records and its backward projection takes the raw sums: nothing reads them)
-    const int lean = (use_records && ((uintptr_t)records & 15) == 0 && ms_lean_enabled() && (!aux_frame || ms_lean_aux_enabled()))
+    const int lean = (use_records && ((uintptr_t)records & 15) == 0)
                          ? ms::kTightLean | (last_ids ? ms::kTightKeepArrays : 0) : 0;
     const int cull = ((use_records && !aux_frame && N >= 32768 && N < (1ll << 28) && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0) | lean;
     const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0) | cull;
@@ -320,7 +285,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         const int64_t cap = split ? (isect_bytes > 768 ? (int64_t)((isect_bytes - 768) / 28) : 0)
                                   : (isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0);
         const bool speculate = sync_event && isect_buf && cap > 0 && N > 0;   // (an empty set has null inputs: exact path, M = 0)
-        const bool deferred = speculate && mirror && (split ? b1 > b0 : r1 > r0) && ms_defer_enabled();
+        const bool deferred = speculate && mirror && (split ? b1 > b0 : r1 > r0);
         // the previous frame on this record (same scratch, same grid) had no tile beyond the small sort class:
         // bet that this one has none either (bit 5 of host_info[7]; checked against the size record below)
         const bool bet_light = !split && lazy && prev[0] > 0 && prev[2] + prev[3] + prev[4] == 0 && !(prev[7] & 4);

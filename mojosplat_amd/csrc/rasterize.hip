@@ -552,17 +552,12 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? M
         tile = by16 * A.tw + bx16;
         sub = 0;
     } else if (A.order) {
-#ifdef MS_RASTER_SUBS_APART
-        tile = A.order[wg / A.nsub];
-        sub = wg % A.nsub;
-#else
         // the nsub 16x16 blocks of a coarse tile on ONE XCD (wg & 7 labels it), back to back: they gather the
         // same records, so the tile's list and records cross into that L2 once instead of nsub times
         const int e = ((wg >> 3) / A.nsub) * 8 + (wg & 7);
         if (e >= A.nblocks / A.nsub) return;   // (uniform per workgroup; the grid is padded to 8 tiles)
         tile = A.order[e];
         sub = (wg >> 3) % A.nsub;
-#endif
     } else {
         const int item = xcd_remap(wg, A.nblocks);
         const int bt = item / A.nsub;
@@ -1088,9 +1083,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.parts = choose_parts(blocks, density_hint, A.records != nullptr, ((tile_size == 32 && blocks >= 8000) || (tile_size == 64 && blocks >= 16384)) && !last_ids && lazy != nullptr);
     A.nblocks = (int)blocks;
     A.ngrid = (int)blocks;
-#ifndef MS_RASTER_SUBS_APART
     if (order) A.ngrid = ((band_tiles + 7) / 8) * 8 * A.nsub;   // tiles dealt over the 8 XCDs, each with its nsub blocks
-#endif
     A.max_isects = (int)M;
     MS_REQUIRE(N > 0 || M == 0, MS_ERR_INVALID_ARG, "rasterize_fwd: M > 0 with N == 0");
     A.n_gauss = (int)(N < 0x7fffffffll ? (N > 0 ? N : 1) : 0x7fffffffll);

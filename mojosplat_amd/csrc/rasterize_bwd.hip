@@ -653,16 +653,8 @@ int ms::rasterize_bwd(
         // waves per block: ONE (measured at config 3, forward + backward step, with the heaviest-first order:
         // 1 wave 0.698 ms, 2 waves 0.732, 4 waves 0.832 -- each wave stages the list from four arrays and the
         // per-entry reduction + flush does not shrink with the quads; without the order 1 wave: 0.779).
-        // MOJOSPLAT_BWD_PARTS=1|2|4 pins it (measurements).
-        static const int forced = [] { const char *e = getenv("MOJOSPLAT_BWD_PARTS"); const int n = e ? atoi(e) : 0; return (n == 1 || n == 2 || n == 4) ? n : 0; }();
-        const int parts = forced ? forced : 1;
-        const dim3 grid2((unsigned)(parts > 1 ? ((blocks + 7) / 8) * 8 * parts : blocks));
-#define MS_LAUNCH_BWD(CPV, RECV)                                                                              \
-    do {                                                                                                       \
-        if (parts == 4) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 1, RECV>), grid2, dim3(64), 0, st, B2);      \
-        else if (parts == 2) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 2, RECV>), grid2, dim3(64), 0, st, B2); \
-        else hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 4, RECV>), grid2, dim3(64), 0, st, B2);                 \
-    } while (0)
+        const dim3 grid2((unsigned)blocks);
+#define MS_LAUNCH_BWD(CPV, RECV) hipLaunchKernelGGL((k_rasterize_bwd_v2<CPV, 4, RECV>), grid2, dim3(64), 0, st, B2)
         if (CDIM == 3 && B2.records) MS_LAUNCH_BWD(3, true);
         else if (CDIM <= 3) MS_LAUNCH_BWD(3, false);
         else MS_LAUNCH_BWD(4, false);

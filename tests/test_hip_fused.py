@@ -145,6 +145,9 @@ def test_host_threads_render_concurrently_on_their_own_scratch(device):
         jobs.append((sc, cam, stagewise(sc, cam, bg, 16)))
     torch.cuda.synchronize()
     errors, scratch = [], []
+    # (every thread keeps its scratch until all have reported theirs: a thread that has exited returns its blocks to the
+    # allocator, which may hand the same address to a later one -- the comparison below would then see a "shared" pointer)
+    alive = threading.Barrier(len(jobs), timeout=120)
 
     def work(sc, cam, ref):
         try:
@@ -157,6 +160,11 @@ def test_host_threads_render_concurrently_on_their_own_scratch(device):
             scratch.append(_fused._dev_state(g[0].device, 0)["ws"].data_ptr())
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
+        finally:
+            try:
+                alive.wait()
+            except threading.BrokenBarrierError:
+                pass
 
     threads = [threading.Thread(target=work, args=j) for j in jobs]
     for t in threads:
