@@ -9,5 +9,5 @@ for set in "SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
   rm -rf /tmp/pmcv
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcv -- python3 $R/scripts/bwd_probe.py > /dev/null 2> /tmp/pmcv.err || { echo "set failed: $set"; tail -3 /tmp/pmcv.err; continue; }
-  python3 $R/scripts/pmc_summary.py $(find /tmp/pmcv -name "*counter_collection.csv" | head -1) | grep "k_rasterize_bwd_quads"
+  python3 $R/scripts/pmc_summary.py $(find /tmp/pmcv -name "*counter_collection.csv" | head -1) | grep "k_rasterize_bwd_"
 done
