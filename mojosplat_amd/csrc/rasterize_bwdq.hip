@@ -6,26 +6,33 @@
 //
 // Why another shape (profiles/r04_bwd_pmc.md): k_rasterize_bwd_v2 issues 191 M vector instructions per config-3 frame for
 // 1.3 M walked (block, entry) pairs -- ~50 per (quad, entry) evaluation plus ~45 for the wave reduction of nine sums
-// and ~20 of walk -- at 3.9 waves per SIMD: 281 us.  Here
+// and ~20 of walk -- at 3.9 waves per SIMD: 281 us; and it walks by POSITION from last_ids back, so its forward had to
+// sort every list in full (250 us of forward against the inference frame's 165).  Here
 //   * the walk is the FORWARD kernel's (rasterize.hip, raster_tile): per-quad compacted record streams in LDS, two records
 //     per trip, exp2 with log2(opacity) in the FMA chain, the alpha >= 1/255 select by underflow, the transmittance
-//     carried as S = T * 2^126, one stop test per pair.  Walking front to back needs no division to recover T and no
-//     per-entry index compare; what lies BEHIND an entry comes from the frame's own output:
+//     carried as S = T * 2^126, one stop test per pair.  It walks whatever lists the forward walked -- lazily sorted
+//     fronts on the binning rule's grid included -- so a differentiable frame IS an inference frame that keeps its alphas.
+//     Walking front to back needs no division to recover T and no per-entry index compare; what lies BEHIND an entry
+//     comes from the frame's own output:
 //         sum_{s > t} Cd_s w_s = v . (C - T_final bg) - sum_{s <= t} Cd_s w_s,      Cd_s = colour_s . v   (v = dL/dC of the pixel)
 //     so that   dL/dalpha_t (1 - alpha_t) = Cd_t T_t + Q_{t-1},   Q_t = T_final (v_a - bg . v) - v . (C - T_final bg) + sum_{s <= t} Cd_s w_s
 //     is one FMA on a running scalar per pixel;
 //   * the nine per-entry sums over the quad's 64 pixels are a GEMM: with x, y the pixel's offset from the quad centre,
 //         [sum vs, sum vs x, sum vs y, sum vs x^2, sum vs xy, sum vs y^2] = VS[entry][pixel] . MONO[pixel][6]
 //         [sum w v_r, sum w v_g, sum w v_b]                               = W[entry][pixel] . V[pixel][3]
-//     (vs = dL/dsigma of the pair, w = alpha T).  Every lane leaves vs and w of eight entries in an LDS tile
-//     Y[16 rows][64 pixels]; sixteen v_mfma_f32_16x16x4_f32 (exact fp32, K = the 64 pixels) with the per-lane constants
-//     MONO | V as the B operand turn it into the 8 x 9 sums -- ~0.5 LDS reads and two matrix instructions per entry on
-//     the vector side instead of a 45-instruction shuffle tree, and the matrix pipe runs beside the vector pipe;
+//     (vs = dL/dsigma of the pair, w = alpha T).  Every lane leaves vs and 255 w of eight entries in an LDS tile
+//     Y[16 rows][64 pixels], each value as TWO bf16 terms in one dword (hi = the float cut to 8 mantissa bits, lo = the
+//     exact remainder cut likewise: 16 significant bits, 2^-17 relative), and four v_mfma_f32_16x16x32_bf16 (K = 64
+//     pixels x 2 terms, fp32 accumulation) with the per-lane constants MONO | V_hi | V_lo as the B operand turn the tile
+//     into the 8 x 9 sums.  MONO is exact in bf16 (half-integers up to 3.5 and their products); dL/dC is split like the A
+//     values.  [The first cut used v_mfma_f32_16x16x4_f32 -- exact, sixteen per tile: 307 us.  An fp32 MFMA runs at the
+//     vector rate and, measured, does not overlap the vector pipe's work here; the bf16 form costs a quarter of the
+//     issue time and six vector instructions per evaluation for the split: 274 us.]
 //   * eight lanes move the moments from the quad centre to the Gaussian's mean (dx = u - x, u = mean - centre), and the
-//     totals leave as ONE 64-byte row per (quad, entry): contiguous float atomics, two instructions per eight entries.
+//     totals leave as ONE 64-byte row per (quad, entry): contiguous float atomics, two instructions per eight entries
+//     (2.5 M rows at config 3; the memory side takes 20.8 G rows / s whatever their fill: scripts/ubench/atomic_grad_rows.hip).
 //     The backward projection finishes means / conics / opacity from the raw sums (project_bwd.hip, ROWS = 2).
 #include <stdlib.h>
-#include <string.h>
 
 #include <type_traits>
 
@@ -39,9 +46,6 @@ constexpr int kTile = 8;       // entries per matrix tile (rows 0-7 of Y: vs, ro
 constexpr int kYStride = 68;   // floats per row of Y: the A fragments are read as ds_read_b128 at (row, 16 g + 4 i)
 constexpr int kRowQ = 16;      // floats per packed gradient row: gx gy s1 s2 s3 m0 c0 c1 c2 - ...
 constexpr int kSlots = kTile + kBatch + kGroup;
-#ifndef MS_BWD_DEFAULT
-#define MS_BWD_DEFAULT 0   // which kernel MOJOSPLAT_BWD_KERNEL's absence picks: 0 mfma, 1 tree, 2 tree2
-#endif
 #ifndef MS_BWDQ_ABLATE
 #define MS_BWDQ_ABLATE 0
 #endif
@@ -476,285 +480,6 @@ __global__ __launch_bounds__(64, MS_BWDQ_WAVES) void k_rasterize_bwd_quads(BwdQA
     bwd_quad(A, tile, sub, part, s_stage);
 }
 
-// ---- the same walk, one wave per 16x16 BLOCK, per-entry sums by a shuffle tree ------------------------------------------
-// (MOJOSPLAT_BWD_KERNEL=tree; profiles/r04_bwd_pmc.md has both.)  What the matrix kernel above buys with its tile of
-// eight entries it pays for in LDS and registers: 7.8 KB and 96 VGPRs a wave hold a SIMD to four or five waves, and the
-// kernel's time follows 1 / waves down to there.  This shape keeps round 3's economy instead -- a lane carries the same
-// pixel of each of the block's NQ quads, so an entry's nine sums are added up over the quads in registers first and ONE
-// wave reduction serves the whole block, and a Gaussian leaves one row per BLOCK, not per quad (1.0 M rows against
-// 2.5 M at config 3) -- with this round's arithmetic: front to back (no division to recover T, no index compare per
-// evaluation), the select by underflow, the running scalar Q, direct sums of vs dx^k dy^l (no moment shift), and a
-// reduction whose first two levels are v_permlane32_swap / v_permlane16_swap (two registers halve into one in two
-// instructions; gfx950) and whose last four are DPP adds inside the 16-lane rows: 28 instructions for nine values
-// where round 3's tree took 34 + two ds_bpermute round trips.
-constexpr int kTreeRow = 12;   // floats per staged gradient row in LDS: the nine sums (+ pad)
-
-template <int NQ>
-struct BwdTStage {
-    float4 a[kBatch];     // mean.x, mean.y, a', b'
-    float4 b[kBatch];     // c', log2(opacity), r, g
-    float2 c[kBatch];     // b, Gaussian index (bits)
-    __attribute__((aligned(16))) float grad[kBatch * kTreeRow];
-};
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-// two registers -> one: lanes 0-31 get a's sum over (l, l + 32), lanes 32-63 get b's
-__device__ __forceinline__ float halve32(float a, float b) {
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// ... rows (16 lanes) 0 / 2 get a's sums over its row pairs (0, 1) / (2, 3), rows 1 / 3 get b's
-__device__ __forceinline__ float halve16(float a, float b) {
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// every lane of a 16-lane row gets the row's sum
-__device__ __forceinline__ float row_sum16(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));   // row_ror:4
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-    return v;
-}
-
-template <int NQ>
-__global__ __launch_bounds__(64, (NQ == 4 ? 6 : 8)) void k_rasterize_bwd_tree(BwdQArgs A) {
-    constexpr float kInf = __builtin_huge_valf();
-    constexpr int kParts = 4 / NQ;
-    __shared__ BwdTStage<NQ> S;
-    int wg = blockIdx.x, part = 0;
-    if constexpr (kParts > 1) {
-        const int j = blockIdx.x >> 3;
-        part = j % kParts;
-        wg = ((j / kParts) << 3) | (blockIdx.x & 7);
-    }
-    if (wg >= A.ngrid) return;
-    int tile, sub;
-    if (A.order) {
-        const int e = ((wg >> 3) / A.nsub) * 8 + (wg & 7);
-        if (e >= A.ntiles) return;
-        tile = A.order[e];
-        sub = (wg >> 3) % A.nsub;
-    } else {
-        if (wg >= A.ntiles * A.nsub) return;
-        tile = wg / A.nsub;
-        sub = wg - tile * A.nsub;
-    }
-    if (A.skip_flag && A.skip_flag[tile]) return;
-    const int qbase = part * NQ;
-    const int lane = threadIdx.x & 63;
-    const int lx = lane & 7, ly = lane >> 3;
-    const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
-    const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
-    const int bx = tile_x * A.ts + sub_x * 16, by = tile_y * A.ts + sub_y * 16;
-    if (bx >= A.W || by >= A.H) return;
-    const int end_all = min(A.tile_ranges[2 * tile + 1], A.max_isects);
-    const int start = min(A.tile_ranges[2 * tile], end_all);
-    int end = end_all;
-    if (A.front_count && end_all - start > A.front_threshold) end = start + min(A.front_count[tile], end_all - start);
-    if (end <= start) return;
-
-    // ---- the lane's NQ pixels
-    float vo[NQ][3], Q[NQ], kq[NQ], T[NQ];
-    const float px0 = (float)(bx + lx) + 0.5f, py0 = (float)(by + ly) + 0.5f;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int qq = qbase + q;
-        const int ox = sub_x * 16 + lx + (qq & 1) * 8, oy = sub_y * 16 + ly + (qq >> 1) * 8;
-        const int X = bx + lx + (qq & 1) * 8, Y = by + ly + (qq >> 1) * 8;
-        const bool in = ox < A.ts && oy < A.ts && X < A.W && Y < A.H;
-        const size_t p = in ? (size_t)Y * A.W + X : 0;
-        float Tf = 1.0f, va = 0.f, C[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) vo[q][k] = 0.f;
-        if (in) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { vo[q][k] = A.v_render_colors[p * 3 + k]; C[k] = A.render_colors[p * 3 + k]; }
-            Tf = 1.0f - A.render_alphas[p];
-            if (A.v_render_alphas) va = A.v_render_alphas[p];
-        }
-        float bg_dot = 0.f, ptot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float bg = A.backgrounds ? A.backgrounds[k] : 0.f;
-            bg_dot += bg * vo[q][k];
-            ptot += vo[q][k] * (C[k] - Tf * bg);
-        }
-        Q[q] = 255.0f * (Tf * (va - bg_dot) - ptot);
-        kq[q] = in ? ms::kFlushK : 0.f;
-        T[q] = ms::kTScale;
-    }
-    __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 0);   // fp32 denormals flushed (the select by underflow)
-
-    float4 r_a, r_b, r_c;
-    int id_next, g_staged;
-    auto fetch_id = [&](int b0) {
-        const int idx = min(b0 + lane, end - 1);
-        id_next = A.ids[(size_t)idx * A.id_stride];
-    };
-    auto gather = [&]() {
-        g_staged = min(max(id_next, 0), A.n_gauss - 1);
-        const float4 *rec = A.records + 3 * (size_t)g_staged;
-        r_a = rec[0]; r_b = rec[1]; r_c = rec[2];
-    };
-    // which column of a staged row this lane stores after the reduction: rows of s0 hold sums (0, 2, 1, 3), of s1 (4, 6, 5, 7)
-    const int col_s0 = (lane >> 4) == 0 ? 0 : (lane >> 4) == 1 ? 2 : (lane >> 4) == 2 ? 1 : 3;
-    const bool row_head = (lane & 15) == 0;
-    const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
-    unsigned long long alive_q = 0ull;   // bit q: some pixel of quad q can still blend
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) alive_q |= __any(kq[q] != 0.f) ? (1ull << q) : 0ull;
-
-    fetch_id(start);
-    gather();
-    fetch_id(start + kBatch);
-    for (int b0 = start; b0 < end && alive_q; b0 += kBatch) {
-        int mask = 0;
-        bool npd = false;
-        if (b0 + lane < end) {
-            const float smax = r_c.y, nb_c = r_c.z, nb_a = r_c.w;
-            if (smax == kInf) {
-                mask = (1 << NQ) - 1;
-                npd = true;
-            } else if (smax > -kInf) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int qq = qbase + q;
-                    const float xl = fbx + (float)((qq & 1) * 8) - r_a.x, xh = xl + 7.0f;
-                    const float yl = fby + (float)((qq >> 1) * 8) - r_a.y, yh = yl + 7.0f;
-                    const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
-                    float best = (in_x && in_y) ? 0.f : 3.0e38f;
-                    if (!in_x) {
-                        const float dx = xl > 0.f ? xl : xh;
-                        const float dy = fminf(fmaxf(nb_c * dx, yl), yh);
-                        best = -(r_a.z * dx * dx + r_b.x * dy * dy + r_a.w * dx * dy);
-                    }
-                    if (!in_y) {
-                        const float dy = yl > 0.f ? yl : yh;
-                        const float dx = fminf(fmaxf(nb_a * dy, xl), xh);
-                        best = fminf(best, -(r_a.z * dx * dx + r_b.x * dy * dy + r_a.w * dx * dy));
-                    }
-                    mask |= (best <= smax) ? (1 << q) : 0;
-                }
-            }
-        }
-        unsigned long long Bq[NQ], U = 0ull;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            Bq[q] = ((alive_q >> q) & 1ull) ? __ballot((mask >> q) & 1) : 0ull;
-            U |= Bq[q];
-        }
-        const bool check_sigma = __ballot(npd) != 0;
-        wave_lds_sync_q();   // the previous batch's flush has read grad / c
-        if (mask) {
-            S.a[lane] = r_a;
-            S.b[lane] = r_b;
-            S.c[lane] = make_float2(r_c.x, __int_as_float(g_staged));
-        }
-        wave_lds_sync_q();
-        if (b0 + kBatch < end) {
-            gather();
-            fetch_id(b0 + 2 * kBatch);
-        }
-
-        unsigned long long flush = 0ull;
-        auto walk = [&](auto check) __attribute__((always_inline)) {
-            constexpr bool CHECK = decltype(check)::value;
-            while (U) {
-                const int t = __builtin_ctzll(U);
-                U &= U - 1ull;
-                const float4 ra = S.a[t];
-                const float4 rb = S.b[t];
-                const float blue = S.c[t].x;
-                float acc[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) acc[j] = 0.f;
-                unsigned long long anyv = 0ull;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (!((Bq[q] >> t) & 1ull)) continue;   // wave-uniform
-                    const int qq = qbase + q;
-                    const float dx = ra.x - (px0 + (float)((qq & 1) * 8)), dy = ra.y - (py0 + (float)((qq >> 1) * 8));
-                    const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
-                    float al = __builtin_amdgcn_exp2f(la);
-                    bool clamped = false;
-                    if constexpr (CHECK) {
-                        clamped = al > ms::kMaxAlpha;
-                        al = fminf(ms::kMaxAlpha, al);
-                        al = la <= rb.y ? al : 0.f;
-                    }
-                    float m = al * kq[q];
-                    asm volatile("" : "+v"(m));
-                    float v = m * T[q];
-                    const float tin = T[q];
-                    float nt = fmaf(v, -ms::kAlphaOfV, tin);
-                    if (__ballot(!(nt > ms::kTransmittanceStop * ms::kTScale))) {   // rare: a pixel stops BEFORE this entry
-                        asm volatile("" ::: "memory");
-                        const bool dead = !(nt > ms::kTransmittanceStop * ms::kTScale);
-                        v = dead ? 0.f : v;
-                        m = dead ? 0.f : m;
-                        nt = dead ? tin : nt;
-                        kq[q] = dead ? 0.f : kq[q];
-                        if (!__any(kq[q] != 0.f)) alive_q &= ~(1ull << q);
-                    }
-                    T[q] = nt;
-                    anyv |= __ballot(m != 0.f);
-                    const float cd = fmaf(rb.z, vo[q][0], fmaf(rb.w, vo[q][1], blue * vo[q][2]));
-                    const float num = fmaf(cd, tin * (255.0f * ms::kTUnscale), Q[q]);
-                    Q[q] = fmaf(cd, v, Q[q]);
-                    const float r1 = __builtin_amdgcn_rcpf(1.0f - al);
-                    float am = m * (-ms::kAlphaOfV * ms::kInv255);
-                    if constexpr (CHECK) am = clamped ? 0.f : am;
-                    const float vs = am * (num * r1);
-                    const float sx = vs * dx, sy = vs * dy;
-                    acc[0] += sx;
-                    acc[1] += sy;
-                    acc[2] = fmaf(sx, dx, acc[2]);
-                    acc[3] = fmaf(sx, dy, acc[3]);
-                    acc[4] = fmaf(sy, dy, acc[4]);
-                    acc[5] += vs;
-                    acc[6] = fmaf(v, vo[q][0], acc[6]);
-                    acc[7] = fmaf(v, vo[q][1], acc[7]);
-                    acc[8] = fmaf(v, vo[q][2], acc[8]);
-                }
-                if (anyv == 0ull) continue;
-                // nine sums over the 64 lanes: 32 -> 16 by register pairs, then inside the 16-lane rows
-                const float h01 = halve32(acc[0], acc[1]), h23 = halve32(acc[2], acc[3]);
-                const float h45 = halve32(acc[4], acc[5]), h67 = halve32(acc[6], acc[7]), h8 = halve32(acc[8], 0.f);
-                const float s0 = row_sum16(halve16(h01, h23));   // rows: sums 0, 2, 1, 3
-                const float s1 = row_sum16(halve16(h45, h67));   // rows: sums 4, 6, 5, 7
-                const float s2 = row_sum16(halve16(h8, 0.f));    // row 0: sum 8
-                if (row_head) {
-                    float *row = S.grad + t * kTreeRow;
-                    row[col_s0] = s0;
-                    row[4 + col_s0] = s1;
-                    if (lane == 0) row[8] = s2 * ms::kInv255;
-                }
-                flush |= 1ull << t;
-            }
-        };
-        if (check_sigma) walk(std::true_type{});
-        else walk(std::false_type{});
-        wave_lds_sync_q();
-        // ---- rows: five to a wave instruction (12 lanes each, 9 of them live)
-        {
-            const int rsub = lane / 12, colm = lane - rsub * 12;
-#pragma unroll 1
-            for (int r5 = 0; r5 < kBatch; r5 += 5) {
-                if (((flush >> r5) & 0x1full) == 0ull) continue;
-                const int r = r5 + rsub;
-                if (rsub < 5 && r < kBatch && ((flush >> r) & 1ull) && colm < 9) {
-                    const unsigned gi = (unsigned)__float_as_int(S.c[r].y);
-                    float val = S.grad[r * kTreeRow + colm];
-                    if (colm == 6 || colm == 7) val *= ms::kInv255;   // (colour sums were taken on 255 w; column 8 is scaled at the store)
-                    atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(A.packed) + (gi * (kRowQ * 4u) + (unsigned)colm * 4u)), val);
-                }
-            }
-        }
-    }
-}
-
 // ---- the tiles the forward's clean-up pass redid ------------------------------------------------------------------
 // A lazily sorted frame's rasteriser stops at the end of a heavy tile's sorted front; a tile whose pixels outlive it
 // is redone by k_tile_redo (rasterize.hip) from the tile's unsorted keys, and left out by the launch above (skip_flag).
@@ -842,21 +567,11 @@ int ms::rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const flo
     A.ngrid = order ? (int)(((tiles + 7) / 8) * 8 * A.nsub) : (int)(tiles * A.nsub);
     A.max_isects = (int)M;
     A.n_gauss = (int)N;
-    // MOJOSPLAT_BWD_KERNEL = mfma (one wave per quad, sums on the matrix pipe) | tree (one wave per block, shuffle tree) |
-    // tree2 (two waves per block)
-    static const int which = [] {
-        const char *e = getenv("MOJOSPLAT_BWD_KERNEL");
-        return !e ? MS_BWD_DEFAULT : !strcmp(e, "tree") ? 1 : !strcmp(e, "tree2") ? 2 : 0;
-    }();
-    if (which == 1) {
-        hipLaunchKernelGGL(k_rasterize_bwd_tree<4>, dim3((unsigned)A.ngrid), dim3(64), 0, (hipStream_t)stream, A);
-    } else if (which == 2) {
-        hipLaunchKernelGGL(k_rasterize_bwd_tree<2>, dim3((unsigned)(((A.ngrid + 7) / 8) * 8 * 2)), dim3(64), 0, (hipStream_t)stream, A);
-    } else {
-        // workgroup index space: ngrid blocks padded to a multiple of 8, four waves each
-        const unsigned grid = (unsigned)(((A.ngrid + 7) / 8) * 8 * 4);
-        hipLaunchKernelGGL(k_rasterize_bwd_quads, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
-    }
+    // workgroup index space: ngrid blocks padded to a multiple of 8, four waves each
+    // (the tree variant of this walk -- one wave per 16x16 block, the nine sums by v_permlane32/16_swap + DPP, one row per
+    // block -- was built and measured in round 4: exact to 2e-6, 310 us against this kernel's 274; commit 215461d)
+    const unsigned grid = (unsigned)(((A.ngrid + 7) / 8) * 8 * 4);
+    hipLaunchKernelGGL(k_rasterize_bwd_quads, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
