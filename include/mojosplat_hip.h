@@ -27,8 +27,8 @@
  *     including scratch; the library never allocates device memory and keeps no per-frame or
  *     per-scene state.  What it does keep, process-wide and thread-safe: the thread-local
  *     error string, the environment switches it reads once (MOJOSPLAT_LAZY_SORT, MOJOSPLAT_SPLIT,
- *     MOJOSPLAT_SPLIT_MAX_ENTRIES, MOJOSPLAT_LEAN, MOJOSPLAT_DEFER_TOTAL and the measurement knobs listed in
- *     INTEGRATION.md; MOJOSPLAT_DEPTH_CUT / MOJOSPLAT_DEPTH_CUT_MIN_PAIRS are read per frame: DEPTH CUT-OFFS below),
+ *     MOJOSPLAT_SPLIT_MAX_ENTRIES and the measurement knobs listed in
+ *     INTEGRATION.md; MOJOSPLAT_DEPTH_CUT / MOJOSPLAT_DEPTH_CUT_MIN_PAIRS too: ms_config_depth_cut changes them in-process),
  *     a counter that stamps depth-cut frames, and a mutex-guarded table of the (device, kernel) pairs whose dynamic-LDS ceiling it has
  *     already raised (hipFuncSetAttribute);
  *   - all pointers are DEVICE pointers unless a parameter says "host"; tensors are
@@ -241,6 +241,11 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  *        v_opacities f32[N], v_colors f32[N,CDIM] -- all OVERWRITTEN.
  *   bwd_workspace: ms_render_bwd_workspace_bytes(N, CDIM) bytes of scratch.
  *   mid_event: NULL, or a hipEvent_t recorded on `stream` between the two stages (in-situ timing). */
+/* Depth cut-offs of ms_render_fwd (DEPTH CUT-OFFS below): mode 0 never / 1 from min_pairs pairs on / 2 whenever possible;
+ * a negative argument leaves that setting alone.  Process-wide; the defaults come from MOJOSPLAT_DEPTH_CUT /
+ * MOJOSPLAT_DEPTH_CUT_MIN_PAIRS, read once.  (For tests and measurements that switch inside one process.) */
+int ms_config_depth_cut(int mode, long long min_pairs);
+
 size_t ms_render_bwd_workspace_bytes(int64_t N, int CDIM);
 int ms_render_bwd(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
                   const float *opacities, const float *colors, int CDIM, const float *viewmat, float fx, float fy,
@@ -312,7 +317,7 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  * LEAN FRAMES.  A plain forward frame with CDIM == 3 keeps NO projected arrays in `workspace`: its rasteriser reads
  * the 48-byte records the count kernel leaves per Gaussian, its scatter kernel a 12-byte (tile box, depth bits, reach
  * mask) record; means2d / conics / depths / radii are only written for frames that are asked for render_alphas or
- * last_ids (what a backward needs), for other channel counts, or with MOJOSPLAT_LEAN=0 in the environment.
+ * last_ids (what the older backward rasteriser needs) and for other channel counts.
  * DEPTH CUT-OFFS.  A lean sync-free frame over the whole grid of plain bins (tile_size 32 / 64, up to 255 bins a side)
  * whose predecessor ON THE SAME host_info / workspace / grid was such a frame too, and held at least 6 M pairs
  * (MOJOSPLAT_DEPTH_CUT_MIN_PAIRS), takes that predecessor's per-bin depth cut-offs -- the depth at which each bin's

@@ -112,6 +112,7 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 #                     the library; exact-path frames excluded)
 #   cut_redo_tiles    ... because their depth cut-off was: their dropped pairs were regenerated (likewise)
 #   depth_cut         frames that dropped the pairs behind their bins' depth cut-offs
+#   regen_mismatch    frames whose clean-up launches brought back a pair the count kernel had not counted (a bug if ever > 0)
 #   front_level_up / full_sort_on   the lane's lazy-sorting mode escalated
 #   lazy_sort_retry   a lane on full sorts tried lazily sorted fronts again
 FRAME_STATS = None
@@ -138,7 +139,9 @@ def _count_frame(stats, frame, host, grew):
             stats[why] = stats.get(why, 0) + 1
     if not flags & 4:
         stats["redo_tiles"] = stats.get("redo_tiles", 0) + (int(host[5]) & 0xffffffff)
-        stats["cut_redo_tiles"] = stats.get("cut_redo_tiles", 0) + (int(host[5]) >> 32)
+        stats["cut_redo_tiles"] = stats.get("cut_redo_tiles", 0) + ((int(host[5]) >> 32) & 0x3fffffff)
+        if (int(host[5]) >> 62) & 1:   # the clean-up launches of the previous frame disagreed with its count kernel (never seen)
+            stats["regen_mismatch"] = stats.get("regen_mismatch", 0) + 1
     if flags & 64:
         stats["depth_cut"] = stats.get("depth_cut", 0) + 1
 
@@ -288,7 +291,7 @@ class _Frame:
             # (round 4: ... unless nearly every heavy bin had to be regenerated: that is a scene swap, the fronts of the new
             # scene's bins are as stale as the cut-offs were -- measured: the frame after such a one fails its fronts as
             # well, 70 ms at config 4 -- so the lane goes to full sorts one frame earlier)
-            elif (rc == 0 and not (int(host[7]) & 4) and not st.get("full_sort") and (int(host[5]) >> 32) > max(8, heavy // 2)):
+            elif (rc == 0 and not (int(host[7]) & 4) and not st.get("full_sort") and ((int(host[5]) >> 32) & 0x3fffffff) > max(8, heavy // 2)):
                 st["full_sort"] = True
                 if FRAME_STATS is not None:
                     FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1

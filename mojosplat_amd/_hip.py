@@ -57,6 +57,7 @@ _SIGNATURES = {
                               c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ms_render_workspace_layout": (c_int, [c_int64, c_int, c_int, c_void_p]),
     "ms_render_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "ms_config_depth_cut": (c_int, [c_int, ctypes.c_longlong]),
     "ms_render_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
                               c_float, c_float, c_float, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t,
                               c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -190,3 +191,12 @@ def f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+def config_depth_cut(mode=None, min_pairs=None):
+    """Depth cut-offs of the fused frame (include/mojosplat_hip.h, ms_config_depth_cut): mode 0 never / 1 from
+    `min_pairs` pairs on (the default: 6 M) / 2 on every frame that can.  Process-wide; None leaves a setting alone.
+    The library reads MOJOSPLAT_DEPTH_CUT / MOJOSPLAT_DEPTH_CUT_MIN_PAIRS once -- tests and measurements that switch
+    inside one process call this instead of writing os.environ."""
+    check(lib().ms_config_depth_cut(-1 if mode is None else int(mode), -1 if min_pairs is None else int(min_pairs)),
+          "ms_config_depth_cut")

@@ -917,7 +917,8 @@ __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
         // front was too short, high 32 bits = because their depth cut-off was (redo_count[1] counts those)
         {
             const int prev_cut = min(max(redo_count[1], 0), max(prev_redo, 0));
-            info[5] = (int64_t)(prev_redo - prev_cut) + ((int64_t)prev_cut << 32);
+            // (bit 62: the previous frame's clean-up launches regenerated a pair they had no room for / more than were counted)
+            info[5] = (int64_t)(prev_redo - prev_cut) + ((int64_t)(prev_cut & 0x3fffffff) << 32) + (prev_cut > 0 && info[10] != 0 ? (1ll << 62) : 0);
         }
         redo_count[0] = 0;
         redo_count[1] = 0;
@@ -1162,7 +1163,8 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
         // leaves the split in two device-only words behind the record for the clean-up pass)
         const int prev_cut = min(max(A.redo_count[1], 0), max(prev_redo, 0));   // (see tile_scan_total)
         int64_t rec[7] = {(int64_t)grand + (int64_t)s_far, (int64_t)s_max, (int64_t)s_nmedium, (int64_t)s_nlarge, (int64_t)s_nxl,
-                          (int64_t)(prev_redo - prev_cut) + ((int64_t)prev_cut << 32), (int64_t)s_on_grid};
+                          (int64_t)(prev_redo - prev_cut) + ((int64_t)(prev_cut & 0x3fffffff) << 32) +
+                              (prev_cut > 0 && A.info[10] != 0 ? (1ll << 62) : 0), (int64_t)s_on_grid};
 #pragma unroll
         for (int k = 0; k < 7; ++k) A.info[k] = rec[k];
         A.info[7] = 0;
@@ -1950,6 +1952,9 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
             running += total;
             __syncthreads();
         }
+        // (the count kernel counted every pair it dropped: what comes back cannot exceed that)
+        if (blockIdx.x == 0 && tid == 0 && (int64_t)running > Z.cut_words[1])
+            atomicAdd(reinterpret_cast<unsigned long long *>(Z.cut_words + 2), 1ull);
         __threadfence_block();
         __syncthreads();
     }
@@ -1982,6 +1987,11 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
                 } else {
                     const int64_t pos = near + (int64_t)Z.far_start[tile] + (int64_t)atomicAdd(&Z.far_cur[tile], 1u);
                     if (pos < cap) Z.log_keys[pos] = ((uint64_t)db << 32) | (uint32_t)j;
+                    // (cannot happen while this pass and the count kernel agree on every Gaussian's depth bits, box and
+                    // reach mask -- they are the same inlined functions, but two instantiations: the frame's record
+                    // says so if they ever do not, instead of a pair silently lost: cut_words[2], reported one frame
+                    // later in bit 62 of host_info[5])
+                    else atomicAdd(reinterpret_cast<unsigned long long *>(Z.cut_words + 2), 1ull);
                     brought_back = true;
                 }
             }

@@ -90,17 +90,37 @@ static int ms_order_enabled() {
     return v;
 }
 
-// MOJOSPLAT_DEPTH_CUT=0: never drop the pairs behind a bin's depth cut-off (binning.hip, k_project_hist); 2: take the
-// cut on every frame that can, however few pairs it holds (measurements, tests)
-static int ms_depth_cut_mode() {   // (read per frame: tests and measurements switch it inside one process)
-    const char *e = getenv("MOJOSPLAT_DEPTH_CUT");
-    return e ? atoi(e) : 1;
+// Depth cut-offs (binning.hip, k_project_hist): mode 0 = never drop the pairs behind a bin's cut-off, 1 = on frames whose
+// predecessor held at least `min_pairs` pairs (6 M), 2 = on every frame that can (measurements, tests).  Read ONCE from
+// MOJOSPLAT_DEPTH_CUT / MOJOSPLAT_DEPTH_CUT_MIN_PAIRS; tests and measurements that switch it inside one process call
+// ms_config_depth_cut (round 3 called getenv() on every frame, from any host thread, while Python wrote os.environ:
+// undefined behaviour in libc).
+namespace {
+std::atomic<int> g_cut_mode{-1};
+std::atomic<long long> g_cut_min_pairs{-1};
+void cut_config_init() {
+    if (g_cut_mode.load(std::memory_order_acquire) >= 0) return;
+    static std::atomic<int> once{0};
+    int expected = 0;
+    if (once.compare_exchange_strong(expected, 1)) {
+        const char *e = getenv("MOJOSPLAT_DEPTH_CUT_MIN_PAIRS");
+        const long long n = e ? atoll(e) : -1;
+        g_cut_min_pairs.store(n >= 0 ? n : 6000000ll, std::memory_order_relaxed);
+        const char *m = getenv("MOJOSPLAT_DEPTH_CUT");
+        const int mode = m ? atoi(m) : 1;
+        g_cut_mode.store(mode < 0 ? 0 : mode, std::memory_order_release);
+    } else {
+        while (g_cut_mode.load(std::memory_order_acquire) < 0) {}
+    }
 }
-// pairs a frame must hold (by the previous frame's record) before the cut is worth its bookkeeping
-static int64_t ms_depth_cut_min_pairs() {
-    const char *e = getenv("MOJOSPLAT_DEPTH_CUT_MIN_PAIRS");
-    const long long n = e ? atoll(e) : -1;
-    return (int64_t)(n >= 0 ? n : 6000000ll);
+}  // namespace
+static int ms_depth_cut_mode() { cut_config_init(); return g_cut_mode.load(std::memory_order_relaxed); }
+static int64_t ms_depth_cut_min_pairs() { cut_config_init(); return (int64_t)g_cut_min_pairs.load(std::memory_order_relaxed); }
+extern "C" int ms_config_depth_cut(int mode, long long min_pairs) {
+    cut_config_init();
+    if (mode >= 0) g_cut_mode.store(mode, std::memory_order_relaxed);
+    if (min_pairs >= 0) g_cut_min_pairs.store(min_pairs, std::memory_order_relaxed);
+    return MS_OK;
 }
 // workgroups of the clean-up launch: 256, always.  (Rounds 1-2 launched ONE while recent frames had needed no clean-up;
 // measured in round 3, the frame costs the same with 1 ... 256 of them -- 0.1678-0.1681 ms at config 3: what costs is the

@@ -147,16 +147,31 @@ def _background_as(background, device, dtype, fp32_after):
         return background
     # (keyed by the tensor OBJECT -- a weak reference, checked for identity -- and its version counter: a new tensor at
     # a recycled address, or an in-place update of this one, is converted afresh)
-    key = (id(background), str(device), dtype, fp32_after)
+    # (round 4, advisor: `_version` does not move when the storage is written through `.data`, `set_()` or a numpy / DLPack
+    # alias -- so views and tensors that share storage with anything else are converted afresh every time, and the key
+    # carries the storage address; the converted tensor belongs to the stream that made it: other streams wait for it)
+    if background._base is not None or not background.is_contiguous() or background.requires_grad:
+        out = background.to(device=device, dtype=dtype)
+        return out.to(torch.float32) if fp32_after else out
+    key = (id(background), background.data_ptr(), str(device), dtype, fp32_after)
     hit = _bg_cache.get(key)
     if hit is not None and hit[0]() is background and hit[1] == background._version:
+        if device.type == "cuda":
+            cur = torch.cuda.current_stream(device)
+            if cur != hit[3]:
+                cur.wait_event(hit[4])
         return hit[2]
     out = background.to(device=device, dtype=dtype)
     if fp32_after:
         out = out.to(torch.float32)
     if len(_bg_cache) >= 64:
         _bg_cache.clear()
-    _bg_cache[key] = (weakref.ref(background), background._version, out)
+    stream = ev = None
+    if device.type == "cuda":
+        stream = torch.cuda.current_stream(device)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    _bg_cache[key] = (weakref.ref(background), background._version, out, stream, ev)
     return out
 
 

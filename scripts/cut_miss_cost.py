@@ -3,6 +3,7 @@ python scripts/cut_miss_cost.py cfg4 64"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from mojosplat_amd import _hip
 import mojosplat_amd as ms
 from mojosplat_amd import _fused
 from mojosplat_amd.scenes import randscene_v1
@@ -20,7 +21,7 @@ depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
 other["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.02, sc["opacities"])   # the near half all but gone
 g = lambda s: (s["means3d"], s["scales"], s["quats"], s["opacities"], s["features"])
 for mode in ("1", "0"):
-    os.environ["MOJOSPLAT_DEPTH_CUT"] = mode
+    _hip.config_depth_cut(int(mode))
     _fused._state.clear()
     _fused.FRAME_STATS = {}
     times = []

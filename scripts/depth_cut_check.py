@@ -27,7 +27,7 @@ def orbit(cam, a):
 
 
 def frames(mode, seq):
-    os.environ["MOJOSPLAT_DEPTH_CUT"] = mode
+    _hip.config_depth_cut(int(mode))
     _fused._state.clear()
     _fused.FRAME_STATS = {}
     out = []
@@ -59,7 +59,7 @@ for label, seq in seqs.items():
 # the split of the last depth-cut frame's pairs (device words 8 / 9 of the size record: near, far)
 import ctypes
 from mojosplat_amd import _hip
-os.environ["MOJOSPLAT_DEPTH_CUT"] = "2"
+_hip.config_depth_cut(2)
 _fused._state.clear()
 for _ in range(4):
     ms.render_gaussians(*g(sc), cam, backend="hip", bin_size=px)

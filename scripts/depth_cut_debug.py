@@ -2,6 +2,7 @@
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from mojosplat_amd import _hip
 import mojosplat_amd as ms
 from mojosplat_amd import _fused, _hip
 from mojosplat_amd.scenes import randscene_v1
@@ -19,7 +20,7 @@ tw, th = -(-W // px), -(-H // px)
 T = tw * th
 out = {}
 for mode in ("0", "2"):
-    os.environ["MOJOSPLAT_DEPTH_CUT"] = mode
+    _hip.config_depth_cut(int(mode))
     _fused._state.clear()
     for _ in range(5):
         ms.render_gaussians(*g, cam, backend="hip", bin_size=px)

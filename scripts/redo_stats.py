@@ -18,5 +18,5 @@ for wl in sys.argv[1:] or ["cfg3"]:
         ms.render_gaussians(*g, cam, background_color=bg)
         torch.cuda.synchronize()
         host = _fused._dev_state(dev, 0)["host"]
-        print(wl, "frame", i, "M", int(host[0]), "heavy", int(host[2] + host[3] + host[4]), "redo tiles of previous frame", int(host[5]) & 0xffffffff, "cut redos", int(host[5]) >> 32,
+        print(wl, "frame", i, "M", int(host[0]), "heavy", int(host[2] + host[3] + host[4]), "redo tiles of previous frame", int(host[5]) & 0xffffffff, "cut redos", (int(host[5]) >> 32) & 0x3fffffff,
               "flags", int(host[7]), flush=True)

@@ -6,9 +6,18 @@ import torch
 
 import mojosplat_amd as ms
 from mojosplat_amd import _fused
+from mojosplat_amd import _hip as _hip_mod
 from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _default_depth_cut_after_each_test():
+    """Tests switch the library's depth-cut mode in-process (ms_config_depth_cut: the environment is read once); every
+    test leaves the default behind."""
+    yield
+    _hip_mod.config_depth_cut(1, 6_000_000)
 
 
 def stagewise(sc, cam, bg, tile_size=16):
@@ -644,7 +653,7 @@ def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, 
         sequences["grow"] = [(sc, cam)] * 3 + [(big, cam)] * 4
 
     def run(mode, seq):
-        monkeypatch.setenv("MOJOSPLAT_DEPTH_CUT", mode)
+        _hip_mod.config_depth_cut(int(mode))
         _fused._state.clear()
         _fused.FRAME_STATS = {}
         try:
@@ -662,6 +671,7 @@ def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, 
         assert st0.get("depth_cut", 0) == 0 and st.get("depth_cut", 0) >= (len(seq) - 4 if label in ("still", "orbit") else 1), (label, st)
         for k, (a, b) in enumerate(zip(ref, got)):
             assert torch.equal(a, b), (label, k, float((a - b).abs().max()))
+        assert st.get("regen_mismatch", 0) == 0, (label, st)   # the clean-up launches and the count kernel agree on every pair
         if label in ("still", "orbit"):
             assert st.get("cut_redo_tiles", 0) == 0, (label, st)   # the cut-offs hold while the view changes slowly
         elif label == "swap":
@@ -679,7 +689,7 @@ def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed, dense=False
     clean-up launches, or the lane gave up on lazily sorted fronts altogether."""
     import math
     from mojosplat_amd.utils import Camera
-    monkeypatch.setenv("MOJOSPLAT_DEPTH_CUT", "2")
+    _hip_mod.config_depth_cut(2)
     g = torch.Generator().manual_seed(31000 + seed)
     r = lambda lo, hi: lo + (hi - lo) * torch.rand(1, generator=g).item()
     if dense:   # (scripts/fuzz_cut.py: scenes whose fronts saturate their pixels, so that most frames do take the cut)
