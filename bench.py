@@ -365,7 +365,7 @@ def main():
         legs["orbit"] = orbit_leg(ms, _fused, render_mod, g, cam, bg, stagewise, ms_mean)
         if not fp16:
             legs["cfg3_fwd_bwd" if args.workload == "cfg3" else args.workload + "_fwd_bwd"] = \
-                fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev)
+                fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, m_gsplat=M)
         verified = verified and legs["orbit"]["sampled_frames_bit_identical_to_stagewise"]
 
     # ---- extras: config 5 (the config BASELINE names for 8 GPUs) ----------------------------------
@@ -614,7 +614,7 @@ def orbit_leg(ms, _fused, render_mod, g, cam, bg, stagewise, static_ms, frames=2
     return out
 
 
-def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=6):
+def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=6, m_gsplat=None):
     """BASELINE config 3 as named: forward + backward, grads for means / scales / quats / opacities / colours
     (dL/dimage = rand(H, W, 3), seed 43: SURVEY 8(d)).  ms per step over `steps` un-instrumented steps; stage times
     from HIP events on the launch stream in a separate short pass (an event between two kernels costs a bubble)."""
@@ -648,7 +648,7 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
         step()
     torch.cuda.synchronize()
     dt_streamed = time.perf_counter() - t0
-    m_lists = int(host[0])            # pairs on the differentiable frame's lists (16-px tiles, tight binning)
+    m_lists = int(host[0])            # pairs on the differentiable frame's lists (the binning rule's grid, tight binning)
     finite = all(bool(torch.isfinite(l.grad).all()) for l in leaves)
     # stage times
     n_ev = 10
@@ -673,6 +673,7 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
           "bwd_raster_call": mean([e[0].elapsed_time(e[1]) for e in bev]) * 1e3,
           "bwd_project": mean([e[1].elapsed_time(e[2]) for e in bev]) * 1e3}
     b_rbwd = 40 * m_lists + 24 * H * W + 36 * N
+    b_rbwd_gsplat = 40 * m_gsplat + 24 * H * W + 36 * N if m_gsplat else None
     b_pbwd = 108 * N
     return {"what": "render_gaussians_trainable forward + img.backward(dL/dimage = rand(H, W, 3) seed 43), grads for means3d / scales / quats / "
                     "opacities / colours; every step synchronised (a training step ends with its gradients)",
@@ -681,11 +682,15 @@ def fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, steps=30, warm=
             "ms_per_step_streamed": round(dt_streamed / steps * 1e3, 4), "grads_finite": finite,
             "pairs_on_lists": m_lists,
             "stage_us": {k: round(v, 1) for k, v in us.items()},
-            "stage_us_note": "HIP events on the launch stream, separate pass of 10 steps; bwd_raster_call = the packed rows' memset + "
-                             "k_bwd_order + k_rasterize_bwd_v2 + k_unpack_grads (the first stage of ms_render_bwd)",
-            "roofline": {"bwd_raster": {"bound": "hbm", "algorithmic_bytes": b_rbwd, "formula": "40 M + 24 HW + 36 N",
+            "stage_us_note": "HIP events on the launch stream, separate pass of 10 steps; the forward is the inference frame "
+                             "(lazily sorted fronts on the binning rule's grid) keeping its alphas; bwd_raster_call = the rows' "
+                             "memset + k_rasterize_bwd_quads + its (normally empty) redo launch (the first stage of ms_render_bwd)",
+            "roofline": {"bwd_raster": {"bound": "hbm", "algorithmic_bytes": b_rbwd, "formula": "40 M + 24 HW + 36 N, M = the pairs on the lists the kernel walks",
                                         "achieved": round(b_rbwd / (us["bwd_raster_call"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": round(b_rbwd / (us["bwd_raster_call"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                                        "unit": "GB/s", "frac": round(b_rbwd / (us["bwd_raster_call"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "algorithmic_bytes_gsplat_M": b_rbwd_gsplat,
+                                        "frac_gsplat_M": None if not b_rbwd_gsplat else
+                                        round(b_rbwd_gsplat / (us["bwd_raster_call"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                          "bwd_project": {"bound": "hbm", "algorithmic_bytes": b_pbwd, "formula": "108 N",
                                          "achieved": round(b_pbwd / (us["bwd_project"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": round(b_pbwd / (us["bwd_project"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}}
