@@ -228,3 +228,50 @@ def test_differentiable_frame_whose_sorted_fronts_run_out(device, n, z_lo, z_hi,
         assert torch.equal(r[0], res[0][0])
         for name, a, b in zip(names, r[1], res[0][1]):
             assert_grad_close(name, a, b, rel=2e-3)
+
+
+@pytest.mark.parametrize("px", [16, 64])
+def test_differentiable_frame_on_every_binning_grid(device, monkeypatch, px):
+    """The quad-wave backward walks the lists of whatever grid the frame was binned on: 16-px tiles (one block per
+    tile) and 64-px bins (sixteen blocks per bin, each wave staging the bin's whole list) give the same image bit
+    for bit and the same gradients as the per-stage functions -- on a scene whose heavy bins have lazily sorted
+    fronts, and on the stack scene that sends every bin through the redo launch."""
+    from mojosplat_amd import _fused
+    from test_hip_fused import _stack_scene
+    monkeypatch.setenv("MOJOSPLAT_TRAIN_BIN_PX", str(px))
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    bg = torch.tensor([0.2, 0.1, 0.3], device=device)
+    for sc, cam in (randscene_v1(60_000, 640, 360, ell=-3.2, seed=21, device=device), _stack_scene(4000, 4.0, 6.0, 0.005, device)):
+        v_img = torch.rand(cam.H, cam.W, 3, generator=torch.Generator().manual_seed(5)).to(device)
+        _fused._state.clear()
+        res = []
+        for stagewise in (True, False, False):
+            leaves = [sc[k].clone().requires_grad_(True) for k in names]
+            img = render_gaussians_trainable(*leaves, cam, background_color=bg, stagewise=stagewise)
+            img.backward(v_img)
+            res.append((img.detach(), [l.grad for l in leaves]))
+        _fused._state.clear()
+        for r in res[1:]:
+            assert torch.equal(r[0], res[0][0])
+            for name, a, b in zip(names, r[1], res[0][1]):
+                assert_grad_close(name, a, b, rel=2e-3)
+
+
+def test_differentiable_frame_with_alpha_gradients_and_partial_tiles(device):
+    """An image whose size is no multiple of 8 (quads that hang over the edge), and a loss on the image only where a
+    mask says so (pixels with zero dL/dC inside live quads): gradients against the per-stage functions."""
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    sc, cam = randscene_v1(20_000, 333, 205, ell=-3.0, seed=9, device=device)
+    bg = torch.tensor([0.3, 0.2, 0.1], device=device)
+    v_img = torch.rand(cam.H, cam.W, 3, generator=torch.Generator().manual_seed(6)).to(device)
+    v_img[::3] = 0.0
+    v_img[:, 100:140] = 0.0
+    res = []
+    for stagewise in (True, False):
+        leaves = [sc[k].clone().requires_grad_(True) for k in names]
+        img = render_gaussians_trainable(*leaves, cam, background_color=bg, stagewise=stagewise)
+        img.backward(v_img)
+        res.append((img.detach(), [l.grad for l in leaves]))
+    assert torch.equal(res[0][0], res[1][0])
+    for name, a, b in zip(names, res[1][1], res[0][1]):
+        assert_grad_close(name, a, b, rel=5e-4)
