@@ -308,7 +308,7 @@ class _Frame:
             # ... and giving up is not for ever: a view through fog ends.  After RETRY_FULL_SORT frames on full sorts the
             # lane tries lazily sorted fronts again, at the depth it last used; if they fail again (the library reports
             # it one frame later, above) it is back on full sorts with twice the patience, up to 4096 frames.  (A failed
-            # retry costs one or two frames of the clean-up pass: 40-100 ms on the heaviest scenes since round 3.)
+            # retry costs one or two frames of the clean-up pass: 5-6 ms on the heaviest scenes since round 4's two-launch clean-up.)
             if st.get("full_sort") and same_shape:
                 st["full_sort_frames"] = st.get("full_sort_frames", 0) + 1
                 if st["full_sort_frames"] >= st.get("retry_after", RETRY_FULL_SORT):

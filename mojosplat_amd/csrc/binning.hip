@@ -37,6 +37,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -1862,6 +1863,7 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->row_lo = 0;
     out->row_hi = 0x7fffffff;
     out->redo_grid = 256;
+    out->redo_sort = 0;
     out->cut_stamp = 0;   // (a depth-cut frame's caller sets the stamp, the cut-off buffers, the record's words and the log)
     out->tau = (uint32_t *)(ws + p.off_tau);   // (buffer 0; buffer 1 follows T words on: the caller picks)
     out->tau_next = nullptr;
@@ -1905,7 +1907,7 @@ struct RegenProject {
 };
 constexpr int kRegenThreads = 256, kRegenMaxTiles = 65536;
 template <int PASS>
-__global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, int tw, int n_tiles, int64_t cap, RegenProject R) {
+__global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, int tw, int n_tiles, int64_t cap, RegenProject R, int lds_tiles) {
     const int n_redo = min(*Z.redo_count, n_tiles);
     if (n_redo <= 0) return;
     __shared__ uint32_t s_bits[kRegenMaxTiles / 32];
@@ -1959,50 +1961,84 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
         __syncthreads();
     }
     const int64_t near = Z.cut_words[0];
-    for (int64_t j = (int64_t)blockIdx.x * kRegenThreads + tid; j < Z.n_lean; j += (int64_t)gridDim.x * kRegenThreads) {
-        // the Gaussian's box, reach mask and depth bits as the count kernel had them (it keeps no box records on a
-        // depth-cut frame): the same functions on the same inputs, in the same translation unit
-        uint32_t db = 0u, mk = 0u;
-        int x0 = 0, y0 = 0, bw = 0, bh = 0;
-        const ms::ProjOut o = ms::project_one<uint32_t>((uint32_t)j, R.means3d, R.scales, R.quats, R.opacities, R.viewmat, R.P);
-        if (o.r0 > 0 && o.r1 > 0) {
+    // the pairs a Gaussian has behind the cut-offs of the marked bins: fn(bin) for each, -> whether there was one
+    // (box, reach mask and depth bits as the count kernel had them -- it keeps no box records on a depth-cut frame:
+    // the same functions on the same inputs, in the same translation unit)
+    struct Seen { ms::ProjOut o; uint32_t db, mk; int x0, y0, bw, bh; };
+    auto visit = [&](int64_t j, Seen &v, auto &&fn) __attribute__((always_inline)) {
+        v.db = 0u; v.mk = 0u; v.x0 = 0; v.y0 = 0; v.bw = 0; v.bh = 0;
+        v.o = ms::project_one<uint32_t>((uint32_t)j, R.means3d, R.scales, R.quats, R.opacities, R.viewmat, R.P);
+        if (v.o.r0 > 0 && v.o.r1 > 0) {
             int bx1, by1, be;
-            (void)bin_box<false>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), R.g, x0, bx1, y0, by1, be);
-            bw = bx1 - x0; bh = by1 - y0;
-            if (bw * bh > 0) {
-                mk = bw * bh > 32 ? 0xffffffffu
-                                  : (uint32_t)reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(R.opacities, (uint32_t)j, 1, 0), x0, bx1, y0, by1, R.g.ts);
-                db = __float_as_uint(o.d);
+            (void)bin_box<false>(make_float2(v.o.m0, v.o.m1), make_int2(v.o.r0, v.o.r1), R.g, v.x0, bx1, v.y0, by1, be);
+            v.bw = bx1 - v.x0; v.bh = by1 - v.y0;
+            if (v.bw * v.bh > 0) {
+                v.mk = v.bw * v.bh > 32 ? 0xffffffffu
+                                        : (uint32_t)reach_mask(v.o.m0, v.o.m1, v.o.c0, v.o.c1, v.o.c2, ms::ld_f32(R.opacities, (uint32_t)j, 1, 0), v.x0, bx1, v.y0, by1, R.g.ts);
+                v.db = __float_as_uint(v.o.d);
             }
         }
-        const int n = bw * bh;
-        bool brought_back = false;
-        for (int r = 0, k = 0; r < bh; ++r) {
-            for (int c = 0; c < bw; ++c, ++k) {
-                if (n <= 32 && !((mk >> k) & 1u)) continue;   // (the count / scatter kernels' rule: walk_boxes)
-                const int tile = (y0 + r) * tw + x0 + c;
-                if (!((s_bits[tile >> 5] >> (tile & 31)) & 1u) || db <= Z.tau[tile]) continue;
-                if constexpr (PASS == 0) {
-                    atomicAdd(&Z.far_cnt[tile], 1u);
-                } else {
-                    const int64_t pos = near + (int64_t)Z.far_start[tile] + (int64_t)atomicAdd(&Z.far_cur[tile], 1u);
-                    if (pos < cap) Z.log_keys[pos] = ((uint64_t)db << 32) | (uint32_t)j;
-                    // (cannot happen while this pass and the count kernel agree on every Gaussian's depth bits, box and
-                    // reach mask -- they are the same inlined functions, but two instantiations: the frame's record
-                    // says so if they ever do not, instead of a pair silently lost: cut_words[2], reported one frame
-                    // later in bit 62 of host_info[5])
-                    else atomicAdd(reinterpret_cast<unsigned long long *>(Z.cut_words + 2), 1ull);
-                    brought_back = true;
-                }
+        const int n = v.bw * v.bh;
+        bool any = false;
+        for (int r = 0, k = 0; r < v.bh; ++r) {
+            for (int c = 0; c < v.bw; ++c, ++k) {
+                if (n <= 32 && !((v.mk >> k) & 1u)) continue;   // (the count / scatter kernels' rule: walk_boxes)
+                const int tile = (v.y0 + r) * tw + v.x0 + c;
+                if (!((s_bits[tile >> 5] >> (tile & 31)) & 1u) || v.db <= Z.tau[tile]) continue;
+                fn(tile);
+                any = true;
             }
         }
-        if constexpr (PASS == 1) {
+        return any;
+    };
+    // Round 4: the counters of a grid of up to kRegenLdsTiles bins are kept in LDS, a workgroup adding its sums to the global
+    // ones once per bin: every pair's own global atomic -- six million of them on the ~300 words of a config-4 frame's
+    // stranded bins, all in one L2 channel -- made each of the two launches 6-7 ms.
+    extern __shared__ uint32_t s_dyn[];   // lds_tiles > 0: [n_tiles] pair counts / cursors (+ [n_tiles] segment bases, PASS 1)
+    const bool in_lds = lds_tiles > 0;
+    const int64_t j0 = (int64_t)blockIdx.x * kRegenThreads + tid, jstep = (int64_t)gridDim.x * kRegenThreads;
+    Seen v;
+    if (in_lds) {
+        for (int t = tid; t < n_tiles; t += kRegenThreads) s_dyn[t] = 0u;
+        __syncthreads();
+        for (int64_t j = j0; j < Z.n_lean; j += jstep) (void)visit(j, v, [&](int tile) { atomicAdd(&s_dyn[tile], 1u); });
+        __syncthreads();
+        if constexpr (PASS == 0) {
+            for (int t = tid; t < n_tiles; t += kRegenThreads)
+                if (s_dyn[t]) atomicAdd(&Z.far_cnt[t], s_dyn[t]);
+            return;
+        } else {
+            uint32_t *s_base = s_dyn + n_tiles;   // this workgroup's stretch of each bin's segment
+            for (int t = tid; t < n_tiles; t += kRegenThreads) {
+                const uint32_t c = s_dyn[t];
+                if (c) { s_base[t] = atomicAdd(&Z.far_cur[t], c); s_dyn[t] = 0u; }
+            }
+            __syncthreads();
+        }
+    } else if constexpr (PASS == 0) {
+        for (int64_t j = j0; j < Z.n_lean; j += jstep) (void)visit(j, v, [&](int tile) { atomicAdd(&Z.far_cnt[tile], 1u); });
+        return;
+    }
+    if constexpr (PASS == 1) {
+        const uint32_t *s_base = s_dyn + n_tiles;
+        for (int64_t j = j0; j < Z.n_lean; j += jstep) {
+            const bool brought_back = visit(j, v, [&](int tile) {
+                const uint32_t slot = in_lds ? s_base[tile] + atomicAdd(&s_dyn[tile], 1u) : atomicAdd(&Z.far_cur[tile], 1u);
+                const int64_t pos = near + (int64_t)Z.far_start[tile] + (int64_t)slot;
+                if (pos < cap) Z.log_keys[pos] = ((uint64_t)v.db << 32) | (uint32_t)j;
+                // (cannot happen while this pass and the count kernel agree on every Gaussian's depth bits, box and
+                // reach mask -- they are the same inlined functions, but two instantiations: the frame's record
+                // says so if they ever do not, instead of a pair silently lost: cut_words[2], reported one frame
+                // later in bit 62 of host_info[5])
+                else atomicAdd(reinterpret_cast<unsigned long long *>(Z.cut_words + 2), 1ull);
+            });
+            const int n = v.bw * v.bh;
             if (brought_back && n <= kCoopThreshold && R.rec) {
                 // did the count kernel keep a pair of this Gaussian (then it wrote the record itself)?
                 bool kept = false;
-                for (int r = 0, k = 0; r < bh; ++r)
-                    for (int c = 0; c < bw; ++c, ++k)
-                        if (((mk >> k) & 1u) && db <= Z.tau[(y0 + r) * tw + x0 + c]) kept = true;
+                for (int r = 0, k = 0; r < v.bh; ++r)
+                    for (int c = 0; c < v.bw; ++c, ++k)
+                        if (((v.mk >> k) & 1u) && v.db <= Z.tau[(v.y0 + r) * tw + v.x0 + c]) kept = true;
                 if (!kept) {
                     const uint32_t src = (uint32_t)j;
                     float col[3];
@@ -2013,7 +2049,7 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
                         const ms::F3 c3 = ms::ld_f32x3(reinterpret_cast<const float *>(R.colors), src);
                         col[0] = c3.x; col[1] = c3.y; col[2] = c3.z;
                     }
-                    const ms::RasterRecord rr = ms::make_raster_record(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(R.opacities, src, 1, 0), col[0], col[1], col[2]);
+                    const ms::RasterRecord rr = ms::make_raster_record(v.o.m0, v.o.m1, v.o.c0, v.o.c1, v.o.c2, ms::ld_f32(R.opacities, src, 1, 0), col[0], col[1], col[2]);
                     float4 *out = R.rec + 3 * j;
                     out[0] = rr.a; out[1] = rr.b; out[2] = rr.c;
                 }
@@ -2022,6 +2058,7 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
     }
 }
 
+constexpr int kRegenLdsTiles = 16384;   // (2 x 64 KB of counters next to the 8 KB of marks)
 
 }  // namespace
 
@@ -2037,8 +2074,21 @@ int ms::far_regen(const ms::LazyLists &lazy, int tw, int n_tiles, int64_t cap, v
     // (empty launches on almost every frame -- every workgroup reads the redo count and leaves; the frame costs the same
     // whatever their number: pipeline.hip, ms_redo_grid)
     const unsigned grid = 512u;
-    hipLaunchKernelGGL(k_far_regen<0>, dim3(grid), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
-    hipLaunchKernelGGL(k_far_regen<1>, dim3(grid), dim3(kRegenThreads), 0, stream, lazy, tw, n_tiles, cap, R);
+    const int lds_tiles = n_tiles <= kRegenLdsTiles ? n_tiles : 0;
+    if (lds_tiles > 4096) {   // (more than the 64 KB a launch may take unasked, next to the kernel's 8 KB of marks)
+        static std::mutex mu;
+        static std::vector<int> devices_set;
+        int dev = -1;
+        MS_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        if (std::find(devices_set.begin(), devices_set.end(), dev) == devices_set.end()) {
+            MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_far_regen<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kRegenLdsTiles * 4));
+            MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_far_regen<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kRegenLdsTiles * 8));
+            devices_set.push_back(dev);
+        }
+    }
+    hipLaunchKernelGGL(k_far_regen<0>, dim3(grid), dim3(kRegenThreads), (size_t)lds_tiles * 4, stream, lazy, tw, n_tiles, cap, R, lds_tiles);
+    hipLaunchKernelGGL(k_far_regen<1>, dim3(grid), dim3(kRegenThreads), (size_t)lds_tiles * 8, stream, lazy, tw, n_tiles, cap, R, lds_tiles);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }

@@ -112,6 +112,7 @@ struct LazyLists {
     int packed;             // key / list words are id << 4 | block bits
     int row_lo, row_hi;     // split frames: the band in 16-px block rows (the clean-up leaves other rows alone)
     int redo_grid;          // workgroups of the clean-up launch (256: an empty launch costs the frame the same whatever their number)
+    int redo_sort;          // != 0: the clean-up takes two launches (rasterize.hip, k_redo_sort): stranded bins sorted whole, then a workgroup per block
     // depth-cut frame (cut_stamp != 0): the tiles marked has_far[tile] == cut_stamp own pairs that were never written
     // (depth bits > tau[tile]); the clean-up launches regenerate them for the tiles on the redo list from the frame's
     // 12-byte box records (`lean`, n_lean of them) into the free tail of the key array behind the cut_words[0] entries

@@ -128,6 +128,15 @@ extern "C" int ms_config_depth_cut(int mode, long long min_pairs) {
 // a frame at configs 4 / 5 after a scene swap.  Round 4: 1024 change nothing either -- 70 against 72 ms for that frame: its
 // time is the heaviest bin's sixteen blocks, one after the other in one workgroup.)
 static int ms_redo_grid() { return 256; }
+// MOJOSPLAT_REDO_SORT=0: the clean-up pass in ONE launch always (measurements: the round-3 behaviour of the frames that
+// can expect stranded bins -- rasterize.hip, k_redo_sort)
+static int ms_redo_sort_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_REDO_SORT");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
 static int ms_merged_sort_enabled() {   // (binning.hip reads the same variable)
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_MERGED_SORT");
@@ -396,6 +405,12 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                 lazy_lists.cut_words = info + 8;
                 lazy_lists.log_keys = keys;
                 lazy_lists.cut_inputs = &cut_inputs;
+                // stranded bins can be expected -- a depth-cut frame, or the previous frame on this record redid some: the
+                // clean-up takes two launches (rasterize.hip, k_redo_sort), 2.4 us a frame that quiet frames do not pay
+                const int64_t prev_redos = (prev[7] & 4) ? 0 : (prev[5] & 0xffffffffll) + ((prev[5] >> 32) & 0x3fffffffll);
+                // (bins of 48 px and more -- nine or sixteen blocks to a bin, lists of tens of thousands -- always: such a frame's
+                // FIRST encounter with stranded bins is the 75 ms one)
+                lazy_lists.redo_sort = (cut_stamp != 0u || prev_redos > 0 || tile_size >= 48) && !aux_frame && ms_redo_sort_enabled() ? 1 : 0;
             }
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,

@@ -585,6 +585,208 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? M
 // every chunk is then selected from the buckets that hold the next ~1 024 keys alone.
 constexpr int kRedoChunk = 1024, kRedoCap = 2048, kRedoNB = 2048, kRedoPartMin = 4096;
 
+// Round 4: TWO launches where the lists are long.  One workgroup per bin walking the bin's 16x16 blocks one after the
+// other, every chunk selected and ranked afresh for each block, made the frame after a scene swap the heaviest bin's
+// serial time: 16 blocks x 4.4 ms at config 4 on 64-px bins, 70-85 ms a frame.  On frames that can expect stranded bins
+// (LazyLists::redo_sort: a depth-cut frame, or the record of the previous frame on this scratch reported redone bins)
+// k_redo_sort first SORTS every stranded bin's keys whole, one workgroup per bin, and k_tile_redo then runs one
+// workgroup per (bin, 16x16 block), walking the sorted ids like the main kernel walks a front.
+// The sort is a sample sort in LDS: 4 095 of the bin's keys (evenly spaced positions) are sorted and used as splitters,
+// the entries' indices are written bucket by bucket into the bin's slots of the id array (the partition of the one-launch
+// path, with balanced buckets whatever the depth distribution), then windows of whole buckets of at most 4 096 keys are
+// brought into LDS, every key ranked inside its bucket, and the Gaussian ids written over the indices.  redo_flag[bin] = 2 says "sorted".
+// Keys are distinct, so the order is THE order of the fully sorted path.  A bucket of more than 4 096 keys (the sample
+// failed: not seen) leaves the bin to the selection path below, block by block.
+constexpr int kSortCap = 4096, kSortThreads = 1024, kSortPer = kSortCap / kSortThreads;
+__device__ __forceinline__ void redo_bitonic(uint64_t *s, int P, int tid) {   // P: a power of two <= kSortCap; ends with a barrier
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += kSortThreads) {
+                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1)), b = a | j;
+                const bool up = (a & k) == 0;
+                const uint64_t x = s[a], y = s[b];
+                if ((x > y) == up) { s[a] = y; s[b] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_redo_sort(RasterArgs A) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_key[kSortCap];   // the sorted sample (splitters), then a window's keys
+    __shared__ uint32_t s_cnt[kSortCap];
+    __shared__ uint32_t s_bstart[kSortCap + 1];
+    __shared__ uint32_t s_wred[2 * (kSortThreads / 64)];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n_redo = *A.lazy.redo_count;
+    for (int ri = blockIdx.x; ri < n_redo; ri += gridDim.x) {
+        const int tile = A.lazy.redo_list[ri];
+        const int end_all = min(A.tile_ranges[2 * tile + 1], A.max_isects);
+        const int start = min(A.tile_ranges[2 * tile], end_all);
+        const int n = end_all - start;
+        const uint64_t *kin = A.lazy.keys + start;
+        const bool far_tile = A.lazy.cut_stamp && A.lazy.has_far[tile] == A.lazy.cut_stamp;
+        const int64_t far_base = far_tile ? min((int64_t)A.lazy.cut_words[0] + (int64_t)A.lazy.far_start[tile], (int64_t)A.max_isects) : 0;
+        const int n_far = far_tile ? (int)min((int64_t)A.lazy.far_cnt[tile], (int64_t)A.max_isects - far_base) : 0;
+        const uint64_t *fkeys = A.lazy.keys + far_base;
+        const int m_all = n + n_far;
+        int32_t *ids_near = const_cast<int32_t *>(A.flatten_ids) + start, *ids_far = const_cast<int32_t *>(A.flatten_ids) + far_base;
+        auto key_of = [&](int e) __attribute__((always_inline)) { return e < n ? kin[e] : fkeys[e - n]; };
+        auto put = [&](int pos, int32_t v) __attribute__((always_inline)) { if (pos < n) ids_near[pos] = v; else ids_far[pos - n] = v; };
+        auto get = [&](int pos) __attribute__((always_inline)) { return pos < n ? ids_near[pos] : ids_far[pos - n]; };
+        auto pow2_of = [](int c) { int P = 2; while (P < c) P <<= 1; return P; };
+        __syncthreads();   // (the previous bin is done with the LDS arrays)
+        if (m_all <= 0) continue;   // (uniform)
+        if (m_all <= kSortCap) {
+            const int P = pow2_of(m_all);
+            for (int i = tid; i < P; i += kSortThreads) s_key[i] = i < m_all ? key_of(i) : ~0ull;
+            __syncthreads();
+            redo_bitonic(s_key, P, tid);
+            for (int i = tid; i < m_all; i += kSortThreads) put(i, (int32_t)(uint32_t)s_key[i]);
+            if (tid == 0) A.lazy.redo_flag[tile] = 2;
+            continue;
+        }
+        // splitters: kSortCap - 1 keys at evenly spaced positions (distinct positions, distinct keys) + one +inf
+        for (int i = tid; i < kSortCap; i += kSortThreads)
+            s_key[i] = i < kSortCap - 1 ? key_of((int)(((int64_t)i * m_all) / (kSortCap - 1))) : ~0ull;
+        for (int b = tid; b < kSortCap; b += kSortThreads) s_cnt[b] = 0;
+        __syncthreads();
+        redo_bitonic(s_key, kSortCap, tid);
+        auto bucket_of = [&](uint64_t k) __attribute__((always_inline)) {   // the splitters below k: 0 .. kSortCap - 1
+            int lo = 0;
+#pragma unroll
+            for (int step = kSortCap >> 1; step > 0; step >>= 1)
+                if (s_key[lo + step - 1] < k) lo += step;
+            return lo;
+        };
+        // (four keys of a thread in flight: one load per trip left the pass waiting on memory 117 times for a 120 000-entry bin)
+        auto each_key4 = [&](auto &&fn) __attribute__((always_inline)) {
+            for (int e0 = tid; e0 < m_all; e0 += 4 * kSortThreads) {
+                uint64_t k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kSortThreads;
+                    k4[u] = e < m_all ? key_of(e) : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kSortThreads;
+                    if (e < m_all) fn(e, k4[u]);
+                }
+            }
+        };
+        each_key4([&](int, uint64_t k) { atomicAdd(&s_cnt[bucket_of(k)], 1u); });
+        __syncthreads();
+        unsigned int biggest = 0;
+        {   // exclusive scan of the counters: thread t owns buckets kSortPer t .. kSortPer t + kSortPer - 1
+            constexpr int NW = kSortThreads / 64;
+            unsigned int c[kSortPer], sum = 0;
+#pragma unroll
+            for (int j = 0; j < kSortPer; ++j) { c[j] = s_cnt[kSortPer * tid + j]; sum += c[j]; biggest = max(biggest, c[j]); }
+            unsigned int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned int o = (unsigned int)__shfl_up((int)incl, d);
+                if (lane >= d) incl += o;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) biggest = max(biggest, (unsigned int)__shfl_xor((int)biggest, d));
+            if (lane == 63) s_wred[w] = incl;
+            if (lane == 0) s_wred[NW + w] = biggest;
+            __syncthreads();
+            unsigned int run = incl - sum;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                if (ww < w) run += s_wred[ww];
+                biggest = max(biggest, s_wred[NW + ww]);
+            }
+#pragma unroll
+            for (int j = 0; j < kSortPer; ++j) { s_bstart[kSortPer * tid + j] = run; s_cnt[kSortPer * tid + j] = run; run += c[j]; }
+            if (tid == kSortThreads - 1) s_bstart[kSortCap] = run;
+        }
+        __syncthreads();
+        if (biggest > (unsigned int)kSortCap) continue;   // (uniform) the selection path takes this bin
+#if defined(MS_REDO_SORT_ABLATE) && MS_REDO_SORT_ABLATE == 1
+        continue;   // (measurement: sample + histogram only)
+#endif
+        each_key4([&](int e, uint64_t k) { put((int)atomicAdd(&s_cnt[bucket_of(k)], 1u), e); });
+        __threadfence_block();
+        __syncthreads();   // (the splitters are done with: s_key now holds one window after the other)
+#if defined(MS_REDO_SORT_ABLATE) && MS_REDO_SORT_ABLATE == 2
+        continue;   // (measurement: no window sorts)
+#endif
+#ifdef MS_REDO_SORT_DEBUG
+        int dbg_windows = 0;
+        long long dbg_t[3] = {0, 0, 0}, dbg_start = wall_clock64();
+#endif
+        for (int cb = 0; cb < kSortCap;) {   // (uniform)
+            // the largest ce >= cb whose buckets cb .. ce hold at most kSortCap keys together (every bucket alone does)
+            const unsigned int w0 = s_bstart[cb];
+            int lo_b = cb, hi_b = kSortCap - 1;
+            while (lo_b < hi_b) {
+                const int mid = (lo_b + hi_b + 1) >> 1;
+                if (s_bstart[mid + 1] - w0 <= (unsigned int)kSortCap) lo_b = mid; else hi_b = mid - 1;
+            }
+            const int cnt = (int)(s_bstart[lo_b + 1] - w0);
+            if (cnt > 0) {
+                // every key ranked inside its own bucket (~m / 2 048 keys each): a bitonic network over the window cost 65 us
+                // a window, 2.4 of the launch's 3.0 ms at config 4
+                uint64_t kk[kSortPer];
+#ifdef MS_REDO_SORT_DEBUG
+                const long long t0 = wall_clock64();
+#endif
+#pragma unroll
+                for (int e = 0; e < kSortPer; ++e) {
+                    const int i = e * kSortThreads + tid;
+                    kk[e] = i < cnt ? key_of(get((int)w0 + i)) : ~0ull;
+                    if (i < cnt) s_key[i] = kk[e];
+                }
+                __syncthreads();
+#ifdef MS_REDO_SORT_DEBUG
+                const long long t1 = wall_clock64();
+                dbg_t[0] += t1 - t0;
+#endif
+#pragma unroll
+                for (int e = 0; e < kSortPer; ++e) {
+                    const int i = e * kSortThreads + tid;
+                    if (i < cnt) {
+                        int lo = cb, hi = lo_b;   // the bucket of position w0 + i: the last b with s_bstart[b] <= w0 + i
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (s_bstart[mid] <= w0 + (unsigned int)i) lo = mid; else hi = mid - 1;
+                        }
+                        const int beg = (int)(s_bstart[lo] - w0), en = (int)(s_bstart[lo + 1] - w0);
+                        int r = 0, j = beg;   // (two keys a read: the pass is bound by its LDS instructions)
+                        if ((j & 1) && j < en) { r += s_key[j] < kk[e] ? 1 : 0; ++j; }
+                        for (; j + 1 < en; j += 2) {
+                            const ulonglong2 two = *reinterpret_cast<const ulonglong2 *>(&s_key[j]);
+                            r += (two.x < kk[e] ? 1 : 0) + (two.y < kk[e] ? 1 : 0);
+                        }
+                        if (j < en) r += s_key[j] < kk[e] ? 1 : 0;
+                        put((int)w0 + beg + r, (int32_t)(uint32_t)kk[e]);   // (every get() of this window came before the barrier)
+                    }
+                }
+#ifdef MS_REDO_SORT_DEBUG
+                const long long t2 = wall_clock64();
+                dbg_t[1] += t2 - t1;
+#endif
+                __syncthreads();
+#ifdef MS_REDO_SORT_DEBUG
+                dbg_t[2] += wall_clock64() - t2;
+#endif
+            }
+            cb = lo_b + 1;
+#ifdef MS_REDO_SORT_DEBUG
+            ++dbg_windows;
+#endif
+        }
+#ifdef MS_REDO_SORT_DEBUG
+        if (tid == 0 && n > 100000) printf("redo_sort bin %d: n %d far %d biggest %u windows %d; 100 MHz ticks: gather %lld rank+put %lld sync %lld all windows %lld\n", tile, n, n_far, biggest, dbg_windows, dbg_t[0], dbg_t[1], dbg_t[2], wall_clock64() - dbg_start);
+#endif
+        if (tid == 0) A.lazy.redo_flag[tile] = 2;
+    }
+}
+
 template <int CP, typename ColorT>
 __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     __shared__ uint64_t s_key[kRedoCap];
@@ -595,6 +797,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     __shared__ float4 s_pa[256], s_pb[256];  // staged entries: mean.x mean.y a' b' | c' log2(o) - -
     __shared__ float s_pc[256 * CP];
     __shared__ int s_alive[4];
+    __shared__ unsigned long long s_hit[16];   // [quad][staging wave]: the staged entries that reach the quad
     flush_fp32_denormals();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lx = lane & 7, ly = lane >> 3;
@@ -602,7 +805,12 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
     const int n_redo = *A.lazy.redo_count;
     constexpr float kInf = __builtin_huge_valf();
 
-    for (int ri = blockIdx.x; ri < n_redo; ri += gridDim.x) {
+    // (two launches -- see k_redo_sort: an item is one 16x16 block of a stranded bin; else a bin with all its blocks)
+    const bool two = A.lazy.redo_sort != 0;
+    const int n_items = two ? n_redo * A.nsub : n_redo;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ri = two ? item / A.nsub : item;
+        const int sub_lo = two ? item - ri * A.nsub : 0, sub_hi = two ? sub_lo + 1 : A.nsub;
         const int tile = A.lazy.redo_list[ri];
         const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
         const int end_all = min(A.tile_ranges[2 * tile + 1], A.max_isects);
@@ -618,7 +826,10 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
         // A long list is partitioned once (see above): perm = the entries' indices (0 .. n: the list; n ..: the
         // regenerated segment) in key-bucket order, in the id slots of the same two ranges
         const int m_all = n + n_far;
-        const bool part = !A.lazy.packed && m_all > kRedoPartMin;
+        // (two launches: k_redo_sort left the bin's ids fully sorted in those slots -- or, had its sample failed, untouched:
+        // then every block selects from the whole list, the slots being shared with the bin's other workgroups)
+        const bool sorted = two && A.lazy.redo_flag[tile] == 2;
+        const bool part = !two && !A.lazy.packed && m_all > kRedoPartMin;
         int32_t *perm_near = const_cast<int32_t *>(A.flatten_ids) + start;
         int32_t *perm_far = const_cast<int32_t *>(A.flatten_ids) + far_base;
         auto key_of = [&](int e) __attribute__((always_inline)) { return e < n ? kin[e] : fkeys[e - n]; };
@@ -647,7 +858,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
             pshift = max(0, (span ? 64 - __clzll((long long)span) : 0) - 11);
             for (int e = tid; e < m_all; e += 256) atomicAdd(&s_cnt[(unsigned int)((key_of(e) - pk_min) >> pshift)], 1u);
             __syncthreads();
-            {   // exclusive scan of the 2 048 counters: thread t owns buckets 8 t .. 8 t + 7
+            {   // exclusive scan of the counters: thread t owns buckets 8 t .. 8 t + 7
                 unsigned int c[8], sum = 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { c[j] = s_cnt[8 * tid + j]; sum += c[j]; }
@@ -688,7 +899,7 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
         // the next frame keeps every pair of a tile that outlived its front (k_tile_front, which ran before this
         // launch, has just set the cut-off where that front ended)
         if (A.lazy.tau_next && tid == 0) A.lazy.tau_next[tile] = 0xffffffffu;
-        for (int sub = 0; sub < A.nsub; ++sub) {
+        for (int sub = sub_lo; sub < sub_hi; ++sub) {
             const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
             if (A.lazy.packed) {   // a bin at the edge of a band: only the block rows inside it (uniform)
                 const int brow = tile_y * A.nsx + sub_y;
@@ -705,9 +916,133 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
             float T = ms::kTScale, kq = in ? ms::kFlushK : 0.f, pix[CP];   // k_rasterize_fwd's flush select and scaled state
 #pragma unroll
             for (int k = 0; k < CP; ++k) pix[k] = 0.f;
+            // one staged entry (this thread's slot of the 256) -- `pre`: its record, already in registers -- and the blend of
+            // the m staged entries into this wave's quad
+            auto stage_entry = [&](unsigned int word, const float4 *pre) __attribute__((always_inline)) -> int {
+                const int g = min(max((int)(A.lazy.packed ? word >> 4 : word), 0), A.n_gauss - 1);
+                // opacity below 1/255 can never blend: log2 -> -inf keeps alpha at 0
+                // (split frames: nor can an entry that is not on this block's list)
+                const bool listed = !A.lazy.packed || ((word >> sub) & 1u);
+                if constexpr (CP == 3) {
+                    if (A.records) {
+                        // the frame's ready-made records: the same staged values, and the only per-Gaussian
+                        // data a pre-culled band frame can be asked for by list id (ids are positions in
+                        // the band's candidate list there, not indices into the caller's arrays)
+                        const float4 *rec = A.records + 3 * (size_t)g;
+                        const float4 ra = pre ? pre[0] : rec[0], rb = pre ? pre[1] : rec[1], rc = pre ? pre[2] : rec[2];
+                        // which of the block's four 8x8 quads the entry can reach at all: the forward kernel's
+                        // exact ellipse-vs-quad test on the record's three numbers (log2 units) -- a wave skips
+                        // what cannot blend in its quad (a 64-px bin's list is ~94 % misses for any one quad)
+                        int hit = 0;
+                        const float smax = rc.y, nb_c = rc.z, nb_a = rc.w;
+                        if (smax == kInf) {
+                            hit = 0xf;
+                        } else if (smax > -kInf) {
+                            const float fbx = (float)(tile_x * A.ts + sub_x * 16) + 0.5f, fby = (float)(tile_y * A.ts + sub_y * 16) + 0.5f;
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) {
+                                const float xl = fbx + (float)((qq & 1) * 8) - ra.x, xh = xl + 7.0f;
+                                const float yl = fby + (float)((qq >> 1) * 8) - ra.y, yh = yl + 7.0f;
+                                const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
+                                float best = (in_x && in_y) ? 0.f : 3.0e38f;
+                                if (!in_x) {
+                                    const float ddx = xl > 0.f ? xl : xh;
+                                    const float ddy = fminf(fmaxf(nb_c * ddx, yl), yh);
+                                    best = -(ra.z * ddx * ddx + rb.x * ddy * ddy + ra.w * ddx * ddy);
+                                }
+                                if (!in_y) {
+                                    const float ddy = yl > 0.f ? yl : yh;
+                                    const float ddx = fminf(fmaxf(nb_a * ddy, xl), xh);
+                                    best = fminf(best, -(ra.z * ddx * ddx + rb.x * ddy * ddy + ra.w * ddx * ddy));
+                                }
+                                hit |= (best <= smax) ? (1 << qq) : 0;
+                            }
+                        }
+                        s_pa[tid] = ra;
+                        s_pb[tid] = make_float4(rb.x, rc.y > -kInf && listed ? rb.y : -kInf, __int_as_float(hit), 0.f);
+                        s_pc[tid * CP] = rb.z; s_pc[tid * CP + 1] = rb.w; s_pc[tid * CP + 2] = rc.x;
+                        return hit;
+                    }
+                }
+                {
+                    const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
+                    const float ca = A.conics[3 * g], cb = A.conics[3 * g + 1], cc = A.conics[3 * g + 2];
+                    const float op = A.opacities[g];
+                    s_pa[tid] = make_float4(m.x, m.y, -0.5f * kLog2e * ca, -kLog2e * cb);
+                    s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold && listed ? __log2f(op) : -kInf, __int_as_float(0xf), 0.f);
+#pragma unroll
+                    for (int k = 0; k < CP; ++k)
+                        s_pc[tid * CP + k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
+                }
+                return 0xf;
+            };
+            // (which staged entries reach which quad: 64-bit masks, one per quad and staging wave -- a wave walks the set bits of
+            // its quad's four instead of testing 256 entries of which a 64-px bin's list lets ~6 % through)
+            auto publish_hits = [&](int hit) __attribute__((always_inline)) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const unsigned long long hm = __ballot((hit >> qq) & 1);
+                    if (lane == 0) s_hit[qq * 4 + w] = hm;
+                }
+            };
+            auto blend = [&]() __attribute__((always_inline)) {
+                if (!__any(kq != 0.f)) return;   // (a wave whose pixels are all finished has nothing to blend)
+#pragma unroll 1
+                for (int ww = 0; ww < 4; ++ww) {
+                  const unsigned long long hm_v = s_hit[w * 4 + ww];
+                  unsigned long long hm = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(hm_v >> 32)) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readfirstlane((int)hm_v);
+                  while (hm) {
+                    const int t = ww * 64 + __builtin_ctzll(hm);
+                    hm &= hm - 1ull;
+                    const float4 rb = s_pb[t];
+                    const float4 ra = s_pa[t];
+                    const float dx = ra.x - px, dy = ra.y - py;
+                    const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
+                    // k_rasterize_fwd's generic (CHECK) arithmetic, operation for operation
+                    float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
+                    alpha = la <= rb.y ? alpha : 0.f;
+                    const float mj = alpha * kq;
+                    const float vj = mj * T;
+                    const float nt = fmaf(vj, -ms::kAlphaOfV, T);
+                    const bool dead = !(nt > ms::kTransmittanceStop * ms::kTScale);
+                    const float vis = dead ? 0.f : vj;
+                    kq = dead ? 0.f : kq;
+#pragma unroll
+                    for (int k = 0; k < CP; ++k) pix[k] += s_pc[t * CP + k] * vis;
+                    T = dead ? T : nt;
+                  }
+                }
+            };
+            if (sorted) {
+                // the bin's ids in depth order (k_redo_sort): staged 256 at a time like a chunk below, the next 256 records on
+                // their way while these are blended; done when the block's four quads are, or the list is
+                auto word_at = [&](int i) __attribute__((always_inline)) { return (unsigned int)(i < n ? perm_near[i] : perm_far[i - n]); };
+                bool ahead = false;
+                if constexpr (CP == 3) ahead = A.records != nullptr;
+                float4 nx[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+                auto fetch = [&](int i) __attribute__((always_inline)) {
+                    if (ahead && i < m_all) {
+                        const int g = min(max((int)word_at(i), 0), A.n_gauss - 1);
+                        const float4 *rec = A.records + 3 * (size_t)g;
+                        nx[0] = rec[0]; nx[1] = rec[1]; nx[2] = rec[2];
+                    }
+                };
+                fetch(tid);
+                for (int e0 = 0; e0 < m_all; e0 += 256) {
+                    const bool wa = __any(kq != 0.f);
+                    if (lane == 0) s_alive[w] = wa ? 1 : 0;
+                    __syncthreads();   // (the previous 256 are blended; the waves' flags are in)
+                    if (!(s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3])) break;   // (uniform)
+                    publish_hits(e0 + tid < m_all ? stage_entry(word_at(e0 + tid), ahead ? nx : nullptr) : 0);
+                    __syncthreads();
+                    fetch(e0 + 256 + tid);
+                    blend();
+                }
+            }
             unsigned long long lower = 0ull;   // keys consumed so far are <= lower (exclusive bound once !first)
             bool first = true;
-            for (;;) {
+            for (; !sorted;) {
                 // ---- (1) next chunk: window [wlo, whi] over eligible keys
                 if (!first && lower == ~0ull) break;   // nothing can follow the largest key (and lower + 1 would wrap)
                 unsigned long long wlo = first ? 0ull : lower + 1ull, whi = ~0ull;
@@ -835,87 +1170,9 @@ __global__ __launch_bounds__(256) void k_tile_redo(RasterArgs A) {
                 // ---- (2) composite the chunk, 256 entries staged at a time
                 for (int e0 = 0; e0 < F; e0 += 256) {
                     __syncthreads();
-                    if (e0 + tid < F) {
-                        const unsigned int word = (unsigned int)s_key[e0 + tid];
-                        const int g = min(max((int)(A.lazy.packed ? word >> 4 : word), 0), A.n_gauss - 1);
-                        // opacity below 1/255 can never blend: log2 -> -inf keeps alpha at 0
-                        // (split frames: nor can an entry that is not on this block's list)
-                        const bool listed = !A.lazy.packed || ((word >> sub) & 1u);
-                        bool from_records = false;
-                        if constexpr (CP == 3) {
-                            if (A.records) {
-                                // the frame's ready-made records: the same staged values, and the only per-Gaussian
-                                // data a pre-culled band frame can be asked for by list id (ids are positions in
-                                // the band's candidate list there, not indices into the caller's arrays)
-                                const float4 *rec = A.records + 3 * (size_t)g;
-                                const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-                                // which of the block's four 8x8 quads the entry can reach at all: the forward kernel's
-                                // exact ellipse-vs-quad test on the record's three numbers (log2 units) -- a wave skips
-                                // what cannot blend in its quad (a 64-px bin's list is ~94 % misses for any one quad)
-                                int hit = 0;
-                                const float smax = rc.y, nb_c = rc.z, nb_a = rc.w;
-                                if (smax == kInf) {
-                                    hit = 0xf;
-                                } else if (smax > -kInf) {
-                                    const float fbx = (float)(tile_x * A.ts + sub_x * 16) + 0.5f, fby = (float)(tile_y * A.ts + sub_y * 16) + 0.5f;
-#pragma unroll
-                                    for (int qq = 0; qq < 4; ++qq) {
-                                        const float xl = fbx + (float)((qq & 1) * 8) - ra.x, xh = xl + 7.0f;
-                                        const float yl = fby + (float)((qq >> 1) * 8) - ra.y, yh = yl + 7.0f;
-                                        const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
-                                        float best = (in_x && in_y) ? 0.f : 3.0e38f;
-                                        if (!in_x) {
-                                            const float ddx = xl > 0.f ? xl : xh;
-                                            const float ddy = fminf(fmaxf(nb_c * ddx, yl), yh);
-                                            best = -(ra.z * ddx * ddx + rb.x * ddy * ddy + ra.w * ddx * ddy);
-                                        }
-                                        if (!in_y) {
-                                            const float ddy = yl > 0.f ? yl : yh;
-                                            const float ddx = fminf(fmaxf(nb_a * ddy, xl), xh);
-                                            best = fminf(best, -(ra.z * ddx * ddx + rb.x * ddy * ddy + ra.w * ddx * ddy));
-                                        }
-                                        hit |= (best <= smax) ? (1 << qq) : 0;
-                                    }
-                                }
-                                s_pa[tid] = ra;
-                                s_pb[tid] = make_float4(rb.x, rc.y > -kInf && listed ? rb.y : -kInf, __int_as_float(hit), 0.f);
-                                s_pc[tid * CP] = rb.z; s_pc[tid * CP + 1] = rb.w; s_pc[tid * CP + 2] = rc.x;
-                                from_records = true;
-                            }
-                        }
-                        if (!from_records) {
-                            const float2 m = reinterpret_cast<const float2 *>(A.means2d)[g];
-                            const float ca = A.conics[3 * g], cb = A.conics[3 * g + 1], cc = A.conics[3 * g + 2];
-                            const float op = A.opacities[g];
-                            s_pa[tid] = make_float4(m.x, m.y, -0.5f * kLog2e * ca, -kLog2e * cb);
-                            s_pb[tid] = make_float4(-0.5f * kLog2e * cc, op >= ms::kAlphaThreshold && listed ? __log2f(op) : -kInf, __int_as_float(0xf), 0.f);
-#pragma unroll
-                            for (int k = 0; k < CP; ++k)
-                                s_pc[tid * CP + k] = k < A.cdim ? load_color(colors + (size_t)g * A.cdim + k) : 0.f;
-                        }
-                    }
+                    publish_hits(e0 + tid < F ? stage_entry((unsigned int)s_key[e0 + tid], nullptr) : 0);
                     __syncthreads();
-                    const int m = min(256, F - e0);
-                    const bool wave_alive = __any(kq != 0.f);   // (a wave whose pixels are all finished has nothing to blend)
-                    for (int t = 0; wave_alive && t < m; ++t) {
-                        const float4 rb = s_pb[t];
-                        if (!((__float_as_int(rb.z) >> w) & 1)) continue;   // (wave-uniform: this wave's quad is out of the entry's reach)
-                        const float4 ra = s_pa[t];
-                        const float dx = ra.x - px, dy = ra.y - py;
-                        const float la = fmaf(dx, fmaf(ra.z, dx, ra.w * dy), fmaf(rb.x * dy, dy, rb.y));
-                        // k_rasterize_fwd's generic (CHECK) arithmetic, operation for operation
-                        float alpha = fminf(ms::kMaxAlpha, __builtin_amdgcn_exp2f(la));
-                        alpha = la <= rb.y ? alpha : 0.f;
-                        const float mj = alpha * kq;
-                        const float vj = mj * T;
-                        const float nt = fmaf(vj, -ms::kAlphaOfV, T);
-                        const bool dead = !(nt > ms::kTransmittanceStop * ms::kTScale);
-                        const float vis = dead ? 0.f : vj;
-                        kq = dead ? 0.f : kq;
-#pragma unroll
-                        for (int k = 0; k < CP; ++k) pix[k] += s_pc[t * CP + k] * vis;
-                        T = dead ? T : nt;
-                    }
+                    blend();
                 }
                 // ---- (3) anyone still alive?
                 const bool wa = __any(kq != 0.f);
@@ -984,7 +1241,9 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
         if (A.lazy.front_count) {
             // (depth-cut frame: the pairs -- and records -- the redone bins are short of, first: binning.hip, k_far_regen)
             if (A.lazy.cut_stamp) (void)ms::far_regen(A.lazy, A.tw, A.tw * ((A.H + A.ts - 1) / A.ts), (int64_t)A.max_isects, stream);
-            hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(redo_grid(A)), dim3(256), 0, stream, A);
+            // (frames that can expect stranded bins: their keys sorted whole first, then a workgroup per 16x16 block)
+            if (A.lazy.redo_sort) hipLaunchKernelGGL(k_redo_sort, dim3(512), dim3(kSortThreads), 0, stream, A);
+            hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(A.lazy.redo_sort ? 1024u : redo_grid(A)), dim3(256), 0, stream, A);
         }
     }
 }

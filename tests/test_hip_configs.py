@@ -213,10 +213,11 @@ def test_config3_crop_backward_vs_float64_autograd(device, x0, y0):
 def test_scene_swap_at_config4_is_exact_and_bounded(device):
     """The worst frame the lazy machinery can meet (scripts/cut_miss_cost.py): config 4 on 64-px bins with depth cut-offs,
     then the same Gaussians with the near half all but transparent -- every bin outlives both its cut-off and its sorted
-    front.  Each frame on the way must be bit-identical to the per-stage path of ITS scene; the clean-up pass is slow by
-    design (one workgroup per bin), so the bound here is on what the lane learns: the swapped scene's first frame within
-    150 ms (round 2: 14 s), full sorts from its third frame on at the latest (<= 8 ms: the fully sorted path), and the
-    original scene again within two frames of the swap back."""
+    front.  Each frame on the way must be bit-identical to the per-stage path of ITS scene.  Bounds: the swapped scene's
+    frames within 15 ms each (round 2: 14 s; round 3 and the first half of round 4: 72-85 ms, one workgroup per stranded
+    bin walking its sixteen blocks in turn; since the two-launch clean-up -- rasterize.hip, k_redo_sort -- 4.8-5.9 ms
+    measured, against 3.9 ms for the same scene on the fully sorted path), full sorts from its third frame on at the latest
+    (<= 8 ms), and the original scene again within two frames of the swap back."""
     import time
     sc, cam, g = _scene("cfg4", device)
     bg = torch.tensor(BACKGROUND_V1, device=device).to(sc["features"].dtype)
@@ -249,6 +250,6 @@ def test_scene_swap_at_config4_is_exact_and_bounded(device):
     print("scene swap at config 4, ms per synchronised frame:", [round(t, 2) for t in times], stats)
     assert stats.get("depth_cut", 0) >= 2            # the steady frames before the swap were cut
     assert stats.get("redo_tiles", 0) + stats.get("cut_redo_tiles", 0) > 100   # ... and the swap did strand the bins
-    assert max(times[5:9]) <= 150.0
+    assert max(times[5:9]) <= 15.0
     assert times[7] <= 8.0 and times[8] <= 8.0       # full sorts by the swapped scene's third frame
     assert max(times[10:]) <= 3.0

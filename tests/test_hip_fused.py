@@ -373,6 +373,38 @@ def test_clean_up_pass_with_fp16_colours(device, default_grid_only, n, z_hi, opa
     _fused._state.clear()
 
 
+@pytest.mark.parametrize("n,z_lo,z_hi,opacity", [
+    (4000, 4.0, 6.0, 0.005),        # one 64-px bin of < 4 096 entries: sorted in LDS in one go
+    (16000, 5.0, 5.0, 0.0055),      # ONE depth, 16 000 entries: the sample sort's splitters differ in the index bits alone
+    (20000, 4.0, 6.0, 0.0045),      # 20 000 entries over a depth range: splitters, buckets, windows
+    (9000, 4.0, 4.0001, 0.0045)])   # a handful of depth values
+@pytest.mark.parametrize("px", [64, 32])
+def test_two_launch_clean_up_on_coarse_bins(device, n, z_lo, z_hi, opacity, px):
+    """Round 4: frames that can expect stranded bins (bins of 48 px and more; any grid once the previous frame redid a
+    bin) sort each stranded bin's keys whole in one launch (rasterize.hip, k_redo_sort: LDS bitonic sort up to 4 096
+    entries, sample sort beyond) and composite one workgroup per 16x16 block in the next.  The lane is kept on lazily
+    sorted fronts (it would go to full sorts after the first failure), so every frame after the first runs the
+    clean-up; all must equal the fully sorted per-stage path bit for bit -- fp32 and fp16 colours."""
+    sc, cam = _stack_scene(n, z_lo, z_hi, opacity, device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"])
+    for feats, bgc in ((sc["features"], bg), (sc["features"].half(), bg.half())):
+        ref = stagewise(dict(sc, features=feats), cam, bgc, 16)
+        _fused._state.clear()
+        _fused.FRAME_STATS = stats = {}
+        try:
+            for _ in range(5):
+                img = ms.render_gaussians(*g, feats, cam, background_color=bgc, backend="hip", bin_size=px)
+                assert torch.equal(img, ref)
+                st = _fused._dev_state(sc["means3d"].device, 0)
+                st["full_sort"] = False
+                st["front_level"] = 0
+        finally:
+            _fused.FRAME_STATS = None
+            _fused._state.clear()
+        assert stats.get("redo_tiles", 0) >= 2, stats   # (reported one frame late: at least two frames redid their bins)
+
+
 def test_binning_rule_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
     """A pile of faint Gaussians: the lazily sorted split frame fails its fronts and the lane falls back to
     full sorts, while render_gaussians' binning rule (big footprints -> plain coarse bins) moves the grid
