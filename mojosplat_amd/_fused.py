@@ -9,6 +9,7 @@ intermediates (project_gaussians / bin_gaussians_to_tiles / rasterize_gaussians)
 """
 import ctypes
 import math
+import time
 import os
 import threading
 
@@ -478,11 +479,67 @@ def render_batch_hip(means3d, scales, quats, opacities, colors, cameras, backgro
 
 
 _lanes = {}
+LANE_CALIBRATION = {}   # device -> what _lane_streams measured when it chose the two lane streams (diagnostics)
 
 
 def _lane_streams(dev):
+    """The two streams that frames in flight at the same time alternate between (multi-view batches, the asynchronous
+    single-GPU and sharded entry points).
+
+    Round 4: which two streams is not indifferent.  The runtime spreads a process's streams over a few hardware queues in
+    the order of their first use, and two streams that land on one queue -- or on two queues of one pipe, whose wide
+    kernels the dispatcher takes one after the other -- do not overlap at all: measured at config 3, the third and fourth
+    stream a process uses render 0.166 ms a frame (the blocking call's rate), every other pair tried 0.144
+    (`scripts/two_lane_probe.py`), and a wait put on the CALLER's stream stalls a lane that shares its queue.  So the
+    lanes are chosen once per device from six candidates by a 2 ms calibration: a single-thread spin kernel
+    (torch.cuda._sleep) on each of two streams takes ~1.1x one kernel's time when they are independent, 1.3x on the pair
+    that did not overlap, 2.0x on one queue; the most independent pair wins, streams that share the caller's queue
+    excluded.  MOJOSPLAT_LANE_CALIBRATION=0: the first two streams created, as before."""
     ls = _lanes.get(dev)
-    if ls is None:
-        ls = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    if ls is not None:
+        return ls
+    with _frame_lock:
+        ls = _lanes.get(dev)
+        if ls is not None:
+            return ls
+        cand = [torch.cuda.Stream(device=dev) for _ in range(6)]
+        pick, rec = (0, 1), {"calibrated": False}
+        sleep = getattr(torch.cuda, "_sleep", None)
+        if sleep is not None and os.environ.get("MOJOSPLAT_LANE_CALIBRATION", "1") != "0":
+            try:
+                cur = torch.cuda.current_stream(dev)
+                cycles = 150000
+
+                def spin(*streams):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for s_ in streams:
+                        with torch.cuda.stream(s_):
+                            sleep(cycles)
+                    torch.cuda.synchronize(dev)
+                    return time.perf_counter() - t0
+                with torch.cuda.device(dev):
+                    for s_ in cand:
+                        spin(s_)          # (first use, in this order)
+                    solo = min(spin(cand[0]) for _ in range(3))
+                    with_cur = [min(spin(cur, s_) for _ in range(2)) / solo for s_ in cand]
+                    best = None
+                    pairs = {}
+                    for a in range(len(cand)):
+                        for b in range(a + 1, len(cand)):
+                            r = min(spin(cand[a], cand[b]) for _ in range(2)) / solo
+                            pairs[f"{a},{b}"] = round(r, 2)
+                            # (the pair's own independence first; a lane on the caller's QUEUE -- ~2x -- is out: the waits
+                            # put on the caller's stream would stall it)
+                            score = r + (10.0 if max(with_cur[a], with_cur[b]) > 1.6 else 0.1 * max(with_cur[a], with_cur[b]))
+                            if best is None or score < best[0] - 0.01:
+                                best = (score, (a, b))
+                pick = best[1]
+                rec = {"calibrated": True, "solo_us": round(solo * 1e6, 1), "with_current_stream": [round(x, 2) for x in with_cur],
+                       "pairs": pairs, "picked": list(pick), "ratio_of_the_pick": pairs[f"{pick[0]},{pick[1]}"]}
+            except Exception as e:  # noqa: BLE001  (a calibration that cannot run must not take the renderer down)
+                rec = {"calibrated": False, "error": repr(e)}
+        LANE_CALIBRATION[dev] = rec
+        ls = [cand[pick[0]], cand[pick[1]]]
         _lanes[dev] = ls
-    return ls
+        return ls

@@ -212,6 +212,38 @@ def tune_binning(means3d, scales, quats, opacities, features, camera, background
     return min(times, key=times.get), times
 
 
+def _begin_async(means3d, scales, quats, opacities, colors, camera, bg, mode, evs, info, learn):
+    """render_gaussians(async_op=True): the frame on a lane stream (ms_render_fwd BEGIN, no host wait), as the sharded
+    entry point runs a rank's band (distributed.py) -- streams addressed by handle and ordered with the lanes' persistent
+    events; torch's current stream is never switched."""
+    from ._fused import _Frame, _lane_streams
+    from .distributed import PendingFrame, _current_stream, _lane_events, _turn
+    dev = means3d.device
+    cur = _current_stream(dev)
+    lane = _turn.get(dev, 0)
+    _turn[dev] = 1 - lane
+    s = _lane_streams(dev)[lane]
+    # marshal first (copies of non-fp32 / strided inputs are enqueued on the CURRENT stream), then order the lane behind it
+    frame = _Frame(means3d, scales, quats, opacities, colors, camera, bg, mode, evs, None, None, 1 + lane, s.cuda_stream)
+    ev_in, ev_out = _lane_events(dev, lane)
+    ev_in.record(cur)
+    s.wait_event(ev_in)
+    frame.begin()
+    seen = set()
+    for t in (means3d, scales, quats, opacities, colors, bg, frame.img) + tuple(x for x in frame.keep[:-1] if x is not None):
+        if id(t) not in seen:     # (the caching allocator must not hand their memory out again before the lane is done)
+            seen.add(id(t))
+            t.record_stream(s)
+
+    def finalize():
+        img, m = frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
+        learn(m)
+        ev_out.record(s)
+        _current_stream(dev).wait_event(ev_out)
+        return img
+    return PendingFrame(finalize=finalize)
+
+
 @torch.no_grad()
 def render_gaussians(
     means3d: torch.Tensor,    # (N, 3) world coordinates
@@ -225,7 +257,15 @@ def render_gaussians(
     tile_size: int = TILE_SIZE,
     backend: str = "hip",
     bin_size: Optional[int] = None,   # hip backend, tile_size 16: 16 (split frame) | 32 | 64; None = the rule above
+    async_op: bool = False,           # hip backend: -> a PendingFrame (see below); use it one frame ahead
 ) -> torch.Tensor:
+    """The reference's entry point (render.py:20-103).  async_op=True (hip backend, round 4) enqueues the frame on one of
+    two lane streams -- own scratch each -- without any host wait and returns a `PendingFrame`; `.wait()` completes it on the
+    host side (size-record check), makes the CURRENT stream wait for it and hands out the image.  Meant to be used one
+    frame ahead -- `nxt = render_gaussians(..., async_op=True); img = cur.wait(); cur = nxt` -- so that the kernels of two
+    frames overlap (one frame's latency-bound binning under the other's rasteriser): 0.147 ms a frame against 0.166 for
+    back-to-back blocking calls at config 3 (`scripts/two_lane_probe.py`).  At most two frames may be pending; the
+    inputs must stay unmodified until `.wait()` returns."""
     required = [means3d, scales, quats, opacities, features]
     if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in required):
         raise ValueError("All input gaussian tensors must be CUDA tensors.")
@@ -275,16 +315,23 @@ def render_gaussians(
                 with _bin_lock:
                     mode = _bin_mode.get(key, TILE_SIZE)
             info = {}
+
+            def learn(m):
+                if key is not None:
+                    # (a frame at mode 16 is a split frame -- 32-px bins, flag bit 3 -- unless its lane has fallen back
+                    # to fully sorted 16-px tiles: then the pairs were counted on those)
+                    grid = (32 if info["flags"] & 8 else 16) if mode == TILE_SIZE else mode
+                    _settle(key, mode, bin_rule(mode, m, info["on_grid"], camera.W, camera.H, grid_px=grid))
+            if async_op:
+                return _begin_async(means3d, scales, quats, opacities, colors, camera, bg, mode, evs, info, learn)
             img, m = render_fwd_hip(means3d, scales, quats, opacities, colors, camera, bg, mode,
                                     stage_events=evs, info=info)
-            if key is not None:
-                # (a frame at mode 16 is a split frame -- 32-px bins, flag bit 3 -- unless its lane has fallen back
-                # to fully sorted 16-px tiles: then the pairs were counted on those)
-                grid = (32 if info["flags"] & 8 else 16) if mode == TILE_SIZE else mode
-                _settle(key, mode, bin_rule(mode, m, info["on_grid"], camera.W, camera.H, grid_px=grid))
+            learn(m)
             return img
         # tile grids beyond the binning kernels' LDS budget (> ~40.9k tiles, e.g. 8K x 4K frames) are
         # rendered as consecutive row bands into one framebuffer
+        if async_op:
+            raise ValueError("async_op: frames of more than one row band are rendered by the blocking call")
         img = torch.empty((camera.H, camera.W, colors.shape[-1]), dtype=torch.float32, device=means3d.device)
         info = {}
         for band in bands:
@@ -293,6 +340,8 @@ def render_gaussians(
         # zeros when no Gaussian's box touches the grid (band-independent count, render.py:73-76)
         return img if info["on_grid"] > 0 else torch.zeros_like(img)
 
+    if async_op:
+        raise ValueError("async_op needs backend='hip'")
     means2d, conics, depths, radii = project_gaussians(means3d, scales, quats, opacities, camera,
                                                        backend=backend)
     sorted_ids, tile_ranges = bin_gaussians_to_tiles(means2d, radii, depths, camera.H, camera.W,

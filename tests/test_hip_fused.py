@@ -405,6 +405,42 @@ def test_two_launch_clean_up_on_coarse_bins(device, n, z_lo, z_hi, opacity, px):
         assert stats.get("redo_tiles", 0) >= 2, stats   # (reported one frame late: at least two frames redid their bins)
 
 
+def test_frames_asked_for_one_call_ahead_equal_blocking_frames(device):
+    """render_gaussians(async_op=True): two frames in flight on two lane streams, .wait() one frame later.  Every frame
+    equals the blocking call's, through a change of scene and of colour dtype between pending frames, an empty scene
+    (zeros, not background) and a consumer on the caller's stream right behind .wait()."""
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    scenes = []
+    for n, w, h, ell, seed in ((30000, 640, 360, -3.5, 1), (120000, 1280, 720, -4.0, 2), (5000, 333, 205, -3.0, 3)):
+        sc, cam = randscene_v1(n, w, h, ell=ell, seed=seed, device=device)
+        scenes.append((sc, cam, bg))
+    sc16 = dict(scenes[1][0]); sc16["features"] = sc16["features"].half()
+    scenes.append((sc16, scenes[1][1], bg.half()))
+    far = dict(scenes[0][0]); far["means3d"] = far["means3d"] + torch.tensor([0.0, 0.0, -500.0], device=device)
+    scenes.append((far, scenes[0][1], bg))                      # behind the camera: nothing on the grid
+    g = lambda s_: (s_["means3d"], s_["scales"], s_["quats"], s_["opacities"], s_["features"])
+    _fused._state.clear()
+    refs = [ms.render_gaussians(*g(s_), c_, background_color=b_, backend="hip") for s_, c_, b_ in scenes]
+    assert float(refs[-1].abs().max()) == 0.0
+    order = [0, 1, 0, 3, 1, 4, 2, 2, 3, 0, 4, 1]
+    pend, got = None, []
+    for k in order:
+        s_, c_, b_ = scenes[k]
+        nxt = ms.render_gaussians(*g(s_), c_, background_color=b_, backend="hip", async_op=True)
+        if pend is not None:
+            img = pend[1].wait()
+            got.append((pend[0], img, img.sum()))               # (a kernel on the caller's stream right behind the wait)
+        pend = (k, nxt)
+    img = pend[1].wait()
+    got.append((pend[0], img, img.sum()))
+    for k, img, total in got:
+        assert torch.equal(img, refs[k]), f"scene {k}"
+        assert float(total) == float(refs[k].sum())
+    with pytest.raises(ValueError):
+        ms.render_gaussians(*g(scenes[0][0]), scenes[0][1], backend="torch", async_op=True)
+    _fused._state.clear()
+
+
 def test_binning_rule_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
     """A pile of faint Gaussians: the lazily sorted split frame fails its fronts and the lane falls back to
     full sorts, while render_gaussians' binning rule (big footprints -> plain coarse bins) moves the grid
