@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
     LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth, const uint32_t *__restrict__ tau,
     uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp, LeanRec *__restrict__ near_recs,
-    int keep_arrays) {
+    int keep_arrays, int64_t near_cap) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes]
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
@@ -558,8 +558,9 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
         // depth-cut frame: the rasteriser's record of a Gaussian is only written once it is known to keep a pair (48 of
         // the ~120 bytes this kernel moves per Gaussian; the clean-up launch writes the record of a dropped Gaussian it
         // brings back: rasterize.hip, k_far_regen) -- what it is made of waits in these
-        // (never a band's gathered candidates: such a frame reads its inputs at threadIdx.x of the step's slice)
         bool rec_pending = false;
+        int64_t rec_b0 = 0;        // (a band's gathered candidates: the whole arrays and the Gaussian's index)
+        uint32_t rec_src = 0u;
         float rec_m0 = 0.f, rec_m1 = 0.f, rec_c0 = 0.f, rec_c1 = 0.f, rec_c2 = 0.f;
         auto write_record = [&](int64_t b0, uint32_t rec_src, float m0, float m1, float c0, float c1, float c2) __attribute__((always_inline)) {
             // the rasteriser's staged record, ready made (ms::RasterRecord, ms_common.hpp): three 16-byte
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             if (rec && o.r0 > 0 && o.r1 > 0) {
                 if constexpr (CUT) {
                     rec_pending = true;
+                    rec_b0 = b0; rec_src = src;
                     rec_m0 = o.m0; rec_m1 = o.m1; rec_c0 = o.c0; rec_c1 = o.c1; rec_c2 = o.c2;
                 } else {
                     write_record(b0, src, o.m0, o.m1, o.c0, o.c1, o.c2);
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             }, dbits_of_step);
             // (boxes the whole wave walked: kept whatever the cut-offs say -- their owner does not know)
             const bool keep = near32 != 0u || n > kCoopThreshold;
-            if (rec_pending && keep) write_record(base, (uint32_t)threadIdx.x, rec_m0, rec_m1, rec_c0, rec_c1, rec_c2);
+            if (rec_pending && keep) write_record(rec_b0, rec_src, rec_m0, rec_m1, rec_c0, rec_c1, rec_c2);
             const unsigned long long kb = __ballot(keep);
             if (kb) {
                 const int lane = threadIdx.x & 63;
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 if (keep) {
                     const unsigned int pos = wbase + (unsigned int)__popcll(kb & ((1ull << lane) - 1ull));
                     const uint32_t box = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24);
-                    reinterpret_cast<uint4 *>(near_recs)[i0 + pos] = make_uint4(box, (uint32_t)gi, dbits_of_step, near32);
+                    reinterpret_cast<uint4 *>(near_recs)[(int64_t)wg * near_cap + pos] = make_uint4(box, (uint32_t)gi, dbits_of_step, near32);
                 }
             }
         } else {
@@ -774,7 +776,8 @@ struct ScanTotalArgs {
     const uint32_t *wg_far;
     const uint32_t *tau;
     uint32_t cut_stamp;
-    const LeanRec *near_recs;   // the records that keep a pair, compacted per count workgroup (wg_far[kMaxG + g] of them from g * chunk on)
+    const LeanRec *near_recs;   // the records that keep a pair, compacted per count workgroup (wg_far[kMaxG + g] of them from g * near_cap on)
+    int64_t near_cap;
     uint32_t *far_zero;   // 2 T words the clean-up launches count the regenerated pairs in: zeroed by the total pass
 };
 
@@ -1234,7 +1237,11 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     // held against the cut-offs here.  This workgroup walks those records alone.
     bool cut = false;
     if constexpr (LEAN == 2 && DEFER) cut = A.cut_stamp != 0u;
-    if (cut) i1 = i0 + (int64_t)A.wg_far[kMaxG + wg];
+    if (cut) {   // (whatever the walk above would have been -- a chunk, or a band's candidate steps)
+        i0 = (int64_t)wg * A.near_cap;
+        i1 = i0 + (int64_t)A.wg_far[kMaxG + wg];
+        stride = kHistThreads;
+    }
     // (LEAN == 2: a 12-byte record, kept as its three words while it waits -- three registers a record in flight, not
     // six: at 2 x kAhead records the kernel must stay within the 64 registers that let two workgroups share a CU --
     // and unpacked into the 16-byte form when its turn comes)
@@ -1695,6 +1702,7 @@ __global__ __launch_bounds__(256) void k_offset_encode(int64_t M, const int64_t 
 struct Plan {
     int G;
     int64_t chunk;
+    int64_t near_cap;   // depth-cut frames: the stride of a count workgroup's compacted records (>= what any workgroup walks, band candidates included)
     int T, T_local;
     size_t lds_bytes;
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
@@ -1713,6 +1721,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     if (p.lds_bytes > 64 * 1024 && G > 256) G = 256;
     p.chunk = ms::ceil_div(N > 0 ? N : 1, G);
     p.G = (int)ms::ceil_div(N > 0 ? N : 1, p.chunk);
+    p.near_cap = ms::ceil_div(ms::ceil_div(N > 0 ? N : 1, (int64_t)kHistThreads), (int64_t)p.G) * kHistThreads;
     // workspace carve-up is sized for the FULL grid so one buffer serves any band
     size_t o = 0;
     p.off_hist = o;   o += ms::align_up((size_t)kMaxG * p.T * 4, 256);
@@ -1738,7 +1747,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     p.off_mask = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 8, 256);  // tight binning: reach masks
     p.off_cand = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * 4, 256);  // band pre-cull: candidate list
     p.off_lean = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * sizeof(LeanRec), 256);  // lean frames: box + depth per position
-    p.off_near = o;   o += ms::align_up((size_t)(N > 0 ? N : 1) * sizeof(LeanRec), 256);  // depth-cut frames: the records that keep a pair, compacted per count workgroup
+    p.off_near = o;   o += ms::align_up((size_t)((N > 0 ? N : 1) + (int64_t)kHistThreads * (kMaxG + 1)) * sizeof(LeanRec), 256);  // depth-cut frames: the records that keep a pair, compacted per count workgroup (G strides of near_cap)
     p.total = o;
     return p.lds_bytes <= kMaxLds;
 }
@@ -1779,7 +1788,7 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
                int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream, bool defer_total = false) {
     ScanTotalArgs A{g, count, tile_ranges, medium, large, xl, wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag),
                     (int32_t *)(ws + p.off_redo_count), band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order),
-                    (uint32_t *)wg_on_grid + kMaxG, nullptr, nullptr, 0u, nullptr, nullptr};
+                    (uint32_t *)wg_on_grid + kMaxG, nullptr, nullptr, 0u, nullptr, 0, nullptr};
     if (defer_total && p.T_local > 0) {
         // the per-tile prefix over the partial rows alone: the total pass rides in the scatter launch (deferred_total)
         A.ticket = nullptr;
@@ -1904,8 +1913,9 @@ struct RegenProject {
     ms::ProjParams P;
     float4 *rec;
     Grid g;
+    Candidates cand;   // a pre-culled band: positions of its candidate list (ids: null otherwise)
 };
-constexpr int kRegenThreads = 256, kRegenMaxTiles = 65536;
+constexpr int kRegenThreads = 512, kRegenMaxTiles = 65536;   // (512: a band's candidate map wants a thread per segment)
 template <int PASS>
 __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, int tw, int n_tiles, int64_t cap, RegenProject R, int lds_tiles) {
     const int n_redo = min(*Z.redo_count, n_tiles);
@@ -1961,20 +1971,29 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
         __syncthreads();
     }
     const int64_t near = Z.cut_words[0];
+    __shared__ uint32_t s_pref[kMaxG + 1];
+    CandMap cmap{s_pref};
+    int64_t n_items = Z.n_lean;
+    if (R.cand.ids) {   // (uniform)
+        cmap.build(R.cand);
+        n_items = (int64_t)s_pref[R.cand.n_segs];
+    }
     // the pairs a Gaussian has behind the cut-offs of the marked bins: fn(bin) for each, -> whether there was one
     // (box, reach mask and depth bits as the count kernel had them -- it keeps no box records on a depth-cut frame:
     // the same functions on the same inputs, in the same translation unit)
-    struct Seen { ms::ProjOut o; uint32_t db, mk; int x0, y0, bw, bh; };
+    struct Seen { ms::ProjOut o; uint32_t db, mk, src; int x0, y0, bw, bh; };
     auto visit = [&](int64_t j, Seen &v, auto &&fn) __attribute__((always_inline)) {
         v.db = 0u; v.mk = 0u; v.x0 = 0; v.y0 = 0; v.bw = 0; v.bh = 0;
-        v.o = ms::project_one<uint32_t>((uint32_t)j, R.means3d, R.scales, R.quats, R.opacities, R.viewmat, R.P);
+        // (a pre-culled band: j is a POSITION in its candidate list -- what the lists, the keys and the records are indexed by)
+        v.src = R.cand.ids ? (uint32_t)cmap.gaussian(R.cand, j) : (uint32_t)j;
+        v.o = ms::project_one<uint32_t>(v.src, R.means3d, R.scales, R.quats, R.opacities, R.viewmat, R.P);
         if (v.o.r0 > 0 && v.o.r1 > 0) {
             int bx1, by1, be;
             (void)bin_box<false>(make_float2(v.o.m0, v.o.m1), make_int2(v.o.r0, v.o.r1), R.g, v.x0, bx1, v.y0, by1, be);
             v.bw = bx1 - v.x0; v.bh = by1 - v.y0;
             if (v.bw * v.bh > 0) {
                 v.mk = v.bw * v.bh > 32 ? 0xffffffffu
-                                        : (uint32_t)reach_mask(v.o.m0, v.o.m1, v.o.c0, v.o.c1, v.o.c2, ms::ld_f32(R.opacities, (uint32_t)j, 1, 0), v.x0, bx1, v.y0, by1, R.g.ts);
+                                        : (uint32_t)reach_mask(v.o.m0, v.o.m1, v.o.c0, v.o.c1, v.o.c2, ms::ld_f32(R.opacities, v.src, 1, 0), v.x0, bx1, v.y0, by1, R.g.ts);
                 v.db = __float_as_uint(v.o.d);
             }
         }
@@ -2001,7 +2020,7 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
     if (in_lds) {
         for (int t = tid; t < n_tiles; t += kRegenThreads) s_dyn[t] = 0u;
         __syncthreads();
-        for (int64_t j = j0; j < Z.n_lean; j += jstep) (void)visit(j, v, [&](int tile) { atomicAdd(&s_dyn[tile], 1u); });
+        for (int64_t j = j0; j < n_items; j += jstep) (void)visit(j, v, [&](int tile) { atomicAdd(&s_dyn[tile], 1u); });
         __syncthreads();
         if constexpr (PASS == 0) {
             for (int t = tid; t < n_tiles; t += kRegenThreads)
@@ -2016,12 +2035,12 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
             __syncthreads();
         }
     } else if constexpr (PASS == 0) {
-        for (int64_t j = j0; j < Z.n_lean; j += jstep) (void)visit(j, v, [&](int tile) { atomicAdd(&Z.far_cnt[tile], 1u); });
+        for (int64_t j = j0; j < n_items; j += jstep) (void)visit(j, v, [&](int tile) { atomicAdd(&Z.far_cnt[tile], 1u); });
         return;
     }
     if constexpr (PASS == 1) {
         const uint32_t *s_base = s_dyn + n_tiles;
-        for (int64_t j = j0; j < Z.n_lean; j += jstep) {
+        for (int64_t j = j0; j < n_items; j += jstep) {
             const bool brought_back = visit(j, v, [&](int tile) {
                 const uint32_t slot = in_lds ? s_base[tile] + atomicAdd(&s_dyn[tile], 1u) : atomicAdd(&Z.far_cur[tile], 1u);
                 const int64_t pos = near + (int64_t)Z.far_start[tile] + (int64_t)slot;
@@ -2040,7 +2059,7 @@ __global__ __launch_bounds__(kRegenThreads) void k_far_regen(ms::LazyLists Z, in
                     for (int c = 0; c < v.bw; ++c, ++k)
                         if (((v.mk >> k) & 1u) && v.db <= Z.tau[(v.y0 + r) * tw + v.x0 + c]) kept = true;
                 if (!kept) {
-                    const uint32_t src = (uint32_t)j;
+                    const uint32_t src = v.src;
                     float col[3];
                     if (R.color_f16) {
                         const __half *cp = reinterpret_cast<const __half *>(R.colors);
@@ -2067,10 +2086,21 @@ int ms::far_regen(const ms::LazyLists &lazy, int tw, int n_tiles, int64_t cap, v
     hipStream_t stream = (hipStream_t)stream_;
     MS_REQUIRE(lazy.cut_inputs && n_tiles <= kRegenMaxTiles, MS_ERR_INVALID_ARG, "far_regen: a depth-cut frame without its inputs");
     const ms::CutInputs &I = *lazy.cut_inputs;
+    const int th_ = n_tiles / (tw > 0 ? tw : 1);
+    MS_REQUIRE(I.row_begin >= 0 && I.row_begin <= I.row_end && I.row_end <= th_, MS_ERR_INVALID_ARG, "far_regen: bad band");
+    Candidates cand{nullptr, nullptr, 0, 0};
+    if (I.band_cull) {   // the band's candidate list, where the frame's count launch left it
+        Plan p;
+        MS_REQUIRE(I.isect_workspace && make_plan(I.N, tw, th_, I.row_begin, I.row_end, p), MS_ERR_INVALID_ARG, "far_regen: a pre-culled band without its workspace");
+        const char *ws = (const char *)I.isect_workspace;
+        cand = Candidates{(const int32_t *)(ws + p.off_cand), (const int32_t *)(ws + p.off_cand_count), p.G, p.chunk};
+    }
     const RegenProject R{I.means3d, I.scales, I.quats, I.opacities, I.viewmat, I.colors, I.color_f16,
                          ms::make_proj_params(I.fx, I.fy, I.cx, I.cy, I.W, I.H, I.eps2d, I.near_plane, I.far_plane, 0.0f, I.scales_are_log,
                                               I.opacities != nullptr),
-                         (float4 *)I.records, Grid{I.tile_size, tw, n_tiles / (tw > 0 ? tw : 1), 0, n_tiles / (tw > 0 ? tw : 1), 0, 0, 0}};
+                         (float4 *)I.records,
+                         // (the band's rows: the count kernel clamped every box to them, and the reach masks' bits count from there)
+                         Grid{I.tile_size, tw, th_, I.row_begin, I.row_end, 0, 0, 0}, cand};
     // (empty launches on almost every frame -- every workgroup reads the redo count and leaves; the frame costs the same
     // whatever their number: pipeline.hip, ms_redo_grid)
     const unsigned grid = 512u;
@@ -2236,7 +2266,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                                      : lean ? k_project_hist<false, 1> : k_project_hist<false, 0>);
         // depth-cut frame: per-tile cut-offs beside the counters (the sort kernel of the previous frame left them)
         const bool cut = cut_stamp != 0u;   // (bit 9 of `tight`: which of the two cut-off buffers to read)
-        MS_REQUIRE(!cut || (lean12 && !(tight & kBandCull) && (tight & kDeferTotal)), MS_ERR_INVALID_ARG,
+        MS_REQUIRE(!cut || (lean12 && (tight & kDeferTotal)), MS_ERR_INVALID_ARG,
                    "project_isect_count: a depth-cut frame must be a lean sync-free frame on plain bins");
         const size_t lds = p.lds_bytes + (cut ? (size_t)p.T_local * 5 + 16 : 0);
         MS_REQUIRE(lds <= kMaxLds, MS_ERR_TOO_LARGE, "project_isect_count: %d tiles with cut-offs need %zu B of LDS", p.T_local, lds);
@@ -2247,7 +2277,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                            colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand,
                            (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg),
                            cut ? (const uint32_t *)(ws + p.off_tau) + (size_t)((tight >> 9) & 1) * p.T : nullptr, (uint32_t *)(ws + p.off_wg_far),
-                           (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near), (tight & ms::kTightKeepArrays) ? 1 : 0);
+                           (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near), (tight & ms::kTightKeepArrays) ? 1 : 0, p.near_cap);
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
@@ -2296,14 +2326,15 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                               (int32_t *)(ws + p.off_large), (int32_t *)(ws + p.off_xl), (const uint32_t *)(ws + p.off_on_grid), p.G,
                               (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count), defer->band_only,
                               defer->info, defer->info_mirror, (int32_t *)(ws + p.off_order), nullptr,
-                              nullptr, nullptr, 0u, nullptr, nullptr};
+                              nullptr, nullptr, 0u, nullptr, 0, nullptr};
             if (defer->cut_stamp) {
-                MS_REQUIRE(lean12 && !(tight & kBandCull) && lazy, MS_ERR_INVALID_ARG, "isect emit: a depth-cut frame must be a lean, lazily sorted frame on plain bins");
+                MS_REQUIRE(lean12 && lazy, MS_ERR_INVALID_ARG, "isect emit: a depth-cut frame must be a lean, lazily sorted frame on plain bins");
                 A.wg_far = (const uint32_t *)(ws + p.off_wg_far);
                 A.tau = (const uint32_t *)(ws + p.off_tau) + (size_t)(1 - tau_out) * p.T;
                 A.cut_stamp = defer->cut_stamp;
                 A.far_zero = (uint32_t *)(ws + p.off_far_seg);
                 A.near_recs = (const LeanRec *)(ws + p.off_near);
+                A.near_cap = p.near_cap;
             }
         }
         const size_t scatter_lds = p.lds_bytes + (A.cut_stamp ? (size_t)p.T_local * 4 + 16 : 0);

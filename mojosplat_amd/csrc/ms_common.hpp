@@ -99,6 +99,11 @@ struct CutInputs {
     int scales_are_log;
     void *records;
     int tile_size;
+    // a band frame: its rows of the binning grid, and -- pre-culled (band_cull) -- the isect workspace that holds its candidate list
+    int row_begin, row_end;
+    int64_t N;
+    const void *isect_workspace;
+    int band_cull;
 };
 struct LazyLists {
     const int32_t *front_count;

@@ -324,16 +324,22 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         // behind them but never writes or sorts them (bit 6).  Whatever the cut-offs are, the frame is exact: a bin
         // that outlives its list gets its dropped pairs back in the clean-up launches (rasterize.hip, k_far_regen).
         // (not a differentiable frame: it owns fresh scratch, nobody would read what it left)
-        const bool leaves_cutoffs = speculate && !split && lazy && !bet_light && r0 == 0 && r1 == th && ms_merged_sort_enabled() &&
+        const bool leaves_cutoffs = speculate && !split && lazy && !bet_light && r1 > r0 && ms_merged_sort_enabled() &&
                                     ms_depth_cut_mode() != 0 && !aux_frame;
         const int cut_in = (prev[7] & 128) ? (int)((prev[7] >> 8) & 1) : 0, cut_out = (prev[7] & 128) ? 1 - cut_in : 0;
         // (bits 16-31: the grid those cut-offs belong to -- the record may have served another grid since; a frame whose
         // predecessor had to regenerate the pairs of more than a handful of bins takes no cut: its cut-offs are fresh)
-        const int64_t cut_grid = (int64_t)((tw & 0xff) | ((th & 0xff) << 8)) << 16;
-        const int64_t prev_cut_redos = (prev[7] & 4) ? 0 : (prev[5] >> 32);
-        const bool cut = leaves_cutoffs && deferred && lean && !(cull & 32) && !no_cut && (prev[7] & 128) &&
-                         (prev[7] & (0xffffll << 16)) == cut_grid && prev_cut_redos <= (tw * th) / 64 + 4 &&
-                         (ms_depth_cut_mode() >= 2 || prev[0] >= ms_depth_cut_min_pairs()) && ms::depth_cut_fits(N, tw, th);
+        // (round 4: ... and bits 32-47 the BAND -- a rank's share of a frame keeps cut-offs for its own rows and 16-px clip: the
+        // sort launch only writes those, and the fronts they come from were judged by the blocks inside the clip.  A band's
+        // frame holds a fraction of the pairs: its threshold is the whole frame's scaled by the rows it renders)
+        const int64_t band_sig = (r0 == 0 && r1 == th && clip0 < 0) ? 0 :
+            (int64_t)(1 + (((unsigned)r0 * 31u + (unsigned)r1 * 131u + (unsigned)(clip0 + 1) * 521u + (unsigned)(clip1 + 1) * 1031u) % 0xfffeu)) << 32;
+        const int64_t cut_grid = ((int64_t)((tw & 0xff) | ((th & 0xff) << 8)) << 16) | band_sig;
+        const int64_t prev_cut_redos = (prev[7] & 4) ? 0 : ((prev[5] >> 32) & 0x3fffffffll);
+        const int64_t min_pairs = ms_depth_cut_min_pairs() * (int64_t)(r1 - r0) / (th > 0 ? th : 1);
+        const bool cut = leaves_cutoffs && deferred && lean && !no_cut && (prev[7] & 128) &&
+                         (prev[7] & (0xffffffffll << 16)) == cut_grid && prev_cut_redos <= (tw * (r1 - r0)) / 64 + 4 &&
+                         (ms_depth_cut_mode() >= 2 || prev[0] >= min_pairs) && ms::depth_cut_fits(N, tw, th);
         static std::atomic<uint32_t> cut_stamps{0};
         uint32_t cut_stamp = 0;
         if (cut)
@@ -341,7 +347,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         const ms::DeferredTotal defer{1, info, (int64_t *)mirror, sync_event, cut_stamp};
         const int defer_bit = (deferred ? ms::kTightDeferTotal : 0) | (cut && cut_in ? ms::kTightDepthCutBuf : 0);
         const ms::CutInputs cut_inputs{means3d, scales, quats, opacities, viewmat, colors, color_dtype == MS_COLOR_F16 ? 1 : 0, fx, fy, cx, cy, W, H,
-                                       eps2d, near_plane, far_plane, scales_are_log, records, tile_size};
+                                       eps2d, near_plane, far_plane, scales_are_log, records, tile_size, r0, r1, N, ws + L.off_isect, (cull & 32) ? 1 : 0};
         const int64_t cut_bits = (cut ? 64 : 0) | (leaves_cutoffs ? (128 | (cut_out << 8) | cut_grid) : 0);
         if (int rc = ms::project_isect_count(N, means3d, scales, scales_are_log, quats, opacities, viewmat, fx, fy,
                                              cx, cy, W, H, eps2d, near_plane, far_plane, 0.0f,

@@ -749,6 +749,63 @@ def test_depth_cut_frames_equal_uncut_frames(device, monkeypatch, N, W, H, ell, 
     _fused._state.clear()
 
 
+@pytest.mark.parametrize("px,world", [(32, 4), (64, 3), (32, 8)])
+def test_depth_cut_on_band_frames(device, px, world):
+    """Round 4: a rank's band of a frame takes the depth cut too -- cut-offs kept per band (rows and 16-px clip in the size
+    record's signature), the count kernel's deferred records and the regeneration launches working on POSITIONS of the
+    band's pre-culled candidate list.  Every band's frames with the cut forced equal its frames without, bit for bit --
+    still camera, orbit, and a swap to a scene whose near half has all but vanished (stale cut-offs: bins get their pairs
+    back from k_far_regen by position) -- and the bands of the first frame assemble the per-stage path's image."""
+    from mojosplat_amd.distributed import band_plan
+    N, W, H, ell = 400_000, 1280, 720, (-3.5 if px != 64 else -3.0)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=device)
+    faint = dict(sc)
+    depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
+    faint["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.02, sc["opacities"])
+    seq = [(sc, cam)] * 4 + [(sc, _orbit(cam, 0.004 * i)) for i in range(1, 5)] + [(faint, cam)] * 3 + [(sc, cam)] * 2
+    th16 = -(-H // 16)
+    _, bands = band_plan(th16, world)
+    ref0 = stagewise(sc, cam, bg, 16)
+    assembled = torch.zeros_like(ref0)
+    totals = {}
+    try:
+        for r0, r1 in bands:
+            y0, y1 = r0 * 16, min(r1 * 16, H)
+
+            def run(mode):
+                _hip_mod.config_depth_cut(int(mode))
+                _fused._state.clear()
+                _fused.FRAME_STATS = st = {}
+                frames, culled = [], 0
+                for s_, c_ in seq:
+                    buf = torch.zeros((H, W, 3), device=device)
+                    info = {}
+                    _fused.render_fwd_hip(s_["means3d"], s_["scales"], s_["quats"], s_["opacities"], s_["features"], c_, bg, px,
+                                          row_range=(r0, r1), out=buf, info=info, rows16=(px != 16))
+                    culled += 1 if info["flags"] & 2048 else 0
+                    frames.append(buf[y0:y1].clone())
+                torch.cuda.synchronize()
+                _fused.FRAME_STATS = None
+                return frames, st, culled
+            ref, st0, _ = run(0)
+            got, st, culled = run(2)
+            assert st0.get("depth_cut", 0) == 0, (r0, r1, st0)   # (a sparse edge band has no heavy bin and takes no cut: the total below)
+            assert culled == len(seq), "the bands of this test are pre-culled"
+            assert st.get("regen_mismatch", 0) == 0, st
+            for k, (a, b) in enumerate(zip(ref, got)):
+                assert torch.equal(a, b), ((r0, r1), k, float((a - b).abs().max()))
+            assembled[y0:y1] = got[0]
+            for k_, v_ in st.items():
+                totals[k_] = totals.get(k_, 0) + v_
+    finally:
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
+    assert torch.equal(assembled, ref0)
+    assert totals.get("depth_cut", 0) >= 4 * (world // 2), totals   # at least the centre bands cut most of their frames
+    assert totals.get("cut_redo_tiles", 0) > 0, totals   # the swap did strand bins whose cut-offs were stale
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed, dense=False):
     """Random scenes, image sizes, plain bin sizes, near / far planes and opacity scales, from a camera that drifts a
