@@ -318,17 +318,19 @@ int ms_spherical_harmonics_bwd(int64_t N, int K, int degree, const float *means3
  * the 48-byte records the count kernel leaves per Gaussian, its scatter kernel a 12-byte (tile box, depth bits, reach
  * mask) record; means2d / conics / depths / radii are only written for frames that are asked for render_alphas or
  * last_ids (what the older backward rasteriser needs) and for other channel counts.
- * DEPTH CUT-OFFS.  A lean sync-free frame over the whole grid of plain bins (tile_size 32 / 64, up to 255 bins a side)
- * whose predecessor ON THE SAME host_info / workspace / grid was such a frame too, and held at least 6 M pairs
- * (MOJOSPLAT_DEPTH_CUT_MIN_PAIRS), takes that predecessor's per-bin depth cut-offs -- the depth at which each bin's
+ * DEPTH CUT-OFFS.  A lean sync-free frame on plain bins (tile_size 32 / 64, up to 255 bins a side) -- the whole grid or,
+ * since round 4, a band of it (a rank's share of a frame: pre-culled or not, MS_RENDER_ROWS16 or not) --
+ * whose predecessor ON THE SAME host_info / workspace / grid / band was such a frame too, and held at least 6 M pairs
+ * (MOJOSPLAT_DEPTH_CUT_MIN_PAIRS; a band: that number scaled by its share of the rows), takes that predecessor's per-bin
+ * depth cut-offs -- the depth at which each bin's
  * lazily sorted front ended, plus 1/16 octave -- and neither counts into the lists, scatters, sorts nor writes records
  * for the (Gaussian, bin) pairs behind them: host_info[0] still counts every pair (the buffer keeps room for them),
  * the lists hold the near ones.  The frame is exact whatever the cut-offs are: a bin whose pixels outlive its list
  * gets its dropped pairs -- and their Gaussians' records -- back in the clean-up launches (which project the
  * Gaussians again), and its cut-off is lifted for the next frame.  host_info[5] of the next record reports such bins in its
- * high 32 bits (the low 32: bins whose sorted FRONT was too short, as before); bits 6-8 and 16-31 of host_info[7]
+ * high 32 bits (the low 32: bins whose sorted FRONT was too short, as before); bits 6-8 and 16-47 of host_info[7]
  * are the library's bookkeeping for it (this frame took the cut; it left cut-offs, in which of two buffers, for which
- * grid).  MOJOSPLAT_DEPTH_CUT=0 in the environment (read per frame) switches it off, =2 takes the cut whatever the
+ * grid and band).  MOJOSPLAT_DEPTH_CUT=0 in the environment (read once; ms_config_depth_cut changes it in-process) switches it off, =2 takes the cut whatever the
  * previous frame held.  A frame that fails its speculation is started over without the cut.
  * SPLIT FRAMES.  A plain forward frame (no render_alphas / last_ids, CDIM <= 4) at tile_size 16 over the
  * whole image or a band of >= 16 tile rows is binned on 32-px bins with block masks (see `tight`), and
