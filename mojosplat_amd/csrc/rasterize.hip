@@ -706,19 +706,9 @@ __global__ __launch_bounds__(kSortThreads) void k_redo_sort(RasterArgs A) {
         }
         __syncthreads();
         if (biggest > (unsigned int)kSortCap) continue;   // (uniform) the selection path takes this bin
-#if defined(MS_REDO_SORT_ABLATE) && MS_REDO_SORT_ABLATE == 1
-        continue;   // (measurement: sample + histogram only)
-#endif
         each_key4([&](int e, uint64_t k) { put((int)atomicAdd(&s_cnt[bucket_of(k)], 1u), e); });
         __threadfence_block();
         __syncthreads();   // (the splitters are done with: s_key now holds one window after the other)
-#if defined(MS_REDO_SORT_ABLATE) && MS_REDO_SORT_ABLATE == 2
-        continue;   // (measurement: no window sorts)
-#endif
-#ifdef MS_REDO_SORT_DEBUG
-        int dbg_windows = 0;
-        long long dbg_t[3] = {0, 0, 0}, dbg_start = wall_clock64();
-#endif
         for (int cb = 0; cb < kSortCap;) {   // (uniform)
             // the largest ce >= cb whose buckets cb .. ce hold at most kSortCap keys together (every bucket alone does)
             const unsigned int w0 = s_bstart[cb];
@@ -729,12 +719,9 @@ __global__ __launch_bounds__(kSortThreads) void k_redo_sort(RasterArgs A) {
             }
             const int cnt = (int)(s_bstart[lo_b + 1] - w0);
             if (cnt > 0) {
-                // every key ranked inside its own bucket (~m / 2 048 keys each): a bitonic network over the window cost 65 us
+                // every key ranked inside its own bucket (~m / 4 096 keys each): a bitonic network over 2 048-key windows cost 65 us
                 // a window, 2.4 of the launch's 3.0 ms at config 4
                 uint64_t kk[kSortPer];
-#ifdef MS_REDO_SORT_DEBUG
-                const long long t0 = wall_clock64();
-#endif
 #pragma unroll
                 for (int e = 0; e < kSortPer; ++e) {
                     const int i = e * kSortThreads + tid;
@@ -742,10 +729,6 @@ __global__ __launch_bounds__(kSortThreads) void k_redo_sort(RasterArgs A) {
                     if (i < cnt) s_key[i] = kk[e];
                 }
                 __syncthreads();
-#ifdef MS_REDO_SORT_DEBUG
-                const long long t1 = wall_clock64();
-                dbg_t[0] += t1 - t0;
-#endif
 #pragma unroll
                 for (int e = 0; e < kSortPer; ++e) {
                     const int i = e * kSortThreads + tid;
@@ -766,23 +749,10 @@ __global__ __launch_bounds__(kSortThreads) void k_redo_sort(RasterArgs A) {
                         put((int)w0 + beg + r, (int32_t)(uint32_t)kk[e]);   // (every get() of this window came before the barrier)
                     }
                 }
-#ifdef MS_REDO_SORT_DEBUG
-                const long long t2 = wall_clock64();
-                dbg_t[1] += t2 - t1;
-#endif
                 __syncthreads();
-#ifdef MS_REDO_SORT_DEBUG
-                dbg_t[2] += wall_clock64() - t2;
-#endif
             }
             cb = lo_b + 1;
-#ifdef MS_REDO_SORT_DEBUG
-            ++dbg_windows;
-#endif
         }
-#ifdef MS_REDO_SORT_DEBUG
-        if (tid == 0 && n > 100000) printf("redo_sort bin %d: n %d far %d biggest %u windows %d; 100 MHz ticks: gather %lld rank+put %lld sync %lld all windows %lld\n", tile, n, n_far, biggest, dbg_windows, dbg_t[0], dbg_t[1], dbg_t[2], wall_clock64() - dbg_start);
-#endif
         if (tid == 0) A.lazy.redo_flag[tile] = 2;
     }
 }
