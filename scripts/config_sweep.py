@@ -97,7 +97,10 @@ def main():
             from mojosplat_amd import render as R
             out["bin_px"] = R._bin_mode.get(R._bin_key(g[0], cam), 16)    # the binning rule's choice (render.py)
             out["fps"] = round(1e3 / out["ms_fwd"], 1)
-            out["GBps_alg"] = round((96 * N + (78 if fp16 else 84) * out["M"] + 12 * th * tw + 12 * H * W)
+            # (SURVEY 8(d)'s byte model of a FULL frame -- every pair written, sorted and offered -- over the frame's time: a
+            # lazily sorted, depth-cut frame never touches most of those bytes, so this can exceed the 8 000 GB/s peak; it is
+            # not a bandwidth.  Measured traffic per frame: profiles/r04_pmc_fetch_write*.txt)
+            out["GBps_of_survey_model"] = round((96 * N + (78 if fp16 else 84) * out["M"] + 12 * th * tw + 12 * H * W)
                                     / (out["ms_fwd"] * 1e-3) / 1e9, 1)
         print(json.dumps(out), flush=True)
         del sc, g
