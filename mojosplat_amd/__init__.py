@@ -12,5 +12,11 @@ from .rasterization import rasterize_gaussians
 from .render import render_gaussians, render_gaussians_batch, TILE_SIZE
 from .sh import evaluate_sh
 
+
+def release_scratch():
+    """Give the calling thread's cached render scratch (and the shared lanes') back to the allocator: _fused.release_scratch."""
+    from ._fused import release_scratch as _release
+    _release()
+
 __all__ = ["Camera", "look_at", "project_gaussians", "bin_gaussians_to_tiles",
-           "rasterize_gaussians", "render_gaussians", "render_gaussians_batch", "evaluate_sh", "TILE_SIZE"]
+           "rasterize_gaussians", "render_gaussians", "render_gaussians_batch", "evaluate_sh", "release_scratch", "TILE_SIZE"]

@@ -68,6 +68,17 @@ _state = _LaneStates()
 _frame_lock = threading.RLock()
 
 
+def release_scratch():
+    """Drop the cached scratch of the CALLING thread's blocking path (workspace + intersection buffer: ~0.1 GB at config
+    3, ~1 GB at config 4) and of the shared lanes, back to torch's caching allocator.  For thread pools: a worker's scratch
+    otherwise lives until the thread exits.  The next frame allocates afresh and starts without the previous frames' hints."""
+    with _frame_lock:
+        for key, st in list(_state._shared.items()):
+            if st.get("busy"):
+                raise RuntimeError("release_scratch: a begun frame is still pending on a shared lane")
+        _state.clear()
+
+
 def _dev_state(dev, lane=0):
     st = _state.get((dev, lane))
     if st is None:

@@ -438,6 +438,15 @@ def test_frames_asked_for_one_call_ahead_equal_blocking_frames(device):
         assert float(total) == float(refs[k].sum())
     with pytest.raises(ValueError):
         ms.render_gaussians(*g(scenes[0][0]), scenes[0][1], backend="torch", async_op=True)
+    # release_scratch: refused while a frame is pending on a shared lane, then the scratch goes and frames still render
+    s_, c_, b_ = scenes[0]
+    pend = ms.render_gaussians(*g(s_), c_, background_color=b_, backend="hip", async_op=True)
+    with pytest.raises(RuntimeError):
+        ms.release_scratch()
+    assert torch.equal(pend.wait(), refs[0])
+    ms.release_scratch()
+    assert _fused._state.get((sc16["means3d"].device, 0)) is None
+    assert torch.equal(ms.render_gaussians(*g(s_), c_, background_color=b_, backend="hip"), refs[0])
     _fused._state.clear()
 
 
@@ -839,6 +848,58 @@ def test_depth_cut_fuzz_against_stagewise(device, monkeypatch, seed, dense=False
             got = ms.render_gaussians(*args, cm, background_color=bg, bin_size=px)
             want = stagewise(sc, cm, bg, 16)
             assert torch.equal(got, want), (seed, k, N, W, H, px, dict(_fused.FRAME_STATS), float((got - want).abs().max()))
+    finally:
+        LAST_CUT_FUZZ_STATS.clear()
+        LAST_CUT_FUZZ_STATS.update(_fused.FRAME_STATS or {})
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_band_depth_cut_fuzz_against_stagewise(device, seed, dense=False):
+    """The depth-cut fuzz on a rank's BAND of the frame: a random run of 16-px rows (pre-culled when it is under 60 % of
+    the image and the scene is large enough), bins of 32 or 64 px under it, a camera that drifts every frame and a swap to
+    the same Gaussians with the near half nearly transparent half-way -- stale cut-offs, bins regenerated by POSITION in
+    the band's candidate list.  The band's rows of every frame equal the per-stage path's, bit for bit, and nothing is
+    written outside them."""
+    import math
+    from mojosplat_amd.utils import Camera
+    _hip_mod.config_depth_cut(2)
+    g = torch.Generator().manual_seed(47000 + seed)
+    r = lambda lo, hi: lo + (hi - lo) * torch.rand(1, generator=g).item()
+    if dense:
+        N, W, H, ell = int(10 ** r(5.3, 5.9)), int(r(1000, 1920)), int(r(600, 1080)), r(-3.8, -3.0)
+    else:
+        N, W, H, ell = int(10 ** r(4.4, 5.5)), int(r(400, 1400)), int(r(300, 900)), r(-4.0, -2.8)
+    px = [32, 64][seed % 2]
+    sc, cam = randscene_v1(N, W, H, ell=ell, seed=1900 + seed, device=device)
+    sc["opacities"] = (sc["opacities"] * r(0.7 if dense else 0.4, 1.0)).clamp(max=1.0)
+    faint = dict(sc)
+    depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
+    faint["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.03, sc["opacities"])
+    bg = torch.tensor([r(0, 1), r(0, 1), r(0, 1)], device=device)
+    th = -(-H // 16)
+    r0 = int(r(0, th - 1))
+    r1 = min(th, r0 + 1 + int(r(0, max(1.0, 0.7 * th))))
+    y0, y1 = r0 * 16, min(r1 * 16, H)
+    _fused._state.clear()
+    _fused.FRAME_STATS = {}
+    try:
+        for k in range(9):
+            a = 0.008 * k * (1 if seed % 3 else -1)
+            c, s = math.cos(a), math.sin(a)
+            ry = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], device=device)
+            cm = Camera(R=cam.R @ ry, T=cam.T + torch.tensor([0.0, 0.0, 0.015 * k], device=device), H=H, W=W, fx=cam.fx, fy=cam.fy,
+                        cx=cam.cx, cy=cam.cy, near=cam.near, far=cam.far)
+            s_ = faint if 4 <= k < 7 else sc
+            frame = torch.full((H, W, 3), -1.0, device=device)
+            _fused.render_fwd_hip(s_["means3d"], s_["scales"], s_["quats"], s_["opacities"], s_["features"], cm, bg, px,
+                                  row_range=(r0, r1), out=frame, rows16=True)
+            want = stagewise(s_, cm, bg, 16)
+            what = (seed, k, N, W, H, px, (r0, r1), dict(_fused.FRAME_STATS))
+            assert torch.equal(frame[y0:y1], want[y0:y1]), what + (float((frame[y0:y1] - want[y0:y1]).abs().max()),)
+            assert bool((frame[:y0] == -1.0).all()) and bool((frame[y1:] == -1.0).all()), what
+            assert _fused.FRAME_STATS.get("regen_mismatch", 0) == 0, what
     finally:
         LAST_CUT_FUZZ_STATS.clear()
         LAST_CUT_FUZZ_STATS.update(_fused.FRAME_STATS or {})
