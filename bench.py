@@ -552,7 +552,7 @@ def main():
                                              "algo": {"framebuffer": "grouped isend / irecv into the image's rows (MOJOSPLAT_GATHER=direct)"
                                                       if os.environ.get("MOJOSPLAT_GATHER") == "direct"
                                                       else "in-place all_gather_into_tensor (padded slots + one compaction copy once bands are ragged)",
-                                                      "status": "all_gather of 16 bytes per rank per frame (on-grid count, balance weight)",
+                                                      "status": "all_gather of 32 bytes per rank per frame (on-grid count, Gaussians reaching a pre-culled band or -1, pairs, frame stamp)",
                                                       "band_balance": os.environ.get("MOJOSPLAT_BALANCE", "1") != "0",
                                                       "bands_at_end": band_bounds_end}},
             "roofline": roofline, "cpu_baseline": cpu,
