@@ -493,6 +493,20 @@ _lanes = {}
 LANE_CALIBRATION = {}   # device -> what _lane_streams measured when it chose the two lane streams (diagnostics)
 
 
+def _pick_lane_pair(pair_ratio, with_current):
+    """The lane pair from a calibration: pair_ratio[(a, b)] = time of one spin kernel on each of streams a and b over one
+    kernel's time (~1.1-1.3: independent, ~1.9: one hardware queue), with_current[a] likewise against the caller's stream.
+    The pair's own independence first; a stream on the caller's QUEUE (> 1.6) is out -- the waits put on the caller's
+    stream would stall it: measured slower than no overlap at all; ties (within 0.01) go to the pair met first."""
+    best = None
+    for (a, b), r in sorted(pair_ratio.items()):
+        shared = max(with_current[a], with_current[b])
+        score = r + (10.0 if shared > 1.6 else 0.1 * shared)
+        if best is None or score < best[0] - 0.01:
+            best = (score, (a, b))
+    return best[1]
+
+
 def _lane_streams(dev):
     """The two streams that frames in flight at the same time alternate between (multi-view batches, the asynchronous
     single-GPU and sharded entry points).
@@ -534,18 +548,12 @@ def _lane_streams(dev):
                         spin(s_)          # (first use, in this order)
                     solo = min(spin(cand[0]) for _ in range(3))
                     with_cur = [min(spin(cur, s_) for _ in range(2)) / solo for s_ in cand]
-                    best = None
                     pairs = {}
                     for a in range(len(cand)):
                         for b in range(a + 1, len(cand)):
-                            r = min(spin(cand[a], cand[b]) for _ in range(2)) / solo
-                            pairs[f"{a},{b}"] = round(r, 2)
-                            # (the pair's own independence first; a lane on the caller's QUEUE -- ~2x -- is out: the waits
-                            # put on the caller's stream would stall it)
-                            score = r + (10.0 if max(with_cur[a], with_cur[b]) > 1.6 else 0.1 * max(with_cur[a], with_cur[b]))
-                            if best is None or score < best[0] - 0.01:
-                                best = (score, (a, b))
-                pick = best[1]
+                            pairs[(a, b)] = min(spin(cand[a], cand[b]) for _ in range(2)) / solo
+                pick = _pick_lane_pair(pairs, with_cur)
+                pairs = {f"{a},{b}": round(r, 2) for (a, b), r in pairs.items()}
                 rec = {"calibrated": True, "solo_us": round(solo * 1e6, 1), "with_current_stream": [round(x, 2) for x in with_cur],
                        "pairs": pairs, "picked": list(pick), "ratio_of_the_pick": pairs[f"{pick[0]},{pick[1]}"]}
             except Exception as e:  # noqa: BLE001  (a calibration that cannot run must not take the renderer down)

@@ -271,3 +271,22 @@ def test_render_fwd_batch_argument_checks_without_a_gpu():
     ok = ctypes.c_int(0)
     one = (_hip.ViewLane * 1)()
     assert L.ms_render_fwd_batch(*args(0, 1, one, ok)) == 1 and "lacks scratch" in err()      # lanes without buffers
+
+
+def test_lane_pair_choice_from_a_calibration():
+    """_fused._pick_lane_pair on records of the kind profiles/r04_two_frames_in_flight.jsonl holds: never a pair on one
+    hardware queue (ratio ~1.9) while an independent one is free, never a stream on the caller's queue, the most independent
+    pair otherwise, and a choice even when every pair is bad."""
+    from mojosplat_amd._fused import _pick_lane_pair
+    with_cur = [1.26, 1.25, 1.26, 1.26, 1.94, 1.25]
+    pairs = {(0, 1): 1.94, (0, 2): 1.26, (0, 3): 1.12, (0, 4): 1.25, (0, 5): 1.92, (1, 2): 1.26, (1, 3): 1.10, (1, 4): 1.25,
+             (1, 5): 1.92, (2, 3): 1.12, (2, 4): 1.12, (2, 5): 1.23, (3, 4): 1.24, (3, 5): 1.23, (4, 5): 1.23}
+    assert _pick_lane_pair(pairs, with_cur) == (1, 3)
+    # the only independent pairs sit on the caller's queue: a serialised pair runs at the blocking rate, a lane behind the
+    # caller's waits was measured well below it -- so not stream 4
+    only4 = {k: (1.10 if 4 in k else 1.9) for k in pairs}
+    assert 4 not in _pick_lane_pair(only4, with_cur)
+    shared = {k: 1.9 for k in pairs}
+    shared[(2, 5)] = 1.3
+    assert _pick_lane_pair(shared, [1.2] * 6) == (2, 5)
+    assert _pick_lane_pair({(0, 1): 1.95}, [1.9, 1.9]) == (0, 1)
