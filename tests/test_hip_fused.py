@@ -450,6 +450,22 @@ def test_frames_asked_for_one_call_ahead_equal_blocking_frames(device):
     _fused._state.clear()
 
 
+def test_lane_streams_are_a_calibrated_independent_pair(device):
+    """The two streams frames in flight alternate between are chosen once per device by a spin-kernel calibration
+    (_fused._lane_streams): distinct streams, neither the caller's, and -- when the calibration ran -- a pair it measured
+    as independent (ratio well under the ~1.9 of two streams on one hardware queue)."""
+    ls = _fused._lane_streams(device)
+    assert len(ls) == 2 and ls[0].cuda_stream != ls[1].cuda_stream
+    assert torch.cuda.current_stream(device).cuda_stream not in (ls[0].cuda_stream, ls[1].cuda_stream)
+    assert _fused._lane_streams(device) is ls
+    rec = _fused.LANE_CALIBRATION.get(device) or _fused.LANE_CALIBRATION.get(torch.device("cuda", torch.cuda.current_device()))
+    assert rec is not None
+    if rec.get("calibrated"):
+        a, b = rec["picked"]
+        assert rec["pairs"][f"{a},{b}"] == rec["ratio_of_the_pick"] < 1.6, rec
+        assert max(rec["with_current_stream"][a], rec["with_current_stream"][b]) < 1.6, rec
+
+
 def test_binning_rule_on_a_scene_whose_lane_falls_back_to_full_sorts(device):
     """A pile of faint Gaussians: the lazily sorted split frame fails its fronts and the lane falls back to
     full sorts, while render_gaussians' binning rule (big footprints -> plain coarse bins) moves the grid
