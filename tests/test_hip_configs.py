@@ -145,6 +145,30 @@ def test_config5_as_eight_bands_equals_the_single_gpu_frame(device):
         assert torch.equal(out, full), world
 
 
+def test_config5_centre_band_takes_the_depth_cut_and_stays_exact(device):
+    """Round 4: a rank's band of the 8-GPU config keeps depth cut-offs of its own (threshold scaled by the band's share of
+    the rows).  The centre band of eight, eight frames through the sharded entry point with the default switches: the later
+    frames take the cut, and every frame's rows equal the single-GPU frame's."""
+    sc, cam, g = _scene("cfg5", device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    H = cam.H
+    full = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    _, bands = band_plan(-(-H // 16), 8)
+    r0, r1 = bands[3]
+    y0, y1 = r0 * 16, min(r1 * 16, H)
+    _fused._state.clear()
+    _fused.FRAME_STATS = stats = {}
+    try:
+        for k in range(8):
+            img = render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(3, 8))
+            assert torch.equal(img[y0:y1], full[y0:y1]), k
+    finally:
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
+    assert stats.get("depth_cut", 0) >= 2, stats
+    assert stats.get("cut_redo_tiles", 0) == 0 and stats.get("regen_mismatch", 0) == 0, stats
+
+
 def test_config3_backward_full_size(device):
     """Config 3 forward + backward at full size: gradients for means / scales / quats / opacities / colours
     finite, non-zero, repeatable within the order of the float atomics, and equal to the per-stage
