@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 2   /* 2: ms_render_bwd takes the frame's image (render_colors) */
+#define MS_ABI_VERSION 3   /* 2: ms_render_bwd takes the frame's image (render_colors); 3: ms_render_redo_counts, the band-frame pair, ms_scene_prepare */
 
 typedef enum ms_status {
     MS_OK = 0,
@@ -245,6 +245,15 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  * a negative argument leaves that setting alone.  Process-wide; the defaults come from MOJOSPLAT_DEPTH_CUT /
  * MOJOSPLAT_DEPTH_CUT_MIN_PAIRS, read once.  (For tests and measurements that switch inside one process.) */
 int ms_config_depth_cut(int mode, long long min_pairs);
+
+/* Bins the clean-up pass of a finished ms_render_fwd frame had to redo (lazily sorted fronts that ran out with pixels
+ * alive): host_counts i32[2] = {all redone bins, those redone for their depth cut-off}, copied asynchronously on `stream`
+ * from the frame's `workspace` (host_counts: pinned HOST memory; valid once an event recorded behind the call has
+ * completed).  Frames on cached scratch learn the same number from the NEXT frame's host_info[5]; a differentiable frame
+ * owns fresh scratch, so its caller asks here (behind ms_render_bwd) and chooses MS_RENDER_FRONT_LEVEL / MS_RENDER_FULL_SORT
+ * for the next step from it.  No reference counterpart (the reference has no backward: render.py:11). */
+int ms_render_redo_counts(const void *workspace, size_t workspace_bytes, int64_t N, int tile_w, int tile_h,
+                          int32_t *host_counts, void *stream);
 
 size_t ms_render_bwd_workspace_bytes(int64_t N, int CDIM);
 int ms_render_bwd(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,

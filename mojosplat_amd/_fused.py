@@ -73,9 +73,18 @@ def release_scratch():
     3, ~1 GB at config 4) and of the shared lanes, back to torch's caching allocator.  For thread pools: a worker's scratch
     otherwise lives until the thread exits.  The next frame allocates afresh and starts without the previous frames' hints."""
     with _frame_lock:
+        devs = set()
         for key, st in list(_state._shared.items()):
             if st.get("busy"):
                 raise RuntimeError("release_scratch: a begun frame is still pending on a shared lane")
+            devs.add(key[0])
+        d = getattr(_state._tls, "d", None)
+        if d:
+            devs.update(k[0] for k in d)
+        # (round 5, advisor: the buffers are used on lane streams the caching allocator does not know about -- a block handed
+        # back without a sync could be re-issued while a lane's kernels still touch it; _grow() waits for the same reason)
+        for dev in devs:
+            torch.cuda.synchronize(dev)
         _state.clear()
 
 
@@ -160,9 +169,65 @@ def _count_frame(stats, frame, host, grew):
 
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
 RETRY_FULL_SORT = 64   # frames a lane stays on full sorts before it tries lazily sorted fronts again (doubling each time)
+SWAP_FULL_SORT = 4     # ... after a scene swap (nearly every heavy bin regenerated at once): fixed, short
 FULL_SORT = 0x100
 FRONT_LEVEL = 0x200  # x level (0..3): deeper lazily sorted fronts
 ROWS16 = 0x800       # row_range counts rows of 16 px whatever the tile size (a band keeps its rows, the bins follow the scene)
+
+
+# ---- what a DIFFERENTIABLE frame learns about its lazily sorted fronts (round 5, advisor) ----------------------------
+# A frame on cached scratch is told by the NEXT frame's size record how many bins its clean-up pass had to redo, and the
+# lane moves to deeper fronts or to full sorts (_Frame.finish).  A differentiable frame owns FRESH scratch, so that
+# channel is garbage for it, and round 4 left such frames on the default fronts for ever: a scene whose fronts cannot
+# saturate (low opacities after an opacity reset, fog) paid the clean-up pass and the backward's redo launch on every
+# training step.  Now the backward asks the library for the count (ms_render_redo_counts: an 8-byte asynchronous copy into
+# pinned memory behind ms_render_bwd), and the next differentiable frame of the same shape on this thread -- the first one
+# that finds the copy complete: the host usually runs a step ahead of the GPU -- applies the lane's rule to it.
+def own_mode(st, shape):
+    """-> (full_sort, front_level) for the next lean differentiable frame of `shape` on this thread's lane."""
+    pend = st.get("own_pending")
+    if pend is not None and pend["ev"].query():
+        st["own_pending"] = None
+        redo = int(pend["buf"][0]) - int(pend["buf"][1])
+        m = st.setdefault("own_learnt", {}).setdefault(pend["shape"], dict(full=False, level=0, frames=0, retry_after=RETRY_FULL_SORT))
+        if FRAME_STATS is not None:
+            FRAME_STATS["own_redo_tiles"] = FRAME_STATS.get("own_redo_tiles", 0) + max(redo, 0)
+        if pend["lazy"] and not m["full"] and pend["level"] == m["level"]:
+            if redo > 0:
+                if redo > max(3, pend["heavy"] // 4) or m["level"] >= 2:
+                    m["full"], m["frames"] = True, 0
+                    if FRAME_STATS is not None:
+                        FRAME_STATS["own_full_sort_on"] = FRAME_STATS.get("own_full_sort_on", 0) + 1
+                else:
+                    m["level"] += 1
+                    if FRAME_STATS is not None:
+                        FRAME_STATS["own_front_level_up"] = FRAME_STATS.get("own_front_level_up", 0) + 1
+            else:
+                m["retry_after"] = RETRY_FULL_SORT   # lazily sorted fronts hold: the next fall-back starts with short patience
+    m = st.get("own_learnt", {}).get(shape)
+    if m is None:
+        return False, 0
+    if m["full"]:
+        m["frames"] += 1
+        if m["frames"] > m["retry_after"]:   # a view through fog ends: try lazily sorted fronts again, with doubled patience
+            m["full"], m["frames"] = False, 0
+            m["retry_after"] = min(2 * m["retry_after"], 4096)
+    return bool(m["full"]), int(m["level"])
+
+
+def own_report(st, dev, shape, mode, level, heavy, ws, grid):
+    """Behind a differentiable frame's backward: ask for the frame's redo counts (asynchronously, on the current stream)."""
+    buf = st.get("own_redo_buf")
+    if buf is None:
+        buf = st["own_redo_buf"] = torch.zeros(2, dtype=torch.int32).pin_memory()
+        st["own_redo_np"] = buf.numpy()
+        st["own_redo_ev"] = torch.cuda.Event()
+    N, tw, th = grid
+    _hip.check(_hip.lib().ms_render_redo_counts(_hip.ptr(ws), ws.numel(), N, tw, th, ctypes.c_void_p(buf.data_ptr()),
+                                                _hip.stream(dev)), "ms_render_redo_counts")
+    st["own_redo_ev"].record()
+    st["own_pending"] = dict(ev=st["own_redo_ev"], buf=st["own_redo_np"], shape=shape, lazy=not (mode & FULL_SORT), level=level,
+                             heavy=heavy)
 
 
 class _Frame:
@@ -218,6 +283,10 @@ class _Frame:
         # current depth level, or full sorts once the lane has given up on them
         self.level = int(st.get("front_level", 0))
         self.mode = (FULL_SORT if st.get("full_sort") else FRONT_LEVEL * self.level) | self.rows16
+        if own and not own_last:
+            # (round 5: a lean differentiable frame learns for itself -- own_mode / own_report below)
+            full, self.level = own_mode(st, self.shape)
+            self.mode = (FULL_SORT if full else FRONT_LEVEL * self.level) | self.rows16
         self.img_ptr = None
         if out is not None and out_y0 is not None:
             # `out` is a SLAB holding image rows [out_y0, out_y0 + out.shape[0]) (a rank's slot of a padded gather
@@ -305,12 +374,16 @@ class _Frame:
             # well, 70 ms at config 4 -- so the lane goes to full sorts one frame earlier)
             elif (rc == 0 and not (int(host[7]) & 4) and not st.get("full_sort") and ((int(host[5]) >> 32) & 0x3fffffff) > max(8, heavy // 2)):
                 st["full_sort"] = True
+                # (round 5, advisor: a swap is over after a frame -- the cut-offs and fronts the next lazily sorted frame
+                # leaves are fresh -- so this fall-back has a short FIXED patience and does not lengthen the next one's)
+                st["full_sort_frames"], st["full_sort_limit"] = 0, SWAP_FULL_SORT
                 if FRAME_STATS is not None:
                     FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
             elif (rc == 0 and not (int(host[7]) & 4) and (int(host[5]) & 0xffffffff) > 0 and not st.get("full_sort")
                   and st.get("prev_level") == st.get("front_level", 0)):
                 if (int(host[5]) & 0xffffffff) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
                     st["full_sort"] = True
+                    st["full_sort_frames"], st["full_sort_limit"] = 0, None   # (patience: retry_after, doubling)
                     if FRAME_STATS is not None:
                         FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
                 else:
@@ -323,11 +396,21 @@ class _Frame:
             # retry costs one or two frames of the clean-up pass: 5-6 ms on the heaviest scenes since round 4's two-launch clean-up.)
             if st.get("full_sort") and same_shape:
                 st["full_sort_frames"] = st.get("full_sort_frames", 0) + 1
-                if st["full_sort_frames"] >= st.get("retry_after", RETRY_FULL_SORT):
+                fixed = st.get("full_sort_limit")
+                if st["full_sort_frames"] >= (fixed if fixed else st.get("retry_after", RETRY_FULL_SORT)):
                     st["full_sort"], st["full_sort_frames"] = False, 0
-                    st["retry_after"] = min(2 * st.get("retry_after", RETRY_FULL_SORT), 4096)
+                    if not fixed:
+                        st["retry_after"] = min(2 * st.get("retry_after", RETRY_FULL_SORT), 4096)
+                    st["retried"] = 2   # (the next two lazily sorted frames are on probation: the count comes a frame late)
                     if FRAME_STATS is not None:
                         FRAME_STATS["lazy_sort_retry"] = FRAME_STATS.get("lazy_sort_retry", 0) + 1
+            elif same_shape and st.get("retried") and rc == 0 and not (int(host[7]) & 4):
+                # (round 5, advisor: a retried lazily sorted frame that reports no redone bin ends the doubling -- before, every
+                # benign scene swap or camera cut lengthened the NEXT fall-back, up to 4096 frames on the slow path)
+                if (int(host[5]) & 0xffffffff) == 0 and st.get("prev_level") is not None:
+                    st["retried"] -= 1
+                    if st["retried"] == 0:
+                        st["retry_after"] = RETRY_FULL_SORT
             st["shape"], st["prev_level"] = self.shape, (self.level if not self.mode & FULL_SORT else None)
             memo[self.shape] = (bool(st.get("full_sort")), int(st.get("front_level", 0)))
             if len(memo) > 64:

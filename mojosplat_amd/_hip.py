@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get("MOJOSPLAT_HIP_LIB") or \
     os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmojosplat_hip.so")
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); mirrors include/mojosplat_hip.h one to one
 _SIGNATURES = {
@@ -58,6 +58,7 @@ _SIGNATURES = {
     "ms_render_workspace_layout": (c_int, [c_int64, c_int, c_int, c_void_p]),
     "ms_render_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ms_config_depth_cut": (c_int, [c_int, ctypes.c_longlong]),
+    "ms_render_redo_counts": (c_int, [c_void_p, c_size_t, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "ms_render_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
                               c_float, c_float, c_float, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t,
                               c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -115,7 +115,10 @@ class _RenderFusedHip(torch.autograd.Function):
         # three float32 channels: the frame keeps its alphas only and runs the inference frame's binning (lazily sorted
         # fronts on the grid the binning rule picks: the image and the gradients do not depend on it); its backward is
         # the quad-wave rasteriser.  Anything else keeps last_ids and fully sorted lists for the older kernel.
-        lean = colors.shape[1] == 3 and colors.dtype == torch.float32 and os.environ.get("MOJOSPLAT_BWD_QUADS", "1") != "0"
+        # (round 5, advisor: the quad-wave kernel works in 16x16 blocks -- ms_render_bwd only takes it when the tile size is a
+        # multiple of 16; a frame at tile_size 8 / 24 / ... keeps last_ids and fully sorted lists for the older kernel)
+        lean = colors.shape[1] == 3 and colors.dtype == torch.float32 and tile_size % 16 == 0 and \
+            os.environ.get("MOJOSPLAT_BWD_QUADS", "1") != "0"
         key = None
         if lean and tile_size == _render.TILE_SIZE and "MOJOSPLAT_TRAIN_BIN_PX" not in os.environ:
             explicit = _render._env_bin_px()
@@ -141,6 +144,9 @@ class _RenderFusedHip(torch.autograd.Function):
         # ms_render_bwd reads them where the forward call left them
         import numpy as np
         ctx.scratch = (frame.ws, frame.isect, np.array(frame.st["host_np"], dtype=np.int64, copy=True))
+        # (round 5: a lazily sorted differentiable frame reports its clean-up count behind its backward: _fused.own_report)
+        h = ctx.scratch[2]
+        ctx.own_learn = (frame.st, frame.shape, frame.mode, frame.level, int(h[2]) + int(h[3]) + int(h[4]), frame.grid) if lean else None
         # (the image itself is saved too: the quad-wave backward rasteriser takes what lies behind an entry from it)
         ctx.save_for_backward(m3, sc, qu, op, col, bg, frame.alphas, frame.last, img)
         return img
@@ -179,6 +185,10 @@ class _RenderFusedHip(torch.autograd.Function):
                 "ms_render_bwd")
             if bev:
                 bev[2].record()
+            if ctx.own_learn is not None and (int(host[7]) & 512):   # the frame ran on lazily sorted fronts
+                from . import _fused
+                st, shape, mode, level, heavy, grid = ctx.own_learn
+                _fused.own_report(st, dev, shape, mode, level, heavy, ws, grid)
         v_bg = None
         if bg is not None and ctx.needs_input_grad[5]:
             v_bg = ((1.0 - alphas)[..., None] * v_img).sum(dim=(0, 1))

@@ -182,12 +182,14 @@ int rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const float *
                         const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
                         float *packed_rows, const int32_t *order, void *stream);
 
-// ... and its launch for the tiles the forward's clean-up pass redid (their sorted front ran out with pixels alive): one
-// workgroup per tile on the redo list sorts the tile's keys in place and walks the whole list.  Empty on almost every frame.
+// ... and its launch for the tiles the forward's clean-up pass redid (their sorted front ran out with pixels alive): a wave
+// per (tile, block, quad) walks the whole-tile sorted ids the forward's k_redo_sort left (redo_flag[tile] == 2); a tile that
+// was not sorted that way gets its keys sorted in place by one workgroup first.  Empty on almost every frame.
 int rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const float *backgrounds, int W, int H, int tile_size,
-                       const int32_t *tile_ranges, uint64_t *keys, const int32_t *redo_list, const int32_t *redo_count,
-                       const float *render_colors, const float *render_alphas, const float *v_render_colors,
-                       const float *v_render_alphas, float *packed_rows, void *stream);
+                       const int32_t *tile_ranges, uint64_t *keys, const int32_t *ids, const int32_t *redo_list,
+                       const int32_t *redo_count, const int32_t *redo_flag, const float *render_colors,
+                       const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
+                       float *packed_rows, void *stream);
 
 // Block lists of a split frame (ms_render_fwd): what the sort kernels of 32-px bins write instead of
 // flatten_ids.  Bin `b` with list [start, start + n) owns block_ids[4 start, 4 (start + n)): its block q

@@ -179,6 +179,22 @@ extern "C" int ms_render_workspace_layout(int64_t N, int tile_w, int tile_h, siz
     return MS_OK;
 }
 
+// How many bins the clean-up pass of the frame that `workspace` belongs to had to redo: host_counts[0] = all of them,
+// [1] = those redone for their depth cut-off.  An asynchronous 8-byte copy on `stream` (host_counts: pinned memory; read
+// it once an event recorded behind this call has completed).  A frame on cached scratch learns this from the NEXT frame's
+// size record (host_info[5]); a differentiable frame owns fresh scratch, so its caller asks here, behind the backward.
+extern "C" int ms_render_redo_counts(const void *workspace, size_t workspace_bytes, int64_t N, int tile_w, int tile_h,
+                                     int32_t *host_counts, void *stream) {
+    MS_REQUIRE(workspace && host_counts && tile_w > 0 && tile_h > 0 && (int64_t)tile_w * tile_h < (1ll << 30) && N >= 0,
+               MS_ERR_INVALID_ARG, "render_redo_counts: bad argument");
+    const WsLayout L = ws_layout(N, tile_w, tile_h);
+    MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_redo_counts: workspace %zu < %zu", workspace_bytes, L.total);
+    ms::LazyLists ll;
+    ms::isect_lazy_arrays(const_cast<char *>((const char *)workspace) + L.off_isect, N, tile_w, tile_h, &ll);
+    MS_HIP(hipMemcpyAsync(host_counts, ll.redo_count, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MS_OK;
+}
+
 extern "C" size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch) {
     const size_t m = (size_t)(M > 0 ? M : 1);
     return ms::align_up(m * 8, 256) * (with_merge_scratch ? 2 : 1) + ms::align_up(m * 4, 256);
@@ -416,7 +432,10 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                 const int64_t prev_redos = (prev[7] & 4) ? 0 : (prev[5] & 0xffffffffll) + ((prev[5] >> 32) & 0x3fffffffll);
                 // (bins of 48 px and more -- nine or sixteen blocks to a bin, lists of tens of thousands -- always: such a frame's
                 // FIRST encounter with stranded bins is the 75 ms one)
-                lazy_lists.redo_sort = (cut_stamp != 0u || prev_redos > 0 || tile_size >= 48) && !aux_frame && ms_redo_sort_enabled() ? 1 : 0;
+                // (round 5: a differentiable frame ALWAYS -- it owns fresh scratch, so the record it is handed says nothing about
+                // its predecessor, and its backward walks the whole-bin sorted ids k_redo_sort leaves instead of sorting the
+                // bin's keys again in global memory: rasterize_bwdq.hip, k_rasterize_bwd_redo)
+                lazy_lists.redo_sort = (cut_stamp != 0u || prev_redos > 0 || tile_size >= 48 || aux_frame) && ms_redo_sort_enabled() ? 1 : 0;
             }
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
@@ -521,6 +540,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         return rc;
     if (!speculated) mark(2);
     lazy_lists.keys = keys;
+    if (lazy && aux_frame && ms_redo_sort_enabled()) lazy_lists.redo_sort = 1;   // (as on the sync-free path: for the backward's redo launch)
     if (int rc = ms::rasterize_fwd(N, M, M, means2d, conics, colors, color_dtype, CDIM, opacities, backgrounds, W, H,
                                    tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
                                    lazy && host_info[2] + host_info[3] + host_info[4] > 0 ? &lazy_lists : nullptr,
@@ -631,7 +651,7 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
             return rc;
         if (fronts)
             if (int rc = ms::rasterize_bwd_redo(N, M, records, backgrounds, W, H, tile_size, ranges,
-                                                (uint64_t *)const_cast<void *>(isect_buf), ll.redo_list, ll.redo_count,
+                                                (uint64_t *)const_cast<void *>(isect_buf), ids, ll.redo_list, ll.redo_count, ll.redo_flag,
                                                 render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw, stream_))
                 return rc;
         if (mid_event) MS_HIP(hipEventRecord((hipEvent_t)mid_event, stream));

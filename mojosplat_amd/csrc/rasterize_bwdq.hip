@@ -156,32 +156,38 @@ __device__ __forceinline__ void bwd_quad(const BwdQArgs &A, const int tile, cons
     //   j 0-5 : MONO_j(p) for both terms (exact in bf16: half-integers up to 3.5 and their products)
     //   j 6-8 : hi(dL/dC / 255) for both terms            -> sum (w_hi + w_lo) v_hi
     //   j 9-11: lo(dL/dC / 255) for the hi term, 0 for lo -> sum w_hi v_lo      (colour gradient = column 6+c plus 9+c)
+    // Round 5: built through a table in LDS -- every lane writes the thirteen packed words of ITS pixel (row j of Y, column
+    // p = lane; row 12 = the zeros of columns 12-15) and then reads the four pixels of each of its (instruction, k-group)
+    // cells as ONE ds_read_b128 of row j: ~50 instructions and one LDS round trip per wave.  Round 4 built the sixteen
+    // words by a per-lane `if (j == ...)` chain, which the compiler turned into sixteen copies of a divergent branch
+    // tree with an LDS wait in each: ~1 500 instructions per wave, a quarter of everything the kernel issued at config 3
+    // (32 640 waves of ~6 200 instructions each; profiles/r05_bwd_quads.md).
     unsigned Bd[4][4];
     {
-        S.y[lane * 3] = vo[0] * ms::kInv255; S.y[lane * 3 + 1] = vo[1] * ms::kInv255; S.y[lane * 3 + 2] = vo[2] * ms::kInv255;
+        unsigned *tab = reinterpret_cast<unsigned *>(S.y);   // 16 rows of kYStride words: free until the first tile is stored
+        const float x = (float)lx - 3.5f, y = (float)ly - 3.5f;
+        auto both = [](float f) { const unsigned b = __float_as_uint(f); return (b >> 16) | (b & 0xffff0000u); };
+        tab[0 * kYStride + lane] = both(1.0f);
+        tab[1 * kYStride + lane] = both(x);
+        tab[2 * kYStride + lane] = both(y);
+        tab[3 * kYStride + lane] = both(x * x);
+        tab[4 * kYStride + lane] = both(x * y);
+        tab[5 * kYStride + lane] = both(y * y);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float c = vo[k] * ms::kInv255;
+            const unsigned c_hi = __float_as_uint(c) & 0xffff0000u;
+            tab[(6 + k) * kYStride + lane] = (c_hi >> 16) | c_hi;                                     // hi(dL/dC) for both terms
+            tab[(9 + k) * kYStride + lane] = __float_as_uint(c - __uint_as_float(c_hi)) >> 16;       // lo(dL/dC) for the hi term
+        }
+        tab[12 * kYStride + lane] = 0u;
         wave_lds_sync_q();
-        const int g = lane >> 4, j = lane & 15;
+        const int g = lane >> 4, j = min(lane & 15, 12);
+        const u32x4 *row = reinterpret_cast<const u32x4 *>(tab + j * kYStride + 4 * g);   // (16-byte aligned: kYStride % 4 == 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                const int p = 16 * i + 4 * g + mm;
-                const float x = (float)(p & 7) - 3.5f, y = (float)(p >> 3) - 3.5f;
-                float f_hi = 0.f, f_lo = 0.f;
-                if (j == 0) f_hi = f_lo = 1.0f;
-                else if (j == 1) f_hi = f_lo = x;
-                else if (j == 2) f_hi = f_lo = y;
-                else if (j == 3) f_hi = f_lo = x * x;
-                else if (j == 4) f_hi = f_lo = x * y;
-                else if (j == 5) f_hi = f_lo = y * y;
-                else if (j < 12) {
-                    const float c = S.y[p * 3 + (j < 9 ? j - 6 : j - 9)];
-                    const float c_hi = __uint_as_float(__float_as_uint(c) & 0xffff0000u);
-                    if (j < 9) f_hi = f_lo = c_hi;
-                    else f_hi = c - c_hi;
-                }
-                Bd[i][mm] = (__float_as_uint(f_hi) >> 16) | (__float_as_uint(f_lo) & 0xffff0000u);
-            }
+            const u32x4 v = row[4 * i];   // pixels 16 i + 4 g + (0..3)
+            Bd[i][0] = v[0]; Bd[i][1] = v[1]; Bd[i][2] = v[2]; Bd[i][3] = v[3];
         }
         wave_lds_sync_q();
     }
@@ -482,30 +488,53 @@ __global__ __launch_bounds__(64, MS_BWDQ_WAVES) void k_rasterize_bwd_quads(BwdQA
 
 // ---- the tiles the forward's clean-up pass redid ------------------------------------------------------------------
 // A lazily sorted frame's rasteriser stops at the end of a heavy tile's sorted front; a tile whose pixels outlive it
-// is redone by k_tile_redo (rasterize.hip) from the tile's unsorted keys, and left out by the launch above (skip_flag).
-// Here, per such tile: one workgroup sorts the tile's (depth bits << 32 | index) keys IN PLACE -- the frame is
-// finished, nothing else reads them; a sorting network whose compare-exchanges all point the same way, so that the
-// virtual +inf padding up to a power of two never moves -- and its eight waves then walk the WHOLE list quad by quad,
-// taking the indices from the keys' low words.  Slow and simple: no benchmark scene comes here (the launch finds an empty
-// list), tests force it with stacks of faint Gaussians.
-constexpr int kRedoThreads = 512;
+// is redone by the forward's clean-up pass (rasterize.hip) and left out by the launch above (skip_flag).  Round 5: a
+// differentiable frame's clean-up pass is the two-launch one -- k_redo_sort sorts every stranded tile's keys WHOLE in LDS
+// (bitonic up to 4 096 keys, sample sort beyond) and leaves the Gaussian ids in depth order in the tile's slots of the id
+// array, redo_flag[tile] = 2 -- so this launch has nothing to sort: one WAVE per (stranded tile, 16x16 block, quad), dealt
+// over the whole grid, walks those ids with the main launch's walk (no front: the whole list, until its pixels are done).
+// Round 4 sorted the tile's keys again here, in global memory, one 512-thread workgroup per tile on a grid of 64, and
+// walked the tile's blocks one after the other: exact, but unbounded -- a stranded 64-px bin of 100 000 keys is ~300 bitonic
+// passes over 800 KB and then 64 serial walks.  That path remains for a tile whose sample sort gave up (redo_flag == 1:
+// not seen) and for frames whose forward ran the one-launch clean-up (MOJOSPLAT_REDO_SORT=0).
+constexpr int kRedoThreads = 256;
 
 struct BwdRedoArgs {
-    BwdQArgs a;
+    BwdQArgs a;            // ids: the frame's id array (stride 1)
     uint64_t *keys;
-    const int32_t *redo_list, *redo_count;
+    const int32_t *redo_list, *redo_count, *redo_flag;
 };
 
 __global__ __launch_bounds__(kRedoThreads) void k_rasterize_bwd_redo(BwdRedoArgs R) {
     __shared__ BwdQStage s_stage[kRedoThreads / 64];
     const int n_redo = *R.redo_count;
+    if (n_redo <= 0) return;
     const int tid = threadIdx.x, w = tid >> 6;
+    // (1) the tiles whose ids are sorted: a wave per (tile, block, quad)
+    {
+        const int per_tile = R.a.nsub * 4;
+        const int64_t total = (int64_t)n_redo * per_tile, stride = (int64_t)gridDim.x * (kRedoThreads / 64);
+        for (int64_t item = (int64_t)blockIdx.x * (kRedoThreads / 64) + w; item < total; item += stride) {
+            const int ri = (int)(item / per_tile), qi = (int)(item - (int64_t)ri * per_tile);
+            const int tile = R.redo_list[ri];
+            if (R.redo_flag[tile] != 2) continue;
+            bwd_quad(R.a, tile, qi >> 2, qi & 3, s_stage[w]);
+        }
+    }
+    // (2) the others: the tile's (depth bits << 32 | index) keys sorted IN PLACE -- the frame is finished, nothing else
+    // reads them; a sorting network whose compare-exchanges all point the same way, so that the virtual +inf padding up to
+    // a power of two never moves -- and the indices taken from the keys' low words.  Slow and simple.
+    BwdQArgs B = R.a;
+    B.ids = reinterpret_cast<const int32_t *>(R.keys);
+    B.id_stride = 2;
     for (int ri = blockIdx.x; ri < n_redo; ri += gridDim.x) {
         const int tile = R.redo_list[ri];
+        if (R.redo_flag[tile] == 2) continue;   // (uniform)
         const int end_all = min(R.a.tile_ranges[2 * tile + 1], R.a.max_isects);
         const int start = min(R.a.tile_ranges[2 * tile], end_all);
         const int n = end_all - start;
         uint64_t *k = R.keys + start;
+        __syncthreads();
         for (int size = 2; (size >> 1) < n; size <<= 1) {
             // first step of a merge: i against its mirror image inside the block of `size`
             for (int t = tid; t < (n + 1) / 2 + size; t += kRedoThreads) {   // (t indexes pairs; the bound only needs to cover them)
@@ -529,7 +558,7 @@ __global__ __launch_bounds__(kRedoThreads) void k_rasterize_bwd_redo(BwdRedoArgs
             }
         }
         __syncthreads();
-        for (int qi = w; qi < R.a.nsub * 4; qi += kRedoThreads / 64) bwd_quad(R.a, tile, qi >> 2, qi & 3, s_stage[w]);
+        for (int qi = w; qi < R.a.nsub * 4; qi += kRedoThreads / 64) bwd_quad(B, tile, qi >> 2, qi & 3, s_stage[w]);
         __syncthreads();
     }
 }
@@ -577,20 +606,21 @@ int ms::rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const flo
 }
 
 int ms::rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const float *backgrounds, int W, int H, int tile_size,
-                           const int32_t *tile_ranges, uint64_t *keys, const int32_t *redo_list, const int32_t *redo_count,
-                           const float *render_colors, const float *render_alphas, const float *v_render_colors,
-                           const float *v_render_alphas, float *packed_rows, void *stream) {
+                           const int32_t *tile_ranges, uint64_t *keys, const int32_t *ids, const int32_t *redo_list,
+                           const int32_t *redo_count, const int32_t *redo_flag, const float *render_colors,
+                           const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
+                           float *packed_rows, void *stream) {
     MS_REQUIRE(N > 0 && M > 0 && M <= 0x7fffffffll && N <= 0x3ffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd_redo: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0 && tile_size % 16 == 0, MS_ERR_INVALID_ARG,
                "rasterize_bwd_redo: the tile size must be a multiple of 16");
-    MS_REQUIRE(records && tile_ranges && keys && redo_list && redo_count && render_colors && render_alphas && v_render_colors &&
-                   packed_rows, MS_ERR_INVALID_ARG, "rasterize_bwd_redo: null pointer");
+    MS_REQUIRE(records && tile_ranges && keys && ids && redo_list && redo_count && redo_flag && render_colors && render_alphas &&
+                   v_render_colors && packed_rows, MS_ERR_INVALID_ARG, "rasterize_bwd_redo: null pointer");
     BwdRedoArgs R;
     BwdQArgs &A = R.a;
     A.records = (const float4 *)records;
     A.tile_ranges = tile_ranges;
-    A.ids = reinterpret_cast<const int32_t *>(keys);   // the sorted keys' low words
-    A.id_stride = 2;
+    A.ids = ids;
+    A.id_stride = 1;
     A.front_count = nullptr; A.front_threshold = 0; A.skip_flag = nullptr;
     A.render_colors = render_colors; A.render_alphas = render_alphas; A.v_render_colors = v_render_colors;
     A.v_render_alphas = v_render_alphas; A.backgrounds = backgrounds;
@@ -603,8 +633,10 @@ int ms::rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const floa
     A.ngrid = 0;
     A.max_isects = (int)M;
     A.n_gauss = (int)N;
-    R.keys = keys; R.redo_list = redo_list; R.redo_count = redo_count;
-    hipLaunchKernelGGL(k_rasterize_bwd_redo, dim3(64), dim3(kRedoThreads), 0, (hipStream_t)stream, R);
+    R.keys = keys; R.redo_list = redo_list; R.redo_count = redo_count; R.redo_flag = redo_flag;
+    // (every workgroup leaves at once on the frames with an empty redo list -- almost all: what the launch costs then is its
+    // kernel boundary, whatever the grid)
+    hipLaunchKernelGGL(k_rasterize_bwd_redo, dim3(1024), dim3(kRedoThreads), 0, (hipStream_t)stream, R);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }

@@ -102,6 +102,24 @@ def _balance_enabled():
     return os.environ.get("MOJOSPLAT_BALANCE", "1") != "0"
 
 
+def _force_exchange():
+    """MOJOSPLAT_FORCE_EXCHANGE=1: a group of ONE rank still runs the exchange step -- the status all-gather and the
+    in-place all_gather_into_tensor of the framebuffer onto itself.  For the world-1 RCCL test (tests/test_hip_rccl.py):
+    one GPU is all a test box has, RCCL refuses two ranks per device, and this way its collectives, their stream
+    semantics and the in-place aliasing run on hardware."""
+    import os
+    return os.environ.get("MOJOSPLAT_FORCE_EXCHANGE", "0") == "1"
+
+
+def balance_weights(records):
+    """The weights `rebalance` runs on, from the ranks' gathered status records (on_grid, Gaussians that reach the band if the
+    LIBRARY pre-culled it else -1, pairs in the band, stamp): ONE unit for all ranks -- Gaussians only if every band was
+    pre-culled, else pairs (round 3 let each rank pick its unit from a local guess: ragged bands could make one rank
+    report Gaussians and another pairs, and the plan oscillated).  -> (weights, by_gaussians)."""
+    by_gaussians = all(int(r[1]) >= 0 for r in records)
+    return [int(r[1] if by_gaussians else r[2]) for r in records], by_gaussians
+
+
 _plans = {}   # plan key -> dict(bounds, frame): the bands of the next frame of that scene, identical on every rank
 _CHECK_EVERY, _CHECK_SETTLED, _SPREAD_OK = 8, 64, 1.08
 
@@ -242,14 +260,22 @@ class PendingFrame:
     framebuffer all-gather enqueued on the collective's stream) and makes the CURRENT stream wait
     for the gather; -> the full (H, W, C) image."""
 
-    def __init__(self, image=None, finalize=None):
-        self._image, self._finalize = image, finalize
+    def __init__(self, image=None, finalize=None, on_drop=None):
+        self._image, self._finalize, self._on_drop = image, finalize, on_drop
 
     def wait(self) -> torch.Tensor:
         if self._finalize is not None:
-            self._image = self._finalize()
-            self._finalize = None
+            fin, self._finalize = self._finalize, None
+            self._image = fin()
         return self._image
+
+    def __del__(self):
+        # dropped without wait(): release what the frame holds (its lane)
+        if getattr(self, "_finalize", None) is not None and getattr(self, "_on_drop", None) is not None:
+            try:
+                self._on_drop()
+            except Exception:   # noqa: BLE001  (interpreter shutdown)
+                pass
 
 
 _turn = {}  # device -> which of the two lanes the next asynchronous frame takes
@@ -319,7 +345,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color channels ({C})")
 
     # ---- this frame's bands: equal until the ranks' pair counts say otherwise (rebalance, module docstring)
-    live = world > 1 and rehearse is None                 # a real process group: status records are exchanged
+    live = (world > 1 or (_force_exchange() and dist.is_initialized())) and rehearse is None   # a real process group: status records are exchanged
     pkey = _plan_key(means3d, camera, tile_size, world, group)
     if bounds is None:
         bounds = band_bounds(means3d, camera, tile_size, world, group)
@@ -403,8 +429,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                     raise RuntimeError(f"render_gaussians_sharded: the ranks of this group lost step (frame counter / "
                                        f"band bounds stamps {stamps}); every rank must make the same sharded calls")
                 # identical numbers on every rank -> identical new bounds on every rank, from the next frame on
-                by_gaussians = all(int(v) >= 0 for v in rec[:, 1])
-                weights = [int(v) for v in (rec[:, 1] if by_gaussians else rec[:, 2])]
+                weights, _ = balance_weights(rec.tolist())
                 nb, spread = rebalance(list(bounds), weights)
                 plan["settled"] = spread <= _SPREAD_OK
                 if not plan["settled"]:
@@ -512,7 +537,7 @@ def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, 
     if C == 0:
         return torch.empty((0, 0, 0, ch), dtype=torch.float32, device=dev)
     H, W = cams[0].H, cams[0].W
-    if world == 1:
+    if world == 1 and not (_force_exchange() and dist.is_initialized()):
         out = render_gaussians_batch(means3d, scales, quats, opacities, features, cams,
                                      background_color=background_color, tile_size=tile_size)
         return PendingFrame(image=out) if async_op else out

@@ -216,19 +216,23 @@ def _begin_async(means3d, scales, quats, opacities, colors, camera, bg, mode, ev
     """render_gaussians(async_op=True): the frame on a lane stream (ms_render_fwd BEGIN, no host wait), as the sharded
     entry point runs a rank's band (distributed.py) -- streams addressed by handle and ordered with the lanes' persistent
     events; torch's current stream is never switched."""
-    from ._fused import _Frame, _lane_streams
+    from ._fused import _Frame, _frame_lock, _lane_streams
     from .distributed import PendingFrame, _current_stream, _lane_events, _turn
     dev = means3d.device
     cur = _current_stream(dev)
-    lane = _turn.get(dev, 0)
-    _turn[dev] = 1 - lane
-    s = _lane_streams(dev)[lane]
-    # marshal first (copies of non-fp32 / strided inputs are enqueued on the CURRENT stream), then order the lane behind it
-    frame = _Frame(means3d, scales, quats, opacities, colors, camera, bg, mode, evs, None, None, 1 + lane, s.cuda_stream)
-    ev_in, ev_out = _lane_events(dev, lane)
-    ev_in.record(cur)
-    s.wait_event(ev_in)
-    frame.begin()
+    lanes = _lane_streams(dev)
+    # (round 5, advisor: the shared lanes are one-thread-at-a-time under _frame_lock -- the lane pick, the frame's claim on
+    # the lane's scratch and begin() happen under it, so two host threads cannot both pass the "lane is free" check)
+    with _frame_lock:
+        lane = _turn.get(dev, 0)
+        _turn[dev] = 1 - lane
+        s = lanes[lane]
+        # marshal first (copies of non-fp32 / strided inputs are enqueued on the CURRENT stream), then order the lane behind it
+        frame = _Frame(means3d, scales, quats, opacities, colors, camera, bg, mode, evs, None, None, 1 + lane, s.cuda_stream)
+        ev_in, ev_out = _lane_events(dev, lane)
+        ev_in.record(cur)
+        s.wait_event(ev_in)
+        frame.begin()
     seen = set()
     for t in (means3d, scales, quats, opacities, colors, bg, frame.img) + tuple(x for x in frame.keep[:-1] if x is not None):
         if id(t) not in seen:     # (the caching allocator must not hand their memory out again before the lane is done)
@@ -236,12 +240,17 @@ def _begin_async(means3d, scales, quats, opacities, colors, camera, bg, mode, ev
             t.record_stream(s)
 
     def finalize():
-        img, m = frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
+        try:
+            img, m = frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
+        finally:
+            frame.st["busy"] = False              # (a frame whose finish raised must not hold the lane for ever)
         learn(m)
         ev_out.record(s)
         _current_stream(dev).wait_event(ev_out)
         return img
-    return PendingFrame(finalize=finalize)
+    # (a PendingFrame dropped unwaited gives the lane back too: its kernels are ordered on the lane's stream before whatever
+    # the next frame on that lane enqueues)
+    return PendingFrame(finalize=finalize, on_drop=lambda st=frame.st: st.__setitem__("busy", False))
 
 
 @torch.no_grad()

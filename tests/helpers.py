@@ -111,3 +111,56 @@ def check_image_strict(img, ref, margin, *, tag, atol=1e-4, eps=1e-5, flip_cap=1
     assert rec["unexplained"] == 0, f"{tag}: {rec['unexplained']} px beyond {atol} with no branch near its threshold: {rec}"
     assert rec["max_abs"] <= flip_cap, f"{tag}: max abs diff {rec['max_abs']:.3g}"
     return rec
+
+
+# ------------------------------------------------------------------ gradient bars (round 5)
+# Two bars per tensor.  (1) max norm: |g - g_ref| <= rel * max|g_ref| -- what rounds 1-4 asserted; it is blind to the error
+# of the small-gradient majority.  (2) per element: every element with |g_ref| >= floor * max|g_ref| must agree to
+# elem_rel RELATIVE to itself (and the 99.9th percentile of those errors to elem_p999).  The backward rasteriser's
+# two-term bf16 tile (2^-17 per term) and its approximate reciprocal are what bar (2) watches.
+# Where the bars sit (measured, profiles/r05_grad_stats.txt): against float64 autograd the worst element of any test is
+# 3.4e-4 off -> 2e-3 on EVERY element.  Fused against the per-stage functions BOTH sides are fp32 with different orders of
+# summation (the per-stage kernel walks back to front and recovers T by division): regular scenes up to 3e-3 on a single
+# element of ~7 000 (a sum that nearly cancels), 99.9 % within 5e-4 -> 5e-3 on every element, 1e-3 on the 99.9th
+# percentile; the adversarial stacks (thousands of faint entries at one depth behind every pixel) 1.6e-2 / 2.3e-3 ->
+# 5e-2 / 5e-3.
+def grad_stats(got, ref, floor=1e-3):
+    """-> dict(scale, max_norm_err, checked, elem_rel_max, elem_rel_p999, worst_index): got / ref arrays or tensors."""
+    got = (np_(got) if torch.is_tensor(got) else np.asarray(got)).astype(np.float64).reshape(-1)
+    ref = (np_(ref) if torch.is_tensor(ref) else np.asarray(ref)).astype(np.float64).reshape(-1)
+    scale = float(np.abs(ref).max()) if ref.size else 0.0
+    err = np.abs(got - ref)
+    out = dict(scale=scale, max_norm_err=float(err.max() / scale) if scale > 0 else 0.0, checked=0, elem_rel_max=0.0,
+               elem_rel_p999=0.0, worst_index=-1)
+    if scale > 0:
+        sel = np.abs(ref) >= floor * scale
+        if sel.any():
+            rel = err[sel] / np.abs(ref[sel])
+            out.update(checked=int(sel.sum()), elem_rel_max=float(rel.max()), elem_rel_p999=float(np.quantile(rel, 0.999)),
+                       worst_index=int(np.flatnonzero(sel)[int(rel.argmax())]))
+    return out
+
+
+GRAD_LOG = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "gpurun_out", "grad_stats.jsonl")
+
+
+def assert_grad_close(name, got, ref, rel=2e-3, elem_rel=None, floor=1e-3, elem_p999=None):
+    """GRAD_BARS_SOFT=1 in the environment records the per-element statistics (gpurun_out/grad_stats.jsonl) without
+    asserting them -- for calibrating the bars; the max-norm bar is always asserted."""
+    import inspect
+    import json
+    st = grad_stats(got, ref, floor)
+    try:
+        os.makedirs(os.path.dirname(GRAD_LOG), exist_ok=True)
+        with open(GRAD_LOG, "a") as f:
+            f.write(json.dumps(dict(test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], name=name, rel=rel,
+                                    elem_rel=elem_rel, **st)) + "\n")
+    except OSError:
+        pass
+    assert st["max_norm_err"] * st["scale"] <= rel * st["scale"] + 1e-6, f"{name}: max-norm bar {rel}: {st}"
+    if os.environ.get("GRAD_BARS_SOFT") != "1":
+        if elem_rel is not None:
+            assert st["elem_rel_max"] <= elem_rel, f"{name}: per-element bar {elem_rel} (|g_ref| >= {floor} max): {st}"
+        if elem_p999 is not None:
+            assert st["elem_rel_p999"] <= elem_p999, f"{name}: 99.9th percentile of the per-element error > {elem_p999}: {st}"
+    return st

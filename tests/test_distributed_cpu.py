@@ -245,10 +245,22 @@ def test_a_rank_in_two_groups_keeps_a_plan_per_group():
 
 def test_balance_weights_use_one_unit_for_all_ranks():
     """Advisor, round 3: a rank reported 'Gaussians reaching my band' or 'pairs in my band' by a local guess.  The unit is
-    now chosen from the exchanged records: Gaussians only if EVERY rank's band was pre-culled by the library."""
+    chosen from the exchanged records: Gaussians only if EVERY rank's band was pre-culled by the library.  (Round 5:
+    behavioural -- the records of mixed culled / unculled ranks through the function the live path calls.)"""
     import mojosplat_amd.distributed as D
-    import inspect
-    src = inspect.getsource(D.render_gaussians_sharded)
-    assert "by_gaussians = all(int(v) >= 0 for v in rec[:, 1])" in src and "info[\"flags\"] & 2048" in src
-    # the planning step itself is unit-agnostic: identical weights -> identical bounds
-    assert D.rebalance([0, 4, 8], [300, 100])[0] == D.rebalance([0, 4, 8], [300, 100])[0]
+    # records: (on_grid, Gaussians reaching the band | -1, pairs, stamp)
+    all_culled = [(900, 900, 5000, 1), (2500, 2500, 9000, 1), (700, 700, 4000, 1)]
+    w, by_g = D.balance_weights(all_culled)
+    assert by_g and w == [900, 2500, 700]
+    mixed = [(900, 900, 5000, 1), (4100, -1, 9000, 1), (700, 700, 4000, 1)]   # the middle band was too wide for the pre-cull
+    w, by_g = D.balance_weights(mixed)
+    assert not by_g and w == [5000, 9000, 4000], "one unculled rank puts EVERY rank on pairs"
+    # ... and the plans that follow differ exactly as the units do: ragged bands of mixed ranks re-plan on pairs
+    bounds = [0, 5, 17, 23]
+    on_pairs, _ = D.rebalance(bounds, w)
+    on_gaussians, _ = D.rebalance(bounds, [r[0] for r in mixed])       # what a rank guessing "Gaussians" would have planned
+    assert on_pairs != on_gaussians
+    assert D.rebalance(bounds, w)[0] == on_pairs                       # same numbers -> same bounds on every rank
+    # torch tensors as the live path passes them (rec.tolist() of the gathered int64 records)
+    rec = torch.tensor(mixed, dtype=torch.int64)
+    assert D.balance_weights(rec.tolist()) == (w, False)

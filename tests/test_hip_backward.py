@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import np_, oracle_project, proj_scene, raster_scene, simple_camera
+from helpers import assert_grad_close, np_, oracle_project, proj_scene, raster_scene, simple_camera
 from mojosplat_amd.autograd import (project_gaussians_autograd, rasterize_gaussians_autograd,
                                     render_gaussians_trainable)
 from mojosplat_amd.scenes import randscene_v1
@@ -19,11 +19,13 @@ from oracle import torch_oracle
 pytestmark = pytest.mark.gpu
 
 
-def assert_grad_close(name, got, ref, rel=2e-3):
-    got, ref = np_(got).astype(np.float64), np_(ref).astype(np.float64)
-    scale = np.abs(ref).max()
-    err = np.abs(got - ref).max()
-    assert err <= rel * scale + 1e-6, f"{name}: max err {err:.3g} vs scale {scale:.3g}"
+# Per-element bars (round 5, tests/helpers.py::assert_grad_close, where the numbers are justified): next to the max-norm
+# bar, every element with |g_ref| >= 1e-3 max|g_ref| agrees to ELEM_F64 relative against float64 autograd; fused against
+# per-stage (two fp32 implementations) to FUSED["elem_rel"] with the 99.9th percentile within FUSED["elem_p999"]; STACKS:
+# the adversarial stacks of faint Gaussians.
+ELEM_F64 = 2e-3
+FUSED = dict(elem_rel=5e-3, elem_p999=1e-3)
+STACKS = dict(elem_rel=5e-2, elem_p999=5e-3)
 
 
 def _cam_args(cam):
@@ -51,7 +53,7 @@ def test_projection_backward_vs_autograd(device, N, T):
     rloss.backward()
     for name, a, b in zip(("means3d", "scales", "quats"), leaves, ref_leaves):
         assert (a.grad[~vis] == 0).all()
-        assert_grad_close(name, a.grad, b.grad, rel=1e-3)
+        assert_grad_close(name, a.grad, b.grad, rel=1e-3, elem_rel=ELEM_F64)
 
 
 @pytest.mark.parametrize("N,bg", [(5, None), (60, (0.3, 0.5, 0.7)), (250, (0.1, 0.1, 0.1))])
@@ -80,9 +82,9 @@ def test_raster_backward_vs_autograd(device, N, bg):
     (rimg * v_img.double()).sum().backward()
     np.testing.assert_allclose(np_(img), np_(rimg), atol=1e-4)
     for name, a, b in zip(("means2d", "conics", "colors", "opacities"), leaves, rl):
-        assert_grad_close(name, a.grad, b.grad)
+        assert_grad_close(name, a.grad, b.grad, elem_rel=ELEM_F64)
     if bgt is not None:
-        assert_grad_close("background", bgd.grad, rbg.grad)
+        assert_grad_close("background", bgd.grad, rbg.grad, elem_rel=ELEM_F64)
 
 
 def test_raster_backward_repeatable_within_atomic_noise(device):
@@ -125,7 +127,7 @@ def test_end_to_end_gradients_and_finite_difference(device):
     np.testing.assert_allclose(np_(img), np_(rimg), atol=2e-4)
     (rimg * v_img.double().cpu()).sum().backward()
     for name, a, b in zip(names, leaves, rl):
-        assert_grad_close(name, a.grad, b.grad, rel=5e-3)
+        assert_grad_close(name, a.grad, b.grad, rel=5e-3, elem_rel=ELEM_F64)
 
     # finite difference along a random direction of the colours (exactly linear path)
     # (seeded direction, float64 sums: the two losses differ in their 5th digit, which float32 sums
@@ -162,7 +164,7 @@ def test_fused_differentiable_frame_equals_stagewise(device, N, W, H, ell):
             res.append((img.detach(), [l.grad for l in leaves]))
         assert torch.equal(res[0][0], res[1][0]), rep
         for name, a, b in zip(names, res[0][1], res[1][1]):
-            assert_grad_close(name, a, b, rel=1e-4)
+            assert_grad_close(name, a, b, rel=1e-4, **FUSED)
     # an empty frame: zeros image, zero gradients
     sc, cam = randscene_v1(500, W, H, ell=ell, seed=17, device=device)
     leaves = [sc[k].clone().requires_grad_(True) for k in names]
@@ -199,7 +201,7 @@ def test_differentiable_frame_edge_cases(device):
         res.append((out.detach(), [l.grad for l in leaves]))
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
-        assert_grad_close("grad", a, b, rel=1e-4)
+        assert_grad_close("grad", a, b, rel=1e-4, **FUSED)
 
 
 @pytest.mark.parametrize("n,z_lo,z_hi,opacity", [(4000, 4.0, 6.0, 0.005), (3000, 4.0, 4.0001, 0.02), (16000, 5.0, 5.0, 0.0055)])
@@ -227,7 +229,7 @@ def test_differentiable_frame_whose_sorted_fronts_run_out(device, n, z_lo, z_hi,
     for r in res[1:]:
         assert torch.equal(r[0], res[0][0])
         for name, a, b in zip(names, r[1], res[0][1]):
-            assert_grad_close(name, a, b, rel=2e-3)
+            assert_grad_close(name, a, b, rel=2e-3, **STACKS)
 
 
 @pytest.mark.parametrize("px", [16, 64])
@@ -254,7 +256,7 @@ def test_differentiable_frame_on_every_binning_grid(device, monkeypatch, px):
         for r in res[1:]:
             assert torch.equal(r[0], res[0][0])
             for name, a, b in zip(names, r[1], res[0][1]):
-                assert_grad_close(name, a, b, rel=2e-3)
+                assert_grad_close(name, a, b, rel=2e-3, **STACKS)
 
 
 def test_differentiable_frame_with_alpha_gradients_and_partial_tiles(device):
@@ -274,4 +276,25 @@ def test_differentiable_frame_with_alpha_gradients_and_partial_tiles(device):
         res.append((img.detach(), [l.grad for l in leaves]))
     assert torch.equal(res[0][0], res[1][0])
     for name, a, b in zip(names, res[1][1], res[0][1]):
-        assert_grad_close(name, a, b, rel=5e-4)
+        assert_grad_close(name, a, b, rel=5e-4, **FUSED)
+
+
+@pytest.mark.parametrize("ts", [8, 24, 32])
+def test_differentiable_frame_at_any_tile_size(device, ts):
+    """Round 5 (advisor): the quad-wave backward works in 16x16 blocks, so a frame at tile_size 8 / 24 must keep last_ids and
+    fully sorted lists for the older kernel (round 4 chose the lean path by channel count alone and raised in backward());
+    32 takes the quad-wave kernel.  Image bit for bit and gradients against the per-stage functions at the same tile size."""
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    sc, cam = randscene_v1(6000, 208, 120, ell=-3.0, seed=4, device=device)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=device)
+    v_img = torch.rand(cam.H, cam.W, 3, generator=torch.Generator().manual_seed(8)).to(device)
+    res = []
+    for stagewise in (True, False, False):
+        leaves = [sc[k].clone().requires_grad_(True) for k in names]
+        img = render_gaussians_trainable(*leaves, cam, background_color=bg, tile_size=ts, stagewise=stagewise)
+        img.backward(v_img)
+        res.append((img.detach(), [l.grad for l in leaves]))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0])
+        for name, a, b in zip(names, r[1], res[0][1]):
+            assert_grad_close(name, a, b, rel=5e-4, **FUSED)

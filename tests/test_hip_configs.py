@@ -25,7 +25,7 @@ import torch
 
 import mojosplat_amd as ms
 import oracle
-from helpers import check_image_strict, np_
+from helpers import assert_grad_close, check_image_strict, np_
 from mojosplat_amd import _fused
 from mojosplat_amd.binning import bin_gaussians_to_tiles_hip
 from mojosplat_amd.distributed import band_plan, render_gaussians_sharded
@@ -188,9 +188,10 @@ def test_config3_backward_full_size(device):
     assert torch.equal(res[0][0], ms.render_gaussians(*g, cam, background_color=bg, backend="hip"))
     for name, a, b, c in zip(names, res[0][1], res[1][1], res[2][1]):
         assert torch.isfinite(a).all() and a.abs().sum() > 0, name
-        scale = float(c.abs().max())
-        assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-6, f"{name}: not repeatable"
-        assert float((a - c).abs().max()) <= 1e-4 * scale + 1e-6, f"{name}: fused != per-stage"
+        assert_grad_close(name + " (repeat)", a, b, rel=1e-4)
+        # (round 5: ... and element by element -- every element of at least 1e-3 of the tensor's max to 1e-3 of itself)
+        st = assert_grad_close(name + " (fused vs per-stage)", a, c, rel=1e-4, elem_rel=1e-3, elem_p999=5e-4)
+        print("GRAD", name, st)
 
 
 @pytest.mark.parametrize("x0,y0", [(640, 348), (960, 348), (640, 540), (960, 540)])
@@ -229,9 +230,8 @@ def test_config3_crop_backward_vs_float64_autograd(device, x0, y0):
     assert float((d > 1e-4).float().mean()) <= 1e-4 and float(d.max()) <= 1e-2   # branch flips only
     (rimg * v_img.double().cpu()).sum().backward()
     for name, a, b in zip(names, leaves, rl):
-        got, ref = a.grad.double().cpu(), b.grad
-        err, scale = float((got - ref).abs().max()), float(ref.abs().max())
-        assert err <= 5e-3 * scale + 1e-6, f"{name}: max err {err:.3g} vs scale {scale:.3g}"
+        st = assert_grad_close(name, a.grad, b.grad, rel=5e-3, elem_rel=2e-3)   # (round 5: the per-element bar, against float64)
+        print("GRAD", name, st)
 
 
 def test_scene_swap_at_config4_is_exact_and_bounded(device):
@@ -277,3 +277,50 @@ def test_scene_swap_at_config4_is_exact_and_bounded(device):
     assert max(times[5:9]) <= 15.0
     assert times[7] <= 8.0 and times[8] <= 8.0       # full sorts by the swapped scene's third frame
     assert max(times[10:]) <= 3.0
+
+
+def test_training_step_on_stranded_bins_is_exact_and_bounded(device):
+    """Round 5: the worst STEP the lazy machinery can meet -- config 3's scene with the near half all but transparent, through
+    render_gaussians_trainable: the forward's lazily sorted fronts run out in most heavy bins, its two-launch clean-up pass
+    sorts those bins whole and redoes them (alphas included), and the backward's redo launch walks the sorted ids, a wave
+    per (bin, block, quad) (round 4: one workgroup per bin re-sorting its keys in global memory, 64 workgroups in all,
+    unbounded).  Image bit for bit and gradients within the suite's bars of the per-stage functions; every step <= 20 ms;
+    and the differentiable frames LEARN (advisor, round 4): once a step's clean-up count has reached the host, later steps
+    run deeper fronts or full sorts and stop paying the clean-up."""
+    import time
+    from mojosplat_amd.autograd import render_gaussians_trainable
+    sc, cam, _ = _scene("cfg3", device)
+    depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
+    sc = dict(sc)
+    sc["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.02, sc["opacities"])
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    v_img = torch.rand(cam.H, cam.W, 3, generator=torch.Generator().manual_seed(43)).to(device)
+
+    def step(stagewise):
+        leaves = [sc[k].clone().requires_grad_(True) for k in names]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = render_gaussians_trainable(*leaves, cam, background_color=bg, stagewise=stagewise)
+        img.backward(v_img)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, img.detach(), [l.grad for l in leaves]
+    _, ref_img, ref_grads = step(True)
+    _fused._state.clear()
+    _fused.FRAME_STATS = stats = {}
+    times = []
+    try:
+        for k in range(8):
+            ms_, img, grads = step(False)
+            times.append(ms_)
+            assert torch.equal(img, ref_img), f"step {k}: the image differs from the per-stage path"
+            for name, a, b in zip(names, grads, ref_grads):
+                assert_grad_close(f"step {k} {name}", a, b, rel=2e-3, elem_rel=1e-1, elem_p999=5e-3)
+    finally:
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
+    print("training steps on stranded bins, ms per synchronised step:", [round(t, 2) for t in times], stats)
+    assert stats.get("own_redo_tiles", 0) > 50, "the scene did not strand its bins"
+    assert max(times[1:]) <= 20.0          # (the first step includes buffer growth / kernel loading)
+    assert stats.get("own_full_sort_on", 0) + stats.get("own_front_level_up", 0) >= 1, "the differentiable frames never learnt"
+    assert times[-1] <= 0.75 * max(times[1:4]) or times[-1] <= 2.0, "later steps still pay the clean-up pass"
