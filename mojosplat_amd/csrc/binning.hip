@@ -157,6 +157,39 @@ __device__ __forceinline__ int chunk_of_block(int b, int G) {
     return x * n8 + min(x, rem) + k;
 }
 
+// Which POSITIONS a workgroup of the count / scatter kernels walks (round 5).  Rounds 1-4 gave workgroup g the g-th
+// contiguous chunk of the Gaussians.  That is fine for a scene stored in random order -- every chunk is a sample of the
+// whole scene -- and wrong for one stored in a spatially coherent order (Morton-sorted checkpoints are common): a chunk is
+// then one cell of space, and the work of a cell ranges from nothing (off screen, behind the camera, behind its bins'
+// depth cut-offs) to several times the mean (near the camera: large boxes, every pair kept).  With one or two workgroups
+// per CU and no dynamic scheduling the launch ends with its heaviest chunk: measured on the Morton-sorted config 5,
+// k_isect_scatter 32 -> 93 us and k_project_hist 122 -> 140 (profiles/r04_morton_probe.jsonl).  Now the positions are DEALT:
+// slices of kDeal consecutive positions go round-robin over the workgroups, slice s to workgroup s mod G, so every
+// workgroup samples the whole array -- kHistThreads / kDeal slices per trip of its loop, sixteen at the default of one
+// slice per wave -- whatever its order.  Loads and stores stay coalesced per wave (64 consecutive positions: 768 B of
+// means, 3 KB of records).  Which workgroup counts a position and which scatters it must agree (a workgroup's histogram row
+// is its stretch of every tile's segment): both kernels -- and a band's candidate walk -- go through this one mapping.
+#ifndef MS_DEAL
+#define MS_DEAL 64
+#endif
+constexpr int kDeal = MS_DEAL;
+static_assert(kDeal >= 64 && kDeal <= 1024 && (kDeal & (kDeal - 1)) == 0, "a slice is a power-of-two number of waves");
+struct Deal {
+    int64_t n, first, stride;
+    int iters;
+    // n_pos positions, workgroup wg of G (every wave of the workgroup; wave-uniform members)
+    __device__ __forceinline__ Deal(int64_t n_pos, int wg, int G) {
+        constexpr int kWavesPerSlice = kDeal / 64, kParts = kHistThreads / kDeal;
+        const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int part = w / kWavesPerSlice, v = w - part * kWavesPerSlice;
+        n = n_pos;
+        first = ((int64_t)part * G + wg) * kDeal + (int64_t)v * 64;          // trip 0: slice part * G + wg
+        stride = (int64_t)kParts * G * kDeal;                                 // = G * kHistThreads positions per trip of the grid
+        iters = (int)((n_pos + stride - 1) / stride);                         // uniform over the grid
+    }
+    __device__ __forceinline__ int64_t base(int it) const { return first + (int64_t)it * stride; }   // this wave's 64 positions of trip `it`
+};
+
 __device__ __forceinline__ int clampi(float v, int lo, int hi) {
     if (!(v > (float)lo)) return lo;  // also NaN
     if (v >= (float)hi) return hi;
@@ -379,15 +412,15 @@ __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const flo
                                                int32_t *tiles_per_gauss, unsigned int *s_on_grid, Candidates cand, int G, F &&f) {
     __shared__ uint32_t s_pref[kMaxG + 1];
     CandMap map{s_pref};
-    int64_t stride = kHistThreads;
-    if (cand.ids) {   // positions of the candidate list, step s -> workgroup s mod G
+    (void)i0;
+    if (cand.ids) {   // positions of the candidate list
         map.build(cand);
-        i0 = (int64_t)chunk_of_block(blockIdx.x, G) * kHistThreads;
         i1 = (int64_t)s_pref[cand.n_segs];
-        stride = (int64_t)G * kHistThreads;
     }
-    for (int64_t base = i0; base < i1; base += stride) {
-        const int64_t j = base + threadIdx.x;
+    // (i1: the number of positions -- Gaussians, or a band's candidates; dealt over the workgroups, see Deal)
+    const Deal deal(i1, chunk_of_block(blockIdx.x, G), G);
+    for (int it = 0; it < deal.iters; ++it) {
+        const int64_t j = deal.base(it) + (threadIdx.x & 63);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0, gi = 0;
         bool on_grid = false;
         unsigned long long mask = ~0ull;
@@ -541,16 +574,18 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     __syncthreads();
     __shared__ uint32_t s_pref[kMaxG + 1];
     CandMap map{s_pref};
-    const int wg = chunk_of_block(blockIdx.x, gridDim.x);   // this workgroup's chunk (and histogram row)
-    int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk), stride = kHistThreads;
-    if (cand.ids) {   // positions of the band's candidate list, step s -> workgroup s mod G (as the scatter kernel)
+    const int wg = chunk_of_block(blockIdx.x, gridDim.x);   // this workgroup's histogram row (and share of the positions: Deal)
+    (void)chunk;
+    int64_t i1 = N;
+    if (cand.ids) {   // positions of the band's candidate list
         map.build(cand);
-        i0 = (int64_t)wg * kHistThreads;
         i1 = (int64_t)s_pref[cand.n_segs];
-        stride = (int64_t)gridDim.x * kHistThreads;
     }
-    for (int64_t base = i0; base < i1; base += stride) {
-        const int64_t j = base + threadIdx.x;
+    const Deal deal(i1, wg, (int)gridDim.x);
+    const uint32_t lane_u = threadIdx.x & 63u;
+    for (int it = 0; it < deal.iters; ++it) {
+        const int64_t base = deal.base(it);   // (wave-uniform: this wave's slice of 64 positions)
+        const int64_t j = base + lane_u;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0, gi = 0;
         bool on_grid = false;
         unsigned long long mask = ~0ull;
@@ -578,7 +613,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             }
             const ms::RasterRecord r = ms::make_raster_record(m0, m1, c0, c1, c2, ms::ld_f32(opac_b, rec_src, 1, 0), col[0], col[1], col[2]);
             // (stores likewise: the step's slice of the output + a 32-bit byte offset)
-            char *rb = reinterpret_cast<char *>(rec + 3 * base) + 48u * (uint32_t)threadIdx.x;
+            char *rb = reinterpret_cast<char *>(rec + 3 * base) + 48u * lane_u;
             *reinterpret_cast<float4 *>(rb) = r.a;
             *reinterpret_cast<float4 *>(rb + 16) = r.b;
             *reinterpret_cast<float4 *>(rb + 32) = r.c;
@@ -592,7 +627,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             // (32-bit indices against uniform base pointers -- the step's own slice of the inputs, or the whole arrays
             // for a candidate's gather: one address register per load instead of 64-bit arithmetic per lane)
             const bool gather = cand.ids != nullptr;
-            const uint32_t src = gather ? (uint32_t)map.gaussian(cand, j) : (uint32_t)threadIdx.x;
+            const uint32_t src = gather ? (uint32_t)map.gaussian(cand, j) : lane_u;
             const int64_t b0 = gather ? 0 : base;
             const float *opac_b = opacities ? opacities + b0 : nullptr;
             const int64_t i = j;
@@ -631,7 +666,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                     else
                         mask = reach_mask(o.m0, o.m1, o.c0, o.c1, o.c2, ms::ld_f32(opac_b, src, 1, 0), x0, x1, y0, y1, g.ts);
                     if constexpr (LEAN != 2)
-                        *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(masks + base) + 8u * (uint32_t)threadIdx.x) = mask;
+                        *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(masks + base) + 8u * lane_u) = mask;
                 }
             }
             dbits_of_step = __float_as_uint(o.d);
@@ -643,12 +678,12 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             // clean-up launches project what they bring back themselves: nobody would read a box record -- 12 bytes a
             // Gaussian, a sixth of what this kernel moves, not written)
             if constexpr (LEAN == 2 && !CUT) {
-                uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(reinterpret_cast<Lean12 *>(lean) + base) + 12u * (uint32_t)threadIdx.x);
+                uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(reinterpret_cast<Lean12 *>(lean) + base) + 12u * lane_u);
                 const uint32_t box = n > 0 ? ((uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0) << 16) | ((uint32_t)(y1 - y0) << 24)) : 0u;
                 q[0] = box; q[1] = __float_as_uint(o.d); q[2] = (uint32_t)mask;
             }
             if constexpr (LEAN == 1)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lean + base) + 16u * (uint32_t)threadIdx.x) = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16),
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lean + base) + 16u * lane_u) = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16),
                                                                 __float_as_uint(o.d), (uint32_t)n | ((uint32_t)edges << 28));
         }
         count_on_grid(on_grid, &s_on_grid);
@@ -746,8 +781,8 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
     if (threadIdx.x == 0) s_on_grid = 0;
     __syncthreads();
     const int wg = chunk_of_block(blockIdx.x, gridDim.x);
-    const int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk);
-    for_each_isect<false>(i0, i1, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid, Candidates{nullptr, nullptr, 0, 0},
+    (void)chunk;
+    for_each_isect<false>(0, N, means2d, radii, nullptr, g, tiles_per_gauss, &s_on_grid, Candidates{nullptr, nullptr, 0, 0},
                    (int)gridDim.x, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)wg * T_local;
@@ -1206,19 +1241,19 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
             return;
         }
     }
-    const int wg = chunk_of_block(blockIdx.x, G);   // the chunk (and histogram row) the count kernel gave this index
+    const int wg = chunk_of_block(blockIdx.x, G);   // the histogram row (and share of the positions: Deal) the count kernel gave this index
     const uint32_t *row = hist + (size_t)wg * T_local;
-    int64_t i0 = (int64_t)wg * chunk, i1 = min(N, i0 + chunk), stride = kHistThreads;
+    (void)chunk;
+    int64_t n_pos = N;
     if constexpr (LEAN != 0) {
-        if (cand.ids) {   // positions of the band's candidate list, step s -> workgroup s mod G (as the count kernel)
+        if (cand.ids) {   // positions of the band's candidate list (dealt as the count kernel dealt them)
             __shared__ uint32_t s_pref[kMaxG + 1];
             CandMap map{s_pref};
             map.build(cand);
-            i0 = (int64_t)wg * kHistThreads;
-            i1 = (int64_t)s_pref[cand.n_segs];
-            stride = (int64_t)G * kHistThreads;
+            n_pos = (int64_t)s_pref[cand.n_segs];
         }
     }
+    const Deal deal(n_pos, wg, G);
     // The kernel is a chain of round trips (waves sat in s_waitcnt 71 % of their life), so everything the first
     // kAhead steps read -- all a workgroup has at 2 048 Gaussians per chunk -- is on its way before the cursors are set
     // up: the records, and the reach masks (unconditionally: which boxes need theirs is only known from the record).
@@ -1237,11 +1272,24 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     // held against the cut-offs here.  This workgroup walks those records alone.
     bool cut = false;
     if constexpr (LEAN == 2 && DEFER) cut = A.cut_stamp != 0u;
-    if (cut) {   // (whatever the walk above would have been -- a chunk, or a band's candidate steps)
-        i0 = (int64_t)wg * A.near_cap;
-        i1 = i0 + (int64_t)A.wg_far[kMaxG + wg];
-        stride = kHistThreads;
+    // trip `it` of this thread's walk -> the position it reads, or -1: the dealt positions (Deal), or -- a depth-cut frame,
+    // whatever the walk above would have been -- this workgroup's compacted records, kHistThreads at a time
+    int n_trips = deal.iters;
+    int64_t cut_i0 = 0, cut_i1 = 0;
+    if (cut) {
+        cut_i0 = (int64_t)wg * A.near_cap;
+        cut_i1 = cut_i0 + (int64_t)A.wg_far[kMaxG + wg];
+        n_trips = (int)((cut_i1 - cut_i0 + kHistThreads - 1) / kHistThreads);
     }
+    auto pos_of = [&](int it) __attribute__((always_inline)) -> int64_t {
+        if (it >= n_trips) return -1;
+        if (cut) {
+            const int64_t j = cut_i0 + (int64_t)it * kHistThreads + threadIdx.x;
+            return j < cut_i1 ? j : -1;
+        }
+        const int64_t j = deal.base(it) + (threadIdx.x & 63);
+        return j < n_pos ? j : -1;
+    };
     // (LEAN == 2: a 12-byte record, kept as its three words while it waits -- three registers a record in flight, not
     // six: at 2 x kAhead records the kernel must stay within the 64 registers that let two workgroups share a CU --
     // and unpacked into the 16-byte form when its turn comes)
@@ -1275,8 +1323,8 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
     if constexpr (LEAN != 0) {
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) {
-            const int64_t j = i0 + k * stride + threadIdx.x;
-            if (j < i1) load_rec(j, r_nx[k], m_nx[k]);
+            const int64_t j = pos_of(k);
+            if (j >= 0) load_rec(j, r_nx[k], m_nx[k]);
         }
     }
     MS_BIN_STAMP(2, 1);
@@ -1301,27 +1349,27 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
             const uint32_t slot = atomicAdd(&s_cur[t], 1u);
             if ((int64_t)slot < M) keys[slot] = key;
         };
-        for (int64_t base = i0; base < i1; base += kAhead * stride) {
+        for (int it0 = 0; it0 < n_trips; it0 += kAhead) {
 #pragma unroll
             for (int k = 0; k < kAhead; ++k) { r_q[k] = r_nx[k]; m_q[k] = m_nx[k]; }
-            if (base + kAhead * stride < i1) {   // (uniform)
+            if (it0 + kAhead < n_trips) {   // (uniform)
 #pragma unroll
                 for (int k = 0; k < kAhead; ++k) {
-                    const int64_t jn = base + (kAhead + k) * stride + threadIdx.x;
-                    if (jn < i1) load_rec(jn, r_nx[k], m_nx[k]);
+                    const int64_t jn = pos_of(it0 + kAhead + k);
+                    if (jn >= 0) load_rec(jn, r_nx[k], m_nx[k]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < kAhead; ++k) {
-                if (base + k * stride >= i1) break;   // (uniform)
+                if (it0 + k >= n_trips) break;   // (uniform)
                 LeanRec r = r_q[k];
                 unsigned long long mk = m_q[k];
-                const int64_t j = base + k * stride + threadIdx.x;
+                const int64_t j = pos_of(it0 + k);
                 int64_t gi = j;   // the Gaussian (the list id): the position, unless the record names it
                 unpack_rec(r, mk, gi);
                 int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0;
                 unsigned long long mask = ~0ull;
-                if (j < i1) {
+                if (j >= 0) {
                     n = (int)(r.n_edges & 0x0fffffffu);
                     edges = (int)(r.n_edges >> 28);
                     x0 = (int)(r.xy0 & 0xffffu); y0 = (int)(r.xy0 >> 16);
@@ -1370,7 +1418,7 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
             }
         }
     } else {
-        for_each_isect<PACK>(i0, i1, means2d, radii, masks, g, nullptr, nullptr, cand, G, [&](int t, int64_t i, int q) {
+        for_each_isect<PACK>(0, N, means2d, radii, masks, g, nullptr, nullptr, cand, G, [&](int t, int64_t i, int q) {
             const uint32_t slot = atomicAdd(&s_cur[t], 1u);
             const uint32_t low = PACK ? (((uint32_t)i << 4) | (uint32_t)q) : (uint32_t)i;
             const uint32_t dbits = __float_as_uint(depths[i]);

@@ -10,6 +10,7 @@ from mojosplat_amd import _fused
 from mojosplat_amd.distributed import render_gaussians_sharded
 from mojosplat_amd.scenes import randscene_v1, BACKGROUND_V1
 from bench import WORKLOADS
+from mojosplat_amd.scene_order import morton_permutation as morton_perm
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -21,7 +22,7 @@ if fp16:
 bg = torch.tensor(BACKGROUND_V1, device=dev).to(sc["features"].dtype)
 
 
-def morton_perm(p):
+def _unused_morton_perm(p):
     q = ((p - p.min(0).values) / (p.max(0).values - p.min(0).values + 1e-9) * 1023.0).long().clamp(0, 1023)
     def spread(v):
         v = (v | (v << 16)) & 0x030000FF
