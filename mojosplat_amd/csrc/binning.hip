@@ -329,22 +329,36 @@ __device__ __forceinline__ void walk_boxes_impl(int gi, int x0, int x1, int y0, 
             call((y0 + r - g.row_begin) * g.tw + x0 + c, i, q, payload);
         }
     }
+    // Round 5: the owner's registers come over by v_readlane (the owner is wave-uniform: a scalar out of the ballot) and a
+    // tile's row by a float reciprocal -- rounds 1-4 fetched them with eight ds_bpermute round trips (~100 cycles each, one
+    // after the other) and divided by w in integers (~40 instructions a tile).  It mattered once scenes came in a spatially
+    // coherent order: the 237 boxes of more than 32 tiles that config 3 holds sit next to the camera, a Morton curve puts
+    // up to 45 of them into ONE wave's 64 positions (12 in the given order), and that wave's ~1 100 cycles per box were
+    // the tail of the count kernel and of the scatter kernel (+5 us each; profiles/r05_morton_prof_cfg3.txt).
     unsigned long long bigmask = __ballot(big);
     while (bigmask) {
         const int src = __ffsll((long long)bigmask) - 1;
         bigmask &= bigmask - 1;
-        const int bx0 = __shfl(x0, src), bx1 = __shfl(x1, src);
-        const int by0 = __shfl(y0, src), by1 = __shfl(y1, src);
-        const unsigned long long bm = ((unsigned long long)(unsigned)__shfl((int)(mask >> 32), src) << 32) |
-                                      (unsigned)__shfl((int)(mask & 0xffffffffu), src);
-        const int be = PACK ? __shfl(edges, src) : 0;
-        const int64_t bi = __shfl(gi, src);
-        const uint32_t bp = PAYLOAD ? (uint32_t)__shfl((int)payload, src) : 0u;
+        const int bx0 = __builtin_amdgcn_readlane(x0, src), bx1 = __builtin_amdgcn_readlane(x1, src);
+        const int by0 = __builtin_amdgcn_readlane(y0, src), by1 = __builtin_amdgcn_readlane(y1, src);
+        const unsigned long long bm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mask >> 32), src) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)(mask & 0xffffffffu), src);
+        const int be = PACK ? __builtin_amdgcn_readlane(edges, src) : 0;
+        const int64_t bi = __builtin_amdgcn_readlane(gi, src);
+        const uint32_t bp = PAYLOAD ? (uint32_t)__builtin_amdgcn_readlane((int)payload, src) : 0u;
         const int w = bx1 - bx0, cnt = w * (by1 - by0);
-        for (int k = lane; k < cnt; k += 64) {
-            const int r = k / w, c = k % w;
-            if (cnt > 64 || ((bm >> k) & 1ull))
+        if (w <= 256 && cnt <= 65536) {   // (uniform) k / w by reciprocal: exact -- (k + 0.5) / w is >= 0.5 / w off any integer, the product's error < 1e-4
+            const float inv_w = __builtin_amdgcn_rcpf((float)w);
+            for (int k = lane; k < cnt; k += 64) {
+                const int r = (int)(((float)k + 0.5f) * inv_w), c = k - r * w;
+                if (cnt > 64 || ((bm >> k) & 1ull))
+                    call((by0 + r - g.row_begin) * g.tw + bx0 + c, bi, PACK ? edge_blocks(be, c, r, w, by1 - by0) : 0xf, bp);
+            }
+        } else {
+            for (int k = lane; k < cnt; k += 64) {
+                const int r = k / w, c = k % w;
                 call((by0 + r - g.row_begin) * g.tw + bx0 + c, bi, PACK ? edge_blocks(be, c, r, w, by1 - by0) : 0xf, bp);
+            }
         }
     }
 }
@@ -1223,8 +1237,12 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
 // LEAN: per-position LeanRecs (+ reach masks) instead of means2d / radii / depths.  DEFER: the launch carries the
 // scans' total pass (deferred_total; gridDim = G + 2), and the tile starts come from the workgroup's own prefix
 // over the tile counts instead of tile_ranges.
+#ifndef MS_SCATTER_WAVES
+#define MS_SCATTER_WAVES 8   // (round 5: 64 registers for the 12-byte-record variants, two workgroups a CU -- the kernel had grown
+                             // to 72 and ran its grid in two rounds; the 16-byte-record variants would spill 40-90 registers: left alone)
+#endif
 template <bool PACK, int LEAN, bool DEFER>
-__global__ __launch_bounds__(kHistThreads) void k_isect_scatter(
+__global__ __launch_bounds__(kHistThreads, (LEAN == 2 ? MS_SCATTER_WAVES : 4)) void k_isect_scatter(
     int64_t N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
     const LeanRec *__restrict__ lean, Grid g, int64_t chunk, const uint32_t *__restrict__ hist,

@@ -35,6 +35,10 @@ def main():
     L.ms_diag_set_bin_stamps.argtypes = [ctypes.c_void_p]
     sc, cam = randscene_v1(N, W, H, ell=ell, device=dev)
     bg = torch.tensor(BACKGROUND_V1, device=dev)
+    if os.environ.get("SCENE_ORDER") == "morton":   # (round 5: the same scene sorted along a Morton curve of its means)
+        from mojosplat_amd.scene_order import morton_permutation
+        perm = morton_permutation(sc["means3d"])
+        sc = {k: v[perm].contiguous() for k, v in sc.items()}
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
     # python scripts/bin_phases.py cfg3 8 3: rank 3's band of the frame cut 8 ways (the sharded entry point, rehearsed)
     if len(sys.argv) > 3:
