@@ -282,9 +282,24 @@ __device__ __forceinline__ unsigned long long clip_cells(unsigned long long m, i
 // Must be reached by all lanes of the wave (ballot / shuffles inside).
 // `payload`: a word of the box's OWNER that f receives as a fourth argument (the lean scatter's depth bits: a
 // big box is walked by the whole wave, whose other lanes know the owner's index but not its registers).
+// Boxes of more than kCoopThreshold tiles, queued per WORKGROUP (round 5).  Such a box is walked by a whole wave, a round
+// of 64 tiles at a time, each round an LDS round trip.  A scene in random order gives every wave one or two of them; a
+// spatially coherent order puts the boxes next to the camera into a handful of waves -- Morton-sorted config 3: one slice
+// of 64 positions holds 11 boxes of up to 756 tiles, 45 rounds, and its wave ran 12 us behind the other fifteen of its
+// workgroup in the count kernel and again in the scatter kernel (per-workgroup stamps: profiles/r05_bin_phases_morton.txt).
+// With a queue the owner only leaves a 32-byte entry in LDS; after the workgroup's walk its sixteen waves drain the queue
+// round-robin.  Entries that find the queue full (a scene of nothing but huge footprints: every wave is equally loaded
+// then) are walked on the spot, as before.
+struct BigQ {
+    uint32_t *ent;      // LDS: cap entries of 8 words: x0 | y0 << 16, x1 | y1 << 16, index, payload, mask lo, mask hi, edges, -
+    unsigned int *count;
+    unsigned int cap;   // 0: no queue
+};
+
 template <bool PACK, bool PAYLOAD, class F>
 __device__ __forceinline__ void walk_boxes_impl(int gi, int x0, int x1, int y0, int y1, int n, int edges,
-                                                const Grid &g, unsigned long long mask, F &&f, uint32_t payload) {
+                                                const Grid &g, unsigned long long mask, F &&f, uint32_t payload,
+                                                const BigQ *Q = nullptr) {
     auto call = [&](int t, int64_t i, int q, uint32_t pl) __attribute__((always_inline)) {
         if constexpr (PAYLOAD) f(t, i, q, pl);
         else f(t, i, q);
@@ -335,7 +350,18 @@ __device__ __forceinline__ void walk_boxes_impl(int gi, int x0, int x1, int y0, 
     // coherent order: the 237 boxes of more than 32 tiles that config 3 holds sit next to the camera, a Morton curve puts
     // up to 45 of them into ONE wave's 64 positions (12 in the given order), and that wave's ~1 100 cycles per box were
     // the tail of the count kernel and of the scatter kernel (+5 us each; profiles/r05_morton_prof_cfg3.txt).
-    unsigned long long bigmask = __ballot(big);
+    bool queued = false;
+    if (Q && Q->cap && big) {
+        const unsigned int slot = atomicAdd(Q->count, 1u);
+        if (slot < Q->cap) {
+            uint32_t *e = Q->ent + 8u * slot;
+            e[0] = (uint32_t)x0 | ((uint32_t)y0 << 16); e[1] = (uint32_t)x1 | ((uint32_t)y1 << 16);
+            e[2] = (uint32_t)gi; e[3] = payload;
+            e[4] = (uint32_t)mask; e[5] = (uint32_t)(mask >> 32); e[6] = (uint32_t)edges;
+            queued = true;
+        }
+    }
+    unsigned long long bigmask = __ballot(big && !queued);
     while (bigmask) {
         const int src = __ffsll((long long)bigmask) - 1;
         bigmask &= bigmask - 1;
@@ -365,13 +391,44 @@ __device__ __forceinline__ void walk_boxes_impl(int gi, int x0, int x1, int y0, 
 
 template <bool PACK, class F>
 __device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y1, int n, int edges,
-                                           const Grid &g, unsigned long long mask, F &&f) {
-    walk_boxes_impl<PACK, false>(gi, x0, x1, y0, y1, n, edges, g, mask, f, 0u);
+                                           const Grid &g, unsigned long long mask, F &&f, const BigQ *Q = nullptr) {
+    walk_boxes_impl<PACK, false>(gi, x0, x1, y0, y1, n, edges, g, mask, f, 0u, Q);
 }
 template <bool PACK, class F>
 __device__ __forceinline__ void walk_boxes(int gi, int x0, int x1, int y0, int y1, int n, int edges,
-                                           const Grid &g, unsigned long long mask, F &&f, uint32_t payload) {
-    walk_boxes_impl<PACK, true>(gi, x0, x1, y0, y1, n, edges, g, mask, f, payload);
+                                           const Grid &g, unsigned long long mask, F &&f, uint32_t payload, const BigQ *Q = nullptr) {
+    walk_boxes_impl<PACK, true>(gi, x0, x1, y0, y1, n, edges, g, mask, f, payload, Q);
+}
+
+// The queued boxes of a workgroup, its waves taking them round-robin: f(tile, index, blocks[, payload]) for every tile of
+// every box, as walk_boxes would have called it.  ALL threads of the workgroup (a barrier inside).
+template <bool PACK, bool PAYLOAD, class F>
+__device__ __forceinline__ void drain_big_boxes(const BigQ &Q, const Grid &g, F &&f) {
+    if (!Q.cap) return;   // (uniform)
+    __syncthreads();      // every push is in
+    const unsigned int total = min(*Q.count, Q.cap);
+    const int lane = threadIdx.x & 63;
+    const unsigned int nw = blockDim.x >> 6;
+    for (unsigned int e = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); e < total; e += nw) {
+        const uint32_t *q = Q.ent + 8u * e;   // (one address for the wave: an LDS broadcast)
+        const int bx0 = (int)(q[0] & 0xffffu), by0 = (int)(q[0] >> 16), bx1 = (int)(q[1] & 0xffffu), by1 = (int)(q[1] >> 16);
+        const int64_t bi = (int64_t)(int32_t)q[2];
+        const uint32_t bp = q[3];
+        const unsigned long long bm = (unsigned long long)q[4] | ((unsigned long long)q[5] << 32);
+        const int be = (int)q[6];
+        const int w = bx1 - bx0, cnt = w * (by1 - by0);
+        const float inv_w = __builtin_amdgcn_rcpf((float)max(w, 1));
+        const bool by_rcp = w <= 256 && cnt <= 65536;   // (see walk_boxes_impl)
+        for (int k = lane; k < cnt; k += 64) {
+            const int r = by_rcp ? (int)(((float)k + 0.5f) * inv_w) : k / w, c = k - r * w;
+            if (cnt > 64 || ((bm >> k) & 1ull)) {
+                const int t = (by0 + r - g.row_begin) * g.tw + bx0 + c;
+                const int qb = PACK ? edge_blocks(be, c, r, w, by1 - by0) : 0xf;
+                if constexpr (PAYLOAD) f(t, bi, qb, bp);
+                else f(t, bi, qb);
+            }
+        }
+    }
 }
 
 // Walk every (Gaussian, tile) pair of one chunk; F(local_tile, gaussian_index).
@@ -559,10 +616,13 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
     LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth, const uint32_t *__restrict__ tau,
     uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp, LeanRec *__restrict__ near_recs,
-    int keep_arrays, int64_t near_cap) {
-    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes]
+    int keep_arrays, int64_t near_cap, unsigned int big_q_off, unsigned int big_q_cap) {
+    extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes] [+ the queue of big boxes]
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
+    __shared__ unsigned int s_big_n;
+    if (threadIdx.x == 0) s_big_n = 0;   // (published by the barrier below)
+    const BigQ bigq{reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_cnt) + big_q_off), &s_big_n, big_q_cap};
     MS_BIN_STAMP(0, 0);
     // DEPTH CUT (tau != null; LEAN == 2 only): a pair whose depth bits exceed its tile's cut-off -- where the PREVIOUS
     // frame's sorted front of that tile ended, with a margin -- is FAR: it is not counted into the tile's list, the tile
@@ -597,6 +657,13 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     }
     const Deal deal(i1, wg, (int)gridDim.x);
     const uint32_t lane_u = threadIdx.x & 63u;
+    // what a (box, tile) pair does to the histogram: plainly, and on a depth-cut frame (a pair behind its tile's cut-off is
+    // counted as far, its tile marked) -- for the boxes a wave walks on the spot and for those the workgroup queues
+    auto count_plain = [&](int t, int64_t, int) __attribute__((always_inline)) { atomicAdd(&s_cnt[t], 1u); };
+    auto count_cut = [&](int t, int64_t, int, uint32_t db) __attribute__((always_inline)) {
+        if (db <= s_tau[t]) { atomicAdd(&s_cnt[t], 1u); dmin = min(dmin, db); dmax = max(dmax, db); }
+        else { ++far_pairs; s_farflag[t] = 1; }
+    };
     for (int it = 0; it < deal.iters; ++it) {
         const int64_t base = deal.base(it);   // (wave-uniform: this wave's slice of 64 positions)
         const int64_t j = base + lane_u;
@@ -724,10 +791,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 if (near32) { dmin = min(dmin, dbits_of_step); dmax = max(dmax, dbits_of_step); }
             }
             // larger boxes: the whole wave (db is the OWNER's depth there); the scatter kernel applies the cut-offs itself
-            walk_boxes<PACK>(gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask, [&](int t, int64_t, int, uint32_t db) {
-                if (db <= s_tau[t]) { atomicAdd(&s_cnt[t], 1u); dmin = min(dmin, db); dmax = max(dmax, db); }
-                else { ++far_pairs; s_farflag[t] = 1; }
-            }, dbits_of_step);
+            walk_boxes<PACK>(gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask, count_cut, dbits_of_step, &bigq);
             // (boxes the whole wave walked: kept whatever the cut-offs say -- their owner does not know)
             const bool keep = near32 != 0u || n > kCoopThreshold;
             if (rec_pending && keep) write_record(rec_b0, rec_src, rec_m0, rec_m1, rec_c0, rec_c1, rec_c2);
@@ -744,9 +808,12 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 }
             }
         } else {
-            walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, [&](int t, int64_t, int) { atomicAdd(&s_cnt[t], 1u); });
+            walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, count_plain, &bigq);
         }
     }
+    // (the boxes of more than kCoopThreshold tiles that the waves queued: all sixteen waves take them in turn)
+    if constexpr (CUT) drain_big_boxes<PACK, true>(bigq, g, count_cut);
+    else drain_big_boxes<PACK, false>(bigq, g, count_plain);
     if constexpr (CUT) {
         {   // this workgroup's far pairs (the frame's size record counts them: the buffer keeps room for them)
 #pragma unroll
@@ -1247,10 +1314,13 @@ __global__ __launch_bounds__(kHistThreads, (LEAN == 2 ? MS_SCATTER_WAVES : 4)) v
     const float *__restrict__ depths, const unsigned long long *__restrict__ masks,
     const LeanRec *__restrict__ lean, Grid g, int64_t chunk, const uint32_t *__restrict__ hist,
     const int32_t *__restrict__ tile_ranges, int64_t M, uint64_t *__restrict__ keys,
-    uint32_t *__restrict__ wg_depth, Candidates cand, int G, ScanTotalArgs A) {
+    uint32_t *__restrict__ wg_depth, Candidates cand, int G, ScanTotalArgs A, unsigned int big_q_off, unsigned int big_q_cap) {
     extern __shared__ uint32_t s_cur[];
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     const int band0 = g.row_begin * g.tw;
+    __shared__ unsigned int s_big_n;
+    if (threadIdx.x == 0) s_big_n = 0;   // (published by the barriers of the cursors' set-up)
+    const BigQ bigq{reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_cur) + big_q_off), &s_big_n, big_q_cap};
     MS_BIN_STAMP(2, 0);
     if constexpr (DEFER) {
         if ((int)blockIdx.x >= G) {   // (uniform per workgroup)
@@ -1367,6 +1437,7 @@ __global__ __launch_bounds__(kHistThreads, (LEAN == 2 ? MS_SCATTER_WAVES : 4)) v
             const uint32_t slot = atomicAdd(&s_cur[t], 1u);
             if ((int64_t)slot < M) keys[slot] = key;
         };
+        auto emit_cut = [&](int t, int64_t i, int q, uint32_t db) __attribute__((always_inline)) { if (db <= s_tau[t]) emit(t, i, q, db); };
         for (int it0 = 0; it0 < n_trips; it0 += kAhead) {
 #pragma unroll
             for (int k = 0; k < kAhead; ++k) { r_q[k] = r_nx[k]; m_q[k] = m_nx[k]; }
@@ -1426,15 +1497,17 @@ __global__ __launch_bounds__(kHistThreads, (LEAN == 2 ? MS_SCATTER_WAVES : 4)) v
                     }
                     // larger boxes: the whole wave (a depth-cut frame holds them against the cut-offs here)
                     if (cut)
-                        walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask,
-                                         [&](int t, int64_t i, int q, uint32_t db) { if (db <= s_tau[t]) emit(t, i, q, db); }, dbits);
+                        walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask, emit_cut, dbits, &bigq);
                     else
-                        walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask, emit, dbits);
+                        walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n > kCoopThreshold ? n : 0, edges, g, mask, emit, dbits, &bigq);
                 } else {
-                    walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n, edges, g, mask, emit, dbits);
+                    walk_boxes<PACK>((int)gi, x0, x1, y0, y1, n, edges, g, mask, emit, dbits, &bigq);
                 }
             }
         }
+        // (the boxes of more than kCoopThreshold tiles that the waves queued: all sixteen waves take them in turn)
+        if (cut) drain_big_boxes<PACK, true>(bigq, g, emit_cut);
+        else drain_big_boxes<PACK, true>(bigq, g, emit);
     } else {
         for_each_isect<PACK>(0, N, means2d, radii, masks, g, nullptr, nullptr, cand, G, [&](int t, int64_t i, int q) {
             const uint32_t slot = atomicAdd(&s_cur[t], 1u);
@@ -1824,6 +1897,14 @@ int check_grid(int tile_size, int tw, int th, int row_begin, int row_end) {
     MS_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= th, MS_ERR_INVALID_ARG,
                "isect: bad row band [%d,%d) of %d", row_begin, row_end, th);
     return MS_OK;
+}
+
+// entries of a workgroup's queue of big boxes (BigQ) behind `used` bytes of dynamic LDS: up to 256 (8 KB), fewer where the
+// counters of a large grid leave less room, none on grids whose tile coordinates do not fit 16 bits
+unsigned int big_queue_cap(size_t used, int tile_w, int tile_h) {
+    if (tile_w > 0xffff || tile_h > 0xffff || used >= kMaxLds) return 0u;
+    const size_t room = (kMaxLds - used) / 32;
+    return (unsigned int)(room < 256 ? room : 256);
 }
 
 // raise a kernel's dynamic-LDS ceiling to the full 160 KB: once per (device, kernel) -- the attribute
@@ -2334,8 +2415,13 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
         const bool cut = cut_stamp != 0u;   // (bit 9 of `tight`: which of the two cut-off buffers to read)
         MS_REQUIRE(!cut || (lean12 && (tight & kDeferTotal)), MS_ERR_INVALID_ARG,
                    "project_isect_count: a depth-cut frame must be a lean sync-free frame on plain bins");
-        const size_t lds = p.lds_bytes + (cut ? (size_t)p.T_local * 5 + 16 : 0);
+        size_t lds = p.lds_bytes + (cut ? (size_t)p.T_local * 5 + 16 : 0);
         MS_REQUIRE(lds <= kMaxLds, MS_ERR_TOO_LARGE, "project_isect_count: %d tiles with cut-offs need %zu B of LDS", p.T_local, lds);
+        // the workgroup's queue of big boxes behind everything else, as far as the LDS has room (BigQ: 32-byte entries with
+        // 16-bit tile coordinates)
+        const unsigned int big_q_off = (unsigned int)ms::align_up(lds, 16);
+        const unsigned int big_q_cap = big_queue_cap(big_q_off, tile_w, tile_h);
+        lds = (size_t)big_q_off + (size_t)big_q_cap * 32;
         if (lds > 48 * 1024)
             if (int rc = allow_big_lds(kernel)) return rc;
         hipLaunchKernelGGL(kernel, dim3(p.G), dim3(kHistThreads), lds, stream, N, means3d, scales,
@@ -2343,7 +2429,8 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                            colors3, color_dtype == MS_COLOR_F16 ? 1 : 0, (float4 *)raster_records, cand,
                            (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg),
                            cut ? (const uint32_t *)(ws + p.off_tau) + (size_t)((tight >> 9) & 1) * p.T : nullptr, (uint32_t *)(ws + p.off_wg_far),
-                           (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near), (tight & ms::kTightKeepArrays) ? 1 : 0, p.near_cap);
+                           (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near), (tight & ms::kTightKeepArrays) ? 1 : 0, p.near_cap,
+                           big_q_off, big_q_cap);
         MS_LAUNCH_CHECK();
     }
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
@@ -2403,7 +2490,10 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                 A.near_cap = p.near_cap;
             }
         }
-        const size_t scatter_lds = p.lds_bytes + (A.cut_stamp ? (size_t)p.T_local * 4 + 16 : 0);
+        size_t scatter_lds = p.lds_bytes + (A.cut_stamp ? (size_t)p.T_local * 4 + 16 : 0);
+        const unsigned int big_q_off = (unsigned int)ms::align_up(scatter_lds, 16);
+        const unsigned int big_q_cap = (lean ? big_queue_cap(big_q_off, tile_w, tile_h) : 0u);   // (the record walks queue; the array walk does not)
+        scatter_lds = (size_t)big_q_off + (size_t)big_q_cap * 32;
         auto pick = [&](auto packc, auto leanc) {
             constexpr bool PK = decltype(packc)::value;
             constexpr int LN = decltype(leanc)::value;
@@ -2419,7 +2509,7 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
                            // (a lean frame's count kernel has left the per-workgroup depth ranges already)
                            lazy && !lean ? (uint32_t *)(ws + p.off_depth_wg) : nullptr,
                            (tight & kBandCull) ? Candidates{(const int32_t *)(ws + p.off_cand), (const int32_t *)(ws + p.off_cand_count), p.G, p.chunk}
-                                               : Candidates{nullptr, nullptr, 0, 0}, p.G, A);
+                                               : Candidates{nullptr, nullptr, 0, 0}, p.G, A, big_q_off, big_q_cap);
         MS_LAUNCH_CHECK();
         // the size record is complete once the scatter launch is: the caller's hand-off event goes here
         if (deferred && defer->sync_event) MS_HIP(hipEventRecord((hipEvent_t)defer->sync_event, stream));
