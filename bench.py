@@ -384,6 +384,7 @@ def main():
     if world == 1 and not args.no_extras:
         legs["orbit"] = orbit_leg(ms, _fused, render_mod, g, cam, bg, stagewise, ms_mean)
         legs["two_frames_in_flight"] = two_in_flight_leg(ms, g, cam, bg, img, args.steps)
+        legs["morton_order"] = morton_leg(ms, _fused, g, cam, bg, img, ms_per_step)
         if not fp16:
             legs["cfg3_fwd_bwd" if args.workload == "cfg3" else args.workload + "_fwd_bwd"] = \
                 fwd_bwd_leg(_fused, render_mod, g, cam, bg, N, W, H, T, dev, m_gsplat=M)
@@ -570,6 +571,33 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(rc)
+
+
+def morton_leg(ms, _fused, g, cam, bg, ref_img, given_ms, frames=200):
+    """The same scene with its Gaussians sorted along a Morton curve of their means (a caller-side permutation of the five
+    arrays: scene_order.morton_permutation) through the same blocking call.  The order does not change a pixel; since
+    round 5 it must not cost a frame anything either (the count / scatter kernels deal their positions over the
+    workgroups and queue the large boxes per workgroup: csrc/binning.hip, Deal / BigQ) -- round 4 measured +5 % here and
+    +16 % at config 5."""
+    import torch
+    from mojosplat_amd.scene_order import morton_permutation
+    perm = morton_permutation(g[0])
+    gm = tuple(t[perm].contiguous() for t in g)
+    _fused._state.clear()
+    for _ in range(64):
+        img = ms.render_gaussians(*gm, cam, background_color=bg, backend="hip")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        img = ms.render_gaussians(*gm, cam, background_color=bg, backend="hip")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames * 1e3
+    _fused._state.clear()
+    # (a permutation reorders equal-depth ties and the float sums' order nowhere: lists are sorted by (depth bits, index) --
+    # the INDEX differs, so two Gaussians at bit-equal depth may swap; compared to rounding, not bit for bit)
+    d = float((img - ref_img).abs().max())
+    return {"frames": frames, "ms_per_frame": round(dt, 4), "frames_per_s": round(1e3 / dt, 1),
+            "vs_given_order": round(dt / given_ms, 4), "max_abs_vs_given_order_frame": d, "same_frame": d <= 1e-5}
 
 
 def two_in_flight_leg(ms, g, cam, bg, ref_img, steps):

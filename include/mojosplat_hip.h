@@ -413,6 +413,70 @@ int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *sca
                         const ms_view_lane *lanes, int flags, float *render_colors, int64_t *counts,
                         int *views_done, size_t *need_isect_bytes, int *need_lane);
 
+/* ---------------------------------------------------------------------------------------
+ * A multi-GPU rank's BAND of a frame, in two calls (round 5).  No reference counterpart: the reference has no distributed
+ * path (mojosplat/binning.py:83 is a dead comment); what a band bins is what mojosplat/binning.py:73-84 bins, restricted
+ * to the band's tile rows.
+ *
+ * ms_scene: the Gaussians as ms_render_fwd takes them one by one, built ONCE per scene by the caller -- plus, for a
+ * PREPARED scene, the bounds of every block of block_size consecutive Gaussians (ms_scene_prepare): when the Gaussians are
+ * stored in a spatially coherent order (the caller sorts them once, e.g. along a Morton curve of the means) those boxes
+ * are small, the band pre-cull skips every block that cannot reach the band without reading it, and the count kernel's
+ * gathers through the band's candidate list coalesce.  block_bounds == NULL: any order, no bounds (as ms_render_fwd).
+ * The bounds must describe the arrays AS THEY ARE: recompute them after the means or scales change.
+ *   block_bounds f32[n_blocks][8] = {min x, min y, min z of the block's means, its largest LINEAR scale, max x, max y, max z, 0}
+ *
+ * ms_band_lane: one scratch set (as ms_render_fwd wants it: workspace, isect_buf, pinned host_info i64[8], sync_event) with the
+ * hipStream_t the band runs on and two hipEvent_t for the ordering around it; built once per lane, isect_buf / isect_bytes
+ * updated when the buffer grows.  One frame at a time per lane; frames on different lanes overlap.
+ *
+ * ms_render_band_begin : caller_stream -> lane (in_event), then the whole band enqueued on lane->stream (MS_RENDER_BEGIN:
+ *                        speculatively, no host wait).
+ * ms_render_band_finish: waits for the band's size record, checks it, redoes the band on the exact path if the speculation
+ *                        did not hold (MS_ERR_WORKSPACE as ms_render_fwd: grow isect_buf to lane->host_info[5] bytes and call
+ *                        again with resume = 1), then lane -> caller_stream (out_event); status i64[4] (HOST) = {Gaussians on
+ *                        the grid -- of a pre-culled band: of its candidates --, 1 if the library pre-culled the band, pairs
+ *                        in the band, the frame's flag word (host_info[7])}.
+ * flags: MS_RENDER_ROWS16 / MS_RENDER_FULL_SORT / MS_RENDER_FRONT_LEVEL bits, as ms_render_fwd's `resume`.
+ * render_colors addresses image row 0 (rows outside the band are never touched), as for ms_render_fwd.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ms_scene {
+    int64_t N;
+    const float *means3d, *scales;
+    int scales_are_log;
+    const float *quats, *opacities;
+    const void *colors;
+    int color_dtype, CDIM;
+    const float *block_bounds;   /* NULL: not a prepared scene */
+    int block_size;              /* Gaussians per block: a power of two >= 64 */
+    int64_t n_blocks;
+} ms_scene;
+typedef struct ms_band_lane {
+    void *workspace;
+    size_t workspace_bytes;
+    void *isect_buf;
+    size_t isect_bytes;
+    int64_t *host_info;
+    void *sync_event, *stream, *in_event, *out_event;
+} ms_band_lane;
+typedef struct ms_band_frame {
+    const ms_scene *scene;
+    const float *viewmat;        /* DEVICE f32[16] */
+    float fx, fy, cx, cy;
+    int W, H;
+    float eps2d, near_plane, far_plane;
+    int tile_size, row_begin, row_end, flags;
+    const float *backgrounds;
+    float *render_colors;
+    void **stage_events;         /* NULL, or 4 hipEvent_t as ms_render_fwd's (in-situ kernel timing) */
+} ms_band_frame;
+size_t ms_scene_block_bounds_bytes(int64_t N, int block_size);
+int ms_scene_prepare(int64_t N, const float *means3d, const float *scales, int scales_are_log, int block_size,
+                     float *block_bounds, void *stream);
+int ms_render_band_begin(const ms_band_frame *frame, const ms_band_lane *lane, void *caller_stream);
+int ms_render_band_finish(const ms_band_frame *frame, const ms_band_lane *lane, void *caller_stream, int resume,
+                          int64_t *status);
+
 /* Where ms_render_fwd keeps its intermediates inside `workspace` (byte offsets), for callers that
  * go on to differentiate the frame: offsets[0..4] = means2d f32[N,2], conics f32[N,3],
  * depths f32[N], radii i32[N,2], tile_ranges i32[tile_h,tile_w,2]; offsets[5] = total bytes.

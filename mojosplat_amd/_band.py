@@ -1,0 +1,193 @@
+"""A multi-GPU rank's band frame through the library's two-call pair (ms_render_band_begin / ms_render_band_finish,
+include/mojosplat_hip.h) -- the host side of distributed.py's HIP path since round 5.
+
+Round 4's asynchronous band frame cost ~100-130 us of host time (Python marshalling of five tensors and a camera per frame,
+four event operations, record_stream on every tensor that crosses to the lane, a frame object, the plan's bookkeeping) around
+18-45 us of library enqueue -- level with the GPU time of a config-5 band at 8 ranks.  Here everything that does not change
+from frame to frame is built ONCE and cached:
+
+  * the scene (ms_scene: five device pointers, sizes, a prepared scene's block bounds) per set of tensors, keyed by their
+    data pointers and version counters -- the tensors themselves are kept alive by the entry, so the caching allocator
+    cannot recycle them under a lane's kernels and nothing needs record_stream;
+  * the lane (ms_band_lane: scratch, pinned size record, stream, the two events that order the lane against the caller's
+    stream) per (device, lane) -- the same scratch sets _fused.py's other lane users take;
+  * the frame struct per lane, mutated in place (a lane runs one frame at a time).
+
+A frame is then two ctypes calls; the caller -> lane -> caller stream ordering happens inside them (the output buffer is
+allocated on the caller's stream, first touched on the lane after the lane has waited for the caller, and handed back
+only after the caller's stream has waited for the lane: no record_stream for it either).
+
+The reference has no counterpart (no distributed code: mojosplat/binning.py:83 is a dead comment).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _fused, _hip
+from .projection import EPS2D
+
+_scenes = {}    # key -> (Scene struct, tensors kept alive)
+_SCENE_CAP = 16
+
+
+def scene_struct(means3d, scales, quats, opacities, colors):
+    """-> (ms_scene ctypes struct, N, channels) for these tensors as they are now (cached)."""
+    key = (means3d.data_ptr(), means3d._version, scales.data_ptr(), scales._version, quats.data_ptr(), quats._version,
+           opacities.data_ptr(), opacities._version, colors.data_ptr(), colors._version, colors.dtype)
+    hit = _scenes.get(key)
+    if hit is not None:
+        return hit[0]
+    from .scene_order import prepared_bounds
+    N = means3d.shape[0]
+    m, sc, q = _hip.f32c(means3d), _hip.f32c(scales), _hip.f32c(quats)
+    op = _hip.f32c(opacities.reshape(-1))
+    if colors.dtype == torch.float16:
+        cdt, col = 1, colors.contiguous()
+    else:
+        cdt, col = 0, _hip.f32c(colors)
+    C = col.shape[1]
+    assert m.shape == (N, 3) and sc.shape == (N, 3) and q.shape == (N, 4) and op.shape == (N,) and col.shape == (N, C)
+    pb = prepared_bounds(means3d, scales) if (m is means3d and sc is scales) else None
+    S = _hip.Scene(N, m.data_ptr() if N else None, sc.data_ptr() if N else None, 1, q.data_ptr() if N else None,
+                   op.data_ptr() if N else None, col.data_ptr() if N else None, cdt, C,
+                   pb[0].data_ptr() if pb else None, pb[1] if pb else 0, pb[0].shape[0] if pb else 0)
+    if len(_scenes) >= _SCENE_CAP:
+        _scenes.pop(next(iter(_scenes)))
+    # (the originals too: a marshalled copy's source must not change under the key's version check unnoticed)
+    _scenes[key] = (S, (means3d, scales, quats, opacities, colors, m, sc, q, op, col, pb[0] if pb else None))
+    return S
+
+
+class _LaneRec:
+    """The cached ms_band_lane / ms_band_frame pair of one (device, lane slot)."""
+
+    def __init__(self, dev, slot):
+        self.dev, self.slot = dev, slot
+        self.st = _fused._dev_state(dev, slot)
+        self.ev_in, self.ev_out = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.device(dev):
+            self.ev_in.record()
+            self.ev_out.record()    # (materialises the hipEvent_t handles)
+        st = self.st
+        self.lane = _hip.BandLane(None, 0, None, 0, st["host"].data_ptr(), st["ev"].cuda_event, None, self.ev_in.cuda_event,
+                                  self.ev_out.cuda_event)
+        self.frame = _hip.BandFrame()
+        self.status = (ctypes.c_int64 * 4)()
+        self.ws_id = self.isect_id = None
+
+
+_lane_recs = {}
+
+
+def _lane_rec(dev, slot):
+    # (lane slot 0 is per host thread in _fused -- its record lives with that thread's state)
+    st = _fused._dev_state(dev, slot)
+    rec = st.get("band_rec")
+    if rec is None:
+        rec = st["band_rec"] = _LaneRec(dev, slot)
+    return rec
+
+
+class BandHandle:
+    __slots__ = ("rec", "shape", "level", "mode", "keep", "channels", "done")
+
+
+def band_begin(means3d, scales, quats, opacities, colors, camera, bg, tile_size, band, out, out_y0, rows16, slot, lane_stream,
+               caller_stream, stage_events=None):
+    """Enqueue rows `band` of the frame on lane `slot` (its stream: the raw handle `lane_stream`; None = the caller's own
+    stream, the blocking path).  `out`: the framebuffer (image row 0 at its start) or, with out_y0, a slab whose first row
+    is image row out_y0.  -> a BandHandle for band_finish."""
+    L = _hip.lib()
+    dev = means3d.device
+    S = scene_struct(means3d, scales, quats, opacities, colors)
+    N, C = S.N, S.CDIM
+    H, W = camera.H, camera.W
+    th, tw = -(-H // tile_size), -(-W // tile_size)
+    rec = _lane_rec(dev, slot)
+    st = rec.st
+    assert not st.get("busy"), "a begun frame still occupies this lane: finish it first"
+    ws = _fused._grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
+    lane = rec.lane
+    if rec.ws_id != ws.data_ptr():
+        lane.workspace, lane.workspace_bytes = ws.data_ptr(), ws.numel()
+        rec.ws_id = ws.data_ptr()
+    isect = st["isect"]
+    iid = None if isect is None else isect.data_ptr()
+    if rec.isect_id != iid:
+        lane.isect_buf, lane.isect_bytes = iid, 0 if isect is None else isect.numel()
+        rec.isect_id = iid
+    lane.sync_event = st["ev"].cuda_event if st.get("speculate", True) else None
+    lane.stream = caller_stream if lane_stream is None else lane_stream
+    r0, r1 = band
+    flags = _fused.ROWS16 if (rows16 and tile_size != 16) else 0
+    shape = (round(math.log2(N) * 8) if N > 0 else -1, tw, th, r0, r1)
+    level = int(st.get("front_level", 0))
+    mode = (_fused.FULL_SORT if st.get("full_sort") else _fused.FRONT_LEVEL * level) | flags
+    vm = camera._viewmat_f32()
+    if vm.device != dev:
+        vm = vm.to(dev)
+    bgc = None if bg is None else _hip.f32c(bg.reshape(-1))
+    f = rec.frame
+    f.scene = ctypes.pointer(S)
+    f.viewmat = vm.data_ptr()
+    f.fx, f.fy, f.cx, f.cy = camera.fx, camera.fy, camera.cx, camera.cy
+    f.W, f.H = W, H
+    f.eps2d, f.near_plane, f.far_plane = EPS2D, camera.near, camera.far
+    f.tile_size, f.row_begin, f.row_end, f.flags = tile_size, r0, r1, mode
+    f.backgrounds = None if bgc is None else bgc.data_ptr()
+    if out_y0 is not None:
+        px = tile_size if not flags else 16
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[1:]) == (W, C)
+        assert out.shape[0] >= min(r1 * px, H) - min(r0 * px, H) and out_y0 == min(r0 * px, H)
+        f.render_colors = out.data_ptr() - out_y0 * W * C * 4
+    else:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= H and tuple(out.shape[1:]) == (W, C)
+        f.render_colors = out.data_ptr()
+    evs = None
+    if stage_events is not None:   # (bench.py's in-situ timing: 4 recorded-once torch events, entries may be None)
+        evs = (ctypes.c_void_p * 4)(*[None if e is None else ctypes.c_void_p(e.cuda_event) for e in stage_events])
+    f.stage_events = None if evs is None else ctypes.cast(evs, ctypes.c_void_p)
+    with _hip.on_device(dev):
+        _hip.check(L.ms_render_band_begin(ctypes.byref(f), ctypes.byref(lane), caller_stream), "ms_render_band_begin")
+    st["busy"] = True
+    h = BandHandle()
+    h.rec, h.shape, h.level, h.mode, h.channels, h.done = rec, shape, level, mode, C, False
+    h.keep = (S, vm, bgc, out, evs)   # alive until the frame is finished
+    return h
+
+
+class _StatsFrame:   # (what _fused._count_frame wants to know of a frame)
+    own = False
+
+    def __init__(self, st):
+        self.st = st
+
+
+def band_finish(h, caller_stream):
+    """Wait for the band's size record, redo the band exactly if its speculation did not hold, order the caller's stream
+    behind the lane.  -> (Gaussians on the grid, pre-culled by the library, pairs in the band, the frame's flag word)."""
+    L = _hip.lib()
+    rec = h.rec
+    st, lane, f = rec.st, rec.lane, rec.frame
+    host = st["host_np"]
+    grew = False
+    try:
+        with _hip.on_device(rec.dev):
+            rc = L.ms_render_band_finish(ctypes.byref(f), ctypes.byref(lane), caller_stream, 0, rec.status)
+            if rc == 2:   # MS_ERR_WORKSPACE: the intersection buffer is too small for this band's pairs
+                need = int(host[5])
+                grew = need > 0
+                if need > 0 and (st["isect"] is None or st["isect"].numel() < need):
+                    isect = _fused._grow(st, "isect", need, rec.dev, slack=1.25)
+                    lane.isect_buf, lane.isect_bytes = isect.data_ptr(), isect.numel()
+                    rec.isect_id = isect.data_ptr()
+                    rc = L.ms_render_band_finish(ctypes.byref(f), ctypes.byref(lane), caller_stream, 1, rec.status)
+            _hip.check(rc, "ms_render_band_finish")
+    finally:
+        st["busy"] = False
+        h.done = True
+    _fused._after_frame(st, host, rc, grew, shape=h.shape, level=h.level, mode=h.mode, own=False, channels=h.channels,
+                        frame=_StatsFrame(st))
+    s = rec.status
+    return int(s[0]), bool(s[1]), int(s[2]), int(s[3])

@@ -230,6 +230,78 @@ def own_report(st, dev, shape, mode, level, heavy, ws, grid):
                              heavy=heavy)
 
 
+def _after_frame(st, host, rc, grew, *, shape, level, mode, own, channels, frame=None):
+    """What a finished frame teaches its lane (the size record `host` it left, the status `rc` of its finishing call): the
+    lazy-sorting mode of the lane's next frames, whether they may speculate.  Shared by _Frame.finish and the band frames
+    of _band.py."""
+    # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
+    # on the exact path); do not speculate on the next frame of such a scene.  Lazily sorted frames
+    # (the library's default for plain forward frames of <= 4 channels) have no such tiles.
+    # Lazily sorted fronts that turn out too short are made good by a clean-up pass that is slow by
+    # design (one heavy bin costs more than lazy sorting saves on a whole frame).  host[5] = tiles the
+    # PREVIOUS frame on this lane had to redo: when that frame ran at the lane's current level, the
+    # lane moves on to fronts twice as deep, and after level 2 (or when many tiles fail at once) to
+    # full sorts.  (The count lives in the lane's workspace, whose layout follows the frame's shape: it
+    # only means something when the previous frame had the same shape, and a new shape starts afresh.)
+    heavy = int(host[2]) + int(host[3]) + int(host[4])
+    if FRAME_STATS is not None:
+        _count_frame(FRAME_STATS, frame, host, grew)
+    if not own:
+        same_shape = st.get("shape") == shape
+        memo = st.setdefault("learnt", {})   # shape -> (full_sort, front_level): a lane that alternates between
+        if not same_shape:                   # shapes (render.py's race between grids) does not learn them anew
+            st["full_sort"], st["front_level"] = memo.get(shape, (False, 0))
+        # (low 32 bits: a bin redone because of its depth cut-off -- the high bits -- says nothing about the fronts)
+        # (round 4: ... unless nearly every heavy bin had to be regenerated: that is a scene swap, the fronts of the new
+        # scene's bins are as stale as the cut-offs were -- measured: the frame after such a one fails its fronts as
+        # well, 70 ms at config 4 -- so the lane goes to full sorts one frame earlier)
+        elif (rc == 0 and not (int(host[7]) & 4) and not st.get("full_sort") and ((int(host[5]) >> 32) & 0x3fffffff) > max(8, heavy // 2)):
+            st["full_sort"] = True
+            # (round 5, advisor: a swap is over after a frame -- the cut-offs and fronts the next lazily sorted frame
+            # leaves are fresh -- so this fall-back has a short FIXED patience and does not lengthen the next one's)
+            st["full_sort_frames"], st["full_sort_limit"] = 0, SWAP_FULL_SORT
+            if FRAME_STATS is not None:
+                FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
+        elif (rc == 0 and not (int(host[7]) & 4) and (int(host[5]) & 0xffffffff) > 0 and not st.get("full_sort")
+              and st.get("prev_level") == st.get("front_level", 0)):
+            if (int(host[5]) & 0xffffffff) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
+                st["full_sort"] = True
+                st["full_sort_frames"], st["full_sort_limit"] = 0, None   # (patience: retry_after, doubling)
+                if FRAME_STATS is not None:
+                    FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
+            else:
+                st["front_level"] = st.get("front_level", 0) + 1
+                if FRAME_STATS is not None:
+                    FRAME_STATS["front_level_up"] = FRAME_STATS.get("front_level_up", 0) + 1
+        # ... and giving up is not for ever: a view through fog ends.  After RETRY_FULL_SORT frames on full sorts the
+        # lane tries lazily sorted fronts again, at the depth it last used; if they fail again (the library reports
+        # it one frame later, above) it is back on full sorts with twice the patience, up to 4096 frames.  (A failed
+        # retry costs one or two frames of the clean-up pass: 5-6 ms on the heaviest scenes since round 4's two-launch clean-up.)
+        if st.get("full_sort") and same_shape:
+            st["full_sort_frames"] = st.get("full_sort_frames", 0) + 1
+            fixed = st.get("full_sort_limit")
+            if st["full_sort_frames"] >= (fixed if fixed else st.get("retry_after", RETRY_FULL_SORT)):
+                st["full_sort"], st["full_sort_frames"] = False, 0
+                if not fixed:
+                    st["retry_after"] = min(2 * st.get("retry_after", RETRY_FULL_SORT), 4096)
+                st["retried"] = 2   # (the next two lazily sorted frames are on probation: the count comes a frame late)
+                if FRAME_STATS is not None:
+                    FRAME_STATS["lazy_sort_retry"] = FRAME_STATS.get("lazy_sort_retry", 0) + 1
+        elif same_shape and st.get("retried") and rc == 0 and not (int(host[7]) & 4):
+            # (round 5, advisor: a retried lazily sorted frame that reports no redone bin ends the doubling -- before, every
+            # benign scene swap or camera cut lengthened the NEXT fall-back, up to 4096 frames on the slow path)
+            if (int(host[5]) & 0xffffffff) == 0 and st.get("prev_level") is not None:
+                st["retried"] -= 1
+                if st["retried"] == 0:
+                    st["retry_after"] = RETRY_FULL_SORT
+        st["shape"], st["prev_level"] = shape, (level if not mode & FULL_SORT else None)
+        memo[shape] = (bool(st.get("full_sort")), int(st.get("front_level", 0)))
+        if len(memo) > 64:
+            memo.pop(next(iter(memo)))
+    lazy = LAZY_SORT and not own and channels <= 4 and not st.get("full_sort")
+    st["speculate"] = lazy or int(host[4]) == 0
+
+
 class _Frame:
     """One ms_render_fwd frame: its marshalled arguments and the lane whose scratch it occupies.
     `run(phase)` makes the library call; `finish()` completes a frame that was only begun."""
@@ -351,72 +423,8 @@ class _Frame:
                     rc = self.run(RESUME)
             st["busy"] = False
             _hip.check(rc, "ms_render_fwd")
-        # a frame whose tiles need the merge-fallback sort cannot run sync-free (the library redoes it
-        # on the exact path); do not speculate on the next frame of such a scene.  Lazily sorted frames
-        # (the library's default for plain forward frames of <= 4 channels) have no such tiles.
-        # Lazily sorted fronts that turn out too short are made good by a clean-up pass that is slow by
-        # design (one heavy bin costs more than lazy sorting saves on a whole frame).  host[5] = tiles the
-        # PREVIOUS frame on this lane had to redo: when that frame ran at the lane's current level, the
-        # lane moves on to fronts twice as deep, and after level 2 (or when many tiles fail at once) to
-        # full sorts.  (The count lives in the lane's workspace, whose layout follows the frame's shape: it
-        # only means something when the previous frame had the same shape, and a new shape starts afresh.)
-        heavy = int(host[2]) + int(host[3]) + int(host[4])
-        if FRAME_STATS is not None:
-            _count_frame(FRAME_STATS, self, host, grew)
-        if not self.own:
-            same_shape = st.get("shape") == self.shape
-            memo = st.setdefault("learnt", {})   # shape -> (full_sort, front_level): a lane that alternates between
-            if not same_shape:                   # shapes (render.py's race between grids) does not learn them anew
-                st["full_sort"], st["front_level"] = memo.get(self.shape, (False, 0))
-            # (low 32 bits: a bin redone because of its depth cut-off -- the high bits -- says nothing about the fronts)
-            # (round 4: ... unless nearly every heavy bin had to be regenerated: that is a scene swap, the fronts of the new
-            # scene's bins are as stale as the cut-offs were -- measured: the frame after such a one fails its fronts as
-            # well, 70 ms at config 4 -- so the lane goes to full sorts one frame earlier)
-            elif (rc == 0 and not (int(host[7]) & 4) and not st.get("full_sort") and ((int(host[5]) >> 32) & 0x3fffffff) > max(8, heavy // 2)):
-                st["full_sort"] = True
-                # (round 5, advisor: a swap is over after a frame -- the cut-offs and fronts the next lazily sorted frame
-                # leaves are fresh -- so this fall-back has a short FIXED patience and does not lengthen the next one's)
-                st["full_sort_frames"], st["full_sort_limit"] = 0, SWAP_FULL_SORT
-                if FRAME_STATS is not None:
-                    FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
-            elif (rc == 0 and not (int(host[7]) & 4) and (int(host[5]) & 0xffffffff) > 0 and not st.get("full_sort")
-                  and st.get("prev_level") == st.get("front_level", 0)):
-                if (int(host[5]) & 0xffffffff) > max(3, heavy // 4) or st.get("front_level", 0) >= 2:
-                    st["full_sort"] = True
-                    st["full_sort_frames"], st["full_sort_limit"] = 0, None   # (patience: retry_after, doubling)
-                    if FRAME_STATS is not None:
-                        FRAME_STATS["full_sort_on"] = FRAME_STATS.get("full_sort_on", 0) + 1
-                else:
-                    st["front_level"] = st.get("front_level", 0) + 1
-                    if FRAME_STATS is not None:
-                        FRAME_STATS["front_level_up"] = FRAME_STATS.get("front_level_up", 0) + 1
-            # ... and giving up is not for ever: a view through fog ends.  After RETRY_FULL_SORT frames on full sorts the
-            # lane tries lazily sorted fronts again, at the depth it last used; if they fail again (the library reports
-            # it one frame later, above) it is back on full sorts with twice the patience, up to 4096 frames.  (A failed
-            # retry costs one or two frames of the clean-up pass: 5-6 ms on the heaviest scenes since round 4's two-launch clean-up.)
-            if st.get("full_sort") and same_shape:
-                st["full_sort_frames"] = st.get("full_sort_frames", 0) + 1
-                fixed = st.get("full_sort_limit")
-                if st["full_sort_frames"] >= (fixed if fixed else st.get("retry_after", RETRY_FULL_SORT)):
-                    st["full_sort"], st["full_sort_frames"] = False, 0
-                    if not fixed:
-                        st["retry_after"] = min(2 * st.get("retry_after", RETRY_FULL_SORT), 4096)
-                    st["retried"] = 2   # (the next two lazily sorted frames are on probation: the count comes a frame late)
-                    if FRAME_STATS is not None:
-                        FRAME_STATS["lazy_sort_retry"] = FRAME_STATS.get("lazy_sort_retry", 0) + 1
-            elif same_shape and st.get("retried") and rc == 0 and not (int(host[7]) & 4):
-                # (round 5, advisor: a retried lazily sorted frame that reports no redone bin ends the doubling -- before, every
-                # benign scene swap or camera cut lengthened the NEXT fall-back, up to 4096 frames on the slow path)
-                if (int(host[5]) & 0xffffffff) == 0 and st.get("prev_level") is not None:
-                    st["retried"] -= 1
-                    if st["retried"] == 0:
-                        st["retry_after"] = RETRY_FULL_SORT
-            st["shape"], st["prev_level"] = self.shape, (self.level if not self.mode & FULL_SORT else None)
-            memo[self.shape] = (bool(st.get("full_sort")), int(st.get("front_level", 0)))
-            if len(memo) > 64:
-                memo.pop(next(iter(memo)))
-        lazy = LAZY_SORT and not self.own and self.head[8] <= 4 and not st.get("full_sort")
-        st["speculate"] = lazy or int(host[4]) == 0
+        _after_frame(st, host, rc, grew, shape=self.shape, level=self.level, mode=self.mode, own=self.own,
+                     channels=self.head[8], frame=self)
         if info is not None:
             info["on_grid"] = int(host[6])
             info["flags"] = int(host[7])

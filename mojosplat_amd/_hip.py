@@ -91,6 +91,34 @@ _SIGNATURES["ms_render_fwd_batch"] = (c_int, [c_int, c_int64, c_void_p, c_void_p
                                               c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t),
                                               ctypes.POINTER(c_int)])
 
+class Scene(ctypes.Structure):
+    """ms_scene (include/mojosplat_hip.h): the Gaussians, marshalled once per scene (+ a prepared scene's block bounds)."""
+    _fields_ = [("N", c_int64), ("means3d", c_void_p), ("scales", c_void_p), ("scales_are_log", c_int), ("quats", c_void_p),
+                ("opacities", c_void_p), ("colors", c_void_p), ("color_dtype", c_int), ("CDIM", c_int),
+                ("block_bounds", c_void_p), ("block_size", c_int), ("n_blocks", c_int64)]
+
+
+class BandLane(ctypes.Structure):
+    """ms_band_lane: one scratch set + the stream a band runs on + the two events that order it against the caller's."""
+    _fields_ = [("workspace", c_void_p), ("workspace_bytes", c_size_t), ("isect_buf", c_void_p), ("isect_bytes", c_size_t),
+                ("host_info", c_void_p), ("sync_event", c_void_p), ("stream", c_void_p), ("in_event", c_void_p),
+                ("out_event", c_void_p)]
+
+
+class BandFrame(ctypes.Structure):
+    """ms_band_frame: one rank's band of one frame."""
+    _fields_ = [("scene", ctypes.POINTER(Scene)), ("viewmat", c_void_p), ("fx", c_float), ("fy", c_float), ("cx", c_float),
+                ("cy", c_float), ("W", c_int), ("H", c_int), ("eps2d", c_float), ("near_plane", c_float), ("far_plane", c_float),
+                ("tile_size", c_int), ("row_begin", c_int), ("row_end", c_int), ("flags", c_int), ("backgrounds", c_void_p),
+                ("render_colors", c_void_p), ("stage_events", c_void_p)]
+
+
+_SIGNATURES["ms_scene_block_bounds_bytes"] = (c_size_t, [c_int64, c_int])
+_SIGNATURES["ms_scene_prepare"] = (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p])
+_SIGNATURES["ms_render_band_begin"] = (c_int, [ctypes.POINTER(BandFrame), ctypes.POINTER(BandLane), c_void_p])
+_SIGNATURES["ms_render_band_finish"] = (c_int, [ctypes.POINTER(BandFrame), ctypes.POINTER(BandLane), c_void_p, c_int,
+                                               ctypes.POINTER(c_int64)])
+
 # entry points added after ABI v1's first cut; bound when present
 _OPTIONAL = {}
 

@@ -84,7 +84,9 @@ int project_isect_count(int64_t N, const float *means3d, const float *scales, in
                         float radius_clip, int tile_size, int row_begin, int row_end, int tight, float *means2d,
                         float *conics, float *depths, int32_t *radii, void *workspace, size_t workspace_bytes,
                         int32_t *tile_ranges, int64_t *isect_info, int64_t *isect_info_mirror,
-                        const void *colors3, int color_dtype, void *raster_records, void *stream, uint32_t cut_stamp = 0);
+                        const void *colors3, int color_dtype, void *raster_records, void *stream, uint32_t cut_stamp = 0,
+                        // a PREPARED scene (ms_scene_prepare): bounds of every block of block_size Gaussians, for the band pre-cull
+                        const float *block_bounds = nullptr, int block_size = 0);
 
 // Lazy sorting (binning.hip): tiles longer than front_threshold have only front_count[tile] sorted
 // entries; the rasteriser appends a tile to redo_list when pixels are still alive at the end of it.

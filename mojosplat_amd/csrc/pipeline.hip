@@ -206,7 +206,7 @@ static size_t split_isect_bytes(int64_t M) {
     return ms::align_up(m * 8, 256) + ms::align_up(m * 4, 256) + ms::align_up(m * 16, 256);
 }
 
-static int render_fwd_impl(int restart, int64_t N, const float *means3d, const float *scales, int scales_are_log,
+static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, const float *means3d, const float *scales, int scales_are_log,
                              const float *quats, const float *opacities, const void *colors,
                              int color_dtype, int CDIM, const float *viewmat, float fx, float fy,
                              float cx, float cy, int W, int H, float eps2d, float near_plane,
@@ -246,7 +246,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
     // (bit 6: the frame dropped the pairs behind its bins' depth cut-offs -- the exact path cannot finish such a frame:
     // it starts over without the cut)
     if (phase == MS_RENDER_RESUME && (host_info[7] & 64))
-        return render_fwd_impl(restart | 2, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
+        return render_fwd_impl(prepared, restart | 2, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
                                fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, rows16 ? clip0 : tile_row_begin,
                                rows16 ? clip1 : tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
                                (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids, stage_events,
@@ -371,7 +371,10 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
                                              /*tight | ranges for the band only (| block masks)=*/(split ? bin_flags : 1 | 2 | cull) | defer_bit,
                                              means2d, conics, depths, radii, ws + L.off_isect, L.isect_bytes,
                                              split ? bin_ranges : ranges, info, (int64_t *)mirror,
-                                             use_records ? colors : nullptr, color_dtype, records, stream, cut_stamp))
+                                             use_records ? colors : nullptr, color_dtype, records, stream, cut_stamp,
+                                             // (a prepared scene: the band pre-cull skips the blocks that cannot reach the band)
+                                             prepared && prepared->block_bounds && (cull & 32) ? prepared->block_bounds : nullptr,
+                                             prepared ? prepared->block_size : 0))
             return rc;
         mark(1);
         MS_HP_T(hp_t3);
@@ -481,7 +484,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         speculated = (host_info[7] & 1) != 0;  // a redo after growing the buffer: events were already marked
     }
     if (host_info[7] & 64)   // a depth-cut frame that did not fit its buffer: the frame again, every pair written
-        return render_fwd_impl(restart | 2, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
+        return render_fwd_impl(prepared, restart | 2, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
                                fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, rows16 ? clip0 : tile_row_begin,
                                rows16 ? clip1 : tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
                                (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids,
@@ -499,7 +502,7 @@ static int render_fwd_impl(int restart, int64_t N, const float *means3d, const f
         return MS_OK;
     }
     if (split && M > ms_split_max_entries())   // 4 M block-list slots would not fit int32: the frame again, on 16-px tiles
-        return render_fwd_impl(restart | 1, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
+        return render_fwd_impl(prepared, restart | 1, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat,
                                fx, fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, tile_row_begin,
                                tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
                                (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids,
@@ -559,7 +562,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                              size_t isect_bytes, int64_t *host_info, int resume,
                              float *render_colors, float *render_alphas, int32_t *last_ids,
                              void **stage_events, void *sync_event, void *stream_) {
-    return render_fwd_impl(0, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat, fx,
+    return render_fwd_impl(nullptr, 0, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat, fx,
                            fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, tile_row_begin, tile_row_end,
                            backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info, resume,
                            render_colors, render_alphas, last_ids, stage_events, sync_event, stream_);
@@ -674,6 +677,57 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
                                     v_means2d, v_conics, nullptr, v_means3d, v_scales, v_quats, stream_);
 }
 
+
+// ---- a multi-GPU rank's band of a frame, in two calls ----------------------------------------------------------------
+// What distributed.py's asynchronous path did around ms_render_fwd(BEGIN) / (FINISH) in Python -- marshalling five tensors
+// and a camera per frame, four event operations, record_stream on every tensor that crosses to the lane, the frame object --
+// cost ~100-130 us of host time per band frame against 18-45 us for the library's own enqueue, level with the GPU time of a
+// config-5 band at 8 ranks (profiles/r04_band_rehearsal_cfg5.jsonl: host_us_median 146-151).  Here the caller hands over
+// structs it builds ONCE per scene / lane (ms_scene, ms_band_lane) and one small per-frame struct; the stream ordering around
+// the lane (caller -> lane before the band, lane -> caller after it) happens in here.
+static int band_validate(const ms_band_frame *f, const ms_band_lane *lane, const char *who) {
+    MS_REQUIRE(f && lane && f->scene, MS_ERR_INVALID_ARG, "%s: null frame / lane / scene", who);
+    // (sync_event may be null, as for ms_render_fwd: the frame then waits for its size record by synchronising the lane's stream)
+    MS_REQUIRE(lane->workspace && lane->host_info && lane->in_event && lane->out_event,
+               MS_ERR_INVALID_ARG, "%s: the lane lacks scratch or an event", who);
+    MS_REQUIRE(f->render_colors && f->viewmat, MS_ERR_INVALID_ARG, "%s: null image / view matrix", who);
+    return MS_OK;
+}
+
+static int band_call(const ms_band_frame *f, const ms_band_lane *lane, int phase) {
+    const ms_scene *sc = f->scene;
+    return render_fwd_impl(sc, 0, sc->N, sc->means3d, sc->scales, sc->scales_are_log, sc->quats, sc->opacities, sc->colors,
+                           sc->color_dtype, sc->CDIM, f->viewmat, f->fx, f->fy, f->cx, f->cy, f->W, f->H, f->eps2d, f->near_plane,
+                           f->far_plane, f->tile_size, f->row_begin, f->row_end, f->backgrounds, lane->workspace,
+                           lane->workspace_bytes, lane->isect_buf, lane->isect_bytes, lane->host_info,
+                           phase | (f->flags & ~0xff), f->render_colors, nullptr, nullptr, f->stage_events, lane->sync_event, lane->stream);
+}
+
+extern "C" int ms_render_band_begin(const ms_band_frame *f, const ms_band_lane *lane, void *caller_stream) {
+    if (int rc = band_validate(f, lane, "render_band_begin")) return rc;
+    // everything the band reads was produced on (or before) the caller's stream: the lane waits for it
+    MS_HIP(hipEventRecord((hipEvent_t)lane->in_event, (hipStream_t)caller_stream));
+    MS_HIP(hipStreamWaitEvent((hipStream_t)lane->stream, (hipEvent_t)lane->in_event, 0));
+    return band_call(f, lane, MS_RENDER_BEGIN);
+}
+
+extern "C" int ms_render_band_finish(const ms_band_frame *f, const ms_band_lane *lane, void *caller_stream, int resume,
+                                     int64_t *status) {
+    if (int rc = band_validate(f, lane, "render_band_finish")) return rc;
+    MS_REQUIRE(status, MS_ERR_INVALID_ARG, "render_band_finish: null status");
+    // the wait for the band's size record, the check, the exact redo if the speculation did not hold (MS_ERR_WORKSPACE:
+    // lane->host_info[5] bytes of isect_buf needed -- grow it, update the lane, call again with resume = 1)
+    if (int rc = band_call(f, lane, resume ? MS_RENDER_RESUME : MS_RENDER_FINISH)) return rc;
+    // the band is complete on the lane's stream: whatever the caller enqueues next (the exchange) comes behind it
+    MS_HIP(hipEventRecord((hipEvent_t)lane->out_event, (hipStream_t)lane->stream));
+    MS_HIP(hipStreamWaitEvent((hipStream_t)caller_stream, (hipEvent_t)lane->out_event, 0));
+    const int64_t *h = lane->host_info;
+    status[0] = h[6];                      // Gaussians on the grid (a pre-culled band: of its candidates)
+    status[1] = (h[7] & 2048) ? 1 : 0;     // the library pre-culled the band
+    status[2] = h[0];                      // pairs in the band
+    status[3] = h[7];                      // the frame's flag word
+    return MS_OK;
+}
 
 // Camera batch: n_lanes views in flight (begin view v + 1 before finishing view v).  See the header.
 extern "C" int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *scales, int scales_are_log,

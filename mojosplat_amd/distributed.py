@@ -238,16 +238,17 @@ def _render_band(stages, means3d, scales, quats, opacities, features, camera, bg
     H, W = camera.H, camera.W
     th, tw = -(-H // tile_size), -(-W // tile_size)
     if stages is None:
-        from ._fused import render_fwd_hip
-        info = {}
+        from . import _band, _hip
         b = _band_of(band, th)
         key, mode = _band_bin(means3d, camera, b, tile_size)
         # (rows16: the band stays in 16-px rows while the BINS follow the rule -- only when the caller's tiles are the
         # 16-px ones; an explicit tile_size of 32 / 48 / 64 keeps band_plan's units, tile rows of that size)
-        _, m = render_fwd_hip(means3d, scales, quats, opacities, features, camera, bg, mode,
-                              row_range=b, out=out, info=info, rows16=(tile_size == 16), out_y0=out_y0)
-        _band_learn(key, mode, m, info, camera, b)
-        return info["on_grid"], m, bool(info["flags"] & 2048)
+        # (round 5: the library's band pair on the CALLER's stream -- lane slot 0, the calling thread's own scratch)
+        cur = _hip._raw_stream(means3d.device.index) if _hip._raw_stream is not None else torch.cuda.current_stream(means3d.device).cuda_stream
+        h = _band.band_begin(means3d, scales, quats, opacities, features, camera, bg, mode, b, out, out_y0, tile_size == 16, 0, None, cur)
+        on_grid, culled, m, flags = _band.band_finish(h, cur)
+        _band_learn(key, mode, m, {"on_grid": on_grid, "flags": flags}, camera, b)
+        return on_grid, m, culled
     means2d, conics, depths, radii = stages.project(means3d, scales, quats, opacities, camera)
     ids, ranges = stages.bin(means2d, radii, depths, tile_size, tw, th, band)
     if r1 > r0:
@@ -465,49 +466,34 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
             return resolve(img, works)
         return PendingFrame(finalize=lambda: resolve(img, works))
 
-    # asynchronous HIP path: band on a lane stream (ms_render_fwd BEGIN, no host wait).  Streams
-    # are addressed by handle and ordered with events; torch's current stream is never switched
-    # (the context managers would cost more host time than the band's kernels take to launch).
-    from ._fused import _Frame, _lane_streams
-    cur = _current_stream(dev)
+    # asynchronous HIP path: the band on a lane stream, begun without any host wait (ms_render_band_begin); torch's current
+    # stream is never switched.  Round 5: the library's two-call pair does the marshalling-free enqueue and the stream ordering
+    # around the lane (_band.py: scene / lane / frame structs cached, no record_stream -- the scene's tensors are kept alive
+    # by the cache, the framebuffer is first touched on the lane after the lane has waited for the caller's stream and
+    # handed out after the caller's stream has waited for the lane).
+    from . import _band, _hip
+    from ._fused import _frame_lock, _lane_streams
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    raw = _hip._raw_stream(idx) if _hip._raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
     lanes = _lane_streams(dev)
-    lane = _turn.get(dev, 0)
-    _turn[dev] = 1 - lane
-    s = lanes[lane]
     buf = framebuffer()
-    from . import render as _render   # bench.py's in-situ kernel timing hook (None otherwise)
-    evs = _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None
-    # Marshal first (non-fp32 / strided inputs and the view matrix are copied by kernels enqueued on the
-    # CURRENT stream), then make the lane wait for the current stream, then enqueue the band on the lane:
-    # everything the band reads -- the caller's tensors and the marshalled copies -- is ordered before it.
     my_band = _band_of(bands[rank], th)
     bkey, bmode = _band_bin(means3d, camera, my_band, tile_size)
-    frame = _Frame(means3d, scales, quats, opacities, features, camera, bg, bmode, evs,
-                   my_band, buf[rank] if padded else buf, 1 + lane, s.cuda_stream, rows16=(tile_size == 16),
-                   out_y0=y0s[rank] if padded else None)
-    # (persistent events per lane: Stream.wait_stream creates a fresh event per call, ~8 us of host time each)
-    ev_in, ev_out = _lane_events(dev, lane)
-    ev_in.record(cur)
-    s.wait_event(ev_in)
-    frame.begin()
-    # tensors allocated on the current stream and used on the lane: the caching allocator must not hand
-    # their memory out again before the lane is done with it
-    seen = set()
-    for t in (means3d, scales, quats, opacities, features, bg, buf) + tuple(x for x in frame.keep[:-1] if x is not None):
-        if id(t) not in seen:     # (already-fp32 contiguous inputs ARE their marshalled copies)
-            seen.add(id(t))
-            t.record_stream(s)
+    with _frame_lock:   # (the shared lanes are one thread at a time: the lane pick and the frame's claim on it)
+        lane = _turn.get(dev, 0)
+        _turn[dev] = 1 - lane
+        from . import render as _render   # bench.py's in-situ kernel timing hook (None otherwise)
+        h = _band.band_begin(means3d, scales, quats, opacities, features, camera, bg, bmode, my_band, buf[rank] if padded else buf,
+                             y0s[rank] if padded else None, tile_size == 16, 1 + lane, lanes[lane].cuda_stream, raw,
+                             _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None)
 
     def finalize():
-        info = {}
-        _, m = frame.finish(info=info)      # size-record check (+ exact redo on the lane stream if it failed)
-        _band_learn(bkey, bmode, m, info, camera, my_band)
-        now = _current_stream(dev)
-        ev_out.record(s)
-        now.wait_event(ev_out)       # the band is complete before the exchange starts
-        img, works = exchange(buf, info["on_grid"], m, bool(info["flags"] & 2048))   # the collectives' stream waits for `now`
-        return resolve(img, works)                       # ... and `now` for the exchange
-    return PendingFrame(finalize=finalize)
+        now = _hip._raw_stream(idx) if _hip._raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        on_grid, culled, m, flags = _band.band_finish(h, now)   # size-record check (+ exact redo on the lane); lane -> `now`
+        _band_learn(bkey, bmode, m, {"on_grid": on_grid, "flags": flags}, camera, my_band)
+        img, works = exchange(buf, on_grid, m, culled)          # the collectives' stream waits for `now`
+        return resolve(img, works)                              # ... and `now` for the exchange
+    return PendingFrame(finalize=finalize, on_drop=lambda st=h.rec.st: st.__setitem__("busy", False))
 
 
 @torch.no_grad()

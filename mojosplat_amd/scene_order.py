@@ -29,3 +29,70 @@ def morton_permutation(means3d: torch.Tensor, bits: int = 10) -> torch.Tensor:
     assert bits <= 10
     code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
     return torch.argsort(code, stable=True)
+
+
+# ---- prepared scenes ---------------------------------------------------------------------------------------------------
+BLOCK_SIZE = 256   # Gaussians per block of a prepared scene (config 5 cut 8 ways: the centre band's candidates come out 1.6x
+                   # the exact set at 256, 1.8x at 1024, 1.4x at 64 -- the boxes' own size against the band's 270 px)
+
+
+@dataclass
+class PreparedScene:
+    """A scene in a spatially coherent order with its block bounds (`prepare_scene`).  Pass `.arrays` to the render calls:
+    the sharded entry points recognise the tensors and hand the bounds to the library (ms_scene).  `perm[i]` = index in the
+    caller's arrays of the Gaussian now stored at i (gradients / ids map back through it)."""
+    means3d: torch.Tensor
+    scales: torch.Tensor
+    quats: torch.Tensor
+    opacities: torch.Tensor
+    features: torch.Tensor
+    perm: Optional[torch.Tensor]
+    block_bounds: torch.Tensor
+    block_size: int
+
+    @property
+    def arrays(self):
+        return (self.means3d, self.scales, self.quats, self.opacities, self.features)
+
+
+_registry = {}   # id(means3d) -> (weakref to means3d, means version, scales weakref, scales version, PreparedScene)
+
+
+def prepare_scene(means3d, scales, quats, opacities, features, block_size: int = BLOCK_SIZE, reorder: bool = True) -> PreparedScene:
+    """Sort the Gaussians along a Morton curve of their means (reorder=False: keep the caller's order, which must then be
+    spatially coherent for the bounds to be worth anything -- any order stays CORRECT) and compute the bounds of every
+    block of `block_size` of them (ms_scene_prepare).  Once per scene: ~2 ms at 5 M Gaussians.  The scales are the
+    LOG-scales render_gaussians takes.  The bounds describe the arrays as they are now: call again after the means or
+    scales change (an in-place update is noticed through the tensors' version counters and the bounds are dropped)."""
+    import ctypes
+    import weakref
+    from . import _hip
+    _hip.require_cuda(means3d, scales, quats, opacities, features, what="gaussian tensor")
+    perm = None
+    if reorder:
+        perm = morton_permutation(means3d)
+        means3d, scales, quats, opacities, features = (t[perm].contiguous() for t in (means3d, scales, quats, opacities, features))
+    m, sc = _hip.f32c(means3d), _hip.f32c(scales)
+    N = m.shape[0]
+    L = _hip.lib()
+    nbytes = L.ms_scene_block_bounds_bytes(N, block_size)
+    bounds = torch.empty(max(nbytes // 4, 8), dtype=torch.float32, device=m.device)
+    with _hip.on_device(m.device):
+        _hip.check(L.ms_scene_prepare(N, _hip.ptr(m), _hip.ptr(sc), 1, block_size, _hip.ptr(bounds), _hip.stream(m.device)),
+                   "ms_scene_prepare")
+    ps = PreparedScene(m, sc, quats, opacities, features, perm, bounds.view(-1, 8), block_size)
+    if len(_registry) > 64:
+        _registry.clear()
+    _registry[id(m)] = (weakref.ref(m), m._version, weakref.ref(sc), sc._version, ps)
+    return ps
+
+
+def prepared_bounds(means3d, scales):
+    """-> (block_bounds tensor, block_size) if these very tensors -- unmodified since -- belong to a prepared scene, else None."""
+    rec = _registry.get(id(means3d))
+    if rec is None:
+        return None
+    m_ref, m_ver, s_ref, s_ver, ps = rec
+    if m_ref() is not means3d or s_ref() is not scales or means3d._version != m_ver or scales._version != s_ver:
+        return None
+    return ps.block_bounds, ps.block_size

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--worlds", default="1,2,4,8")
+    # given: the scene as randscene_v1 draws it (random order); morton: sorted along a Morton curve of the means by the
+    # CALLER (no bounds); prepared: scene_order.prepare_scene -- the same order plus the block bounds the band pre-cull uses
+    ap.add_argument("--order", default="given", choices=["given", "morton", "prepared"])
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     N, W, H, ell, fp16 = WORKLOADS[args.workload]
@@ -39,6 +42,13 @@ def main():
         sc["features"] = sc["features"].half()
     bg = torch.tensor(BACKGROUND_V1, device=dev)
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    if args.order == "morton":
+        from mojosplat_amd.scene_order import morton_permutation
+        perm = morton_permutation(g[0])
+        g = tuple(t[perm].contiguous() for t in g)
+    elif args.order == "prepared":
+        from mojosplat_amd.scene_order import prepare_scene
+        g = prepare_scene(*g).arrays
     th = -(-H // 16)
 
     def render(r, world, bounds, **kw):
@@ -100,7 +110,7 @@ def main():
         worst_b = max(x["blocking_us_median"] for x in ranks)
         worst_p = max(x["pipelined_us"] for x in ranks)
         best_b = min(x["blocking_us_median"] for x in ranks)
-        print(json.dumps(dict(workload=args.workload, world=world, plan=label, bounds=bounds, frames=args.frames,
+        print(json.dumps(dict(workload=args.workload, order=args.order, world=world, plan=label, bounds=bounds, frames=args.frames,
                               slowest_blocking_us_median=worst_b, rank_spread=round(worst_b / best_b, 3),
                               slowest_pipelined_us=worst_p, fps_bound_pipelined=round(1e6 / worst_p, 1), ranks=ranks)),
               flush=True)

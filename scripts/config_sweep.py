@@ -40,7 +40,16 @@ def timed(fn, iters=100, warm=16):
 
 
 def main():
-    names = sys.argv[1:] or ["cfg2", "cfg3", "cfg3-bwd", "cfg4", "cfg5", "cfg2-heavy", "cfg3-heavy"]
+    # --order morton: every scene with its Gaussians sorted along a Morton curve of their means first (round 5: the order
+    # must not cost a frame anything -- csrc/binning.hip, Deal / BigQ)
+    argv = sys.argv[1:]
+    order = "given"
+    if "--order" in argv:
+        k = argv.index("--order")
+        order = argv[k + 1]
+        argv = argv[:k] + argv[k + 2:]
+    assert order in ("given", "morton")
+    names = argv or ["cfg2", "cfg3", "cfg3-bwd", "cfg4", "cfg5", "cfg2-heavy", "cfg3-heavy"]
     dev = torch.device("cuda:0")
     bg = torch.tensor(BACKGROUND_V1, device=dev)
     for name in names:
@@ -49,8 +58,12 @@ def main():
         sc, cam = randscene_v1(N, W, H, ell=ell, device=dev)
         if fp16:
             sc["features"] = sc["features"].half()
+        if order == "morton":
+            from mojosplat_amd.scene_order import morton_permutation
+            perm = morton_permutation(sc["means3d"])
+            sc = {k: v[perm].contiguous() for k, v in sc.items()}
         g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
-        out = {"config": name, "N": N, "W": W, "H": H}
+        out = {"config": name, "order": order, "N": N, "W": W, "H": H}
         if bwd:
             leaves = [t.float().clone().requires_grad_(True) for t in g]
             gen = torch.Generator().manual_seed(43)

@@ -1,6 +1,7 @@
 """GPU: the one-call forward path (ms_render_fwd, what render_gaussians(backend='hip') runs)
 is bit-identical to the three per-stage calls, across buffer growth, empty scenes, fp16
 colours and tile sizes."""
+import math
 import pytest
 import torch
 
@@ -964,3 +965,62 @@ def test_a_lane_on_full_sorts_tries_lazy_sorting_again(device, default_grid_only
     finally:
         _fused.FRAME_STATS = None
         _fused._state.clear()
+
+
+def test_prepared_scene_bands_equal_the_single_gpu_frame(device):
+    """Round 5: a PREPARED scene (scene_order.prepare_scene: Morton order + the bounds of every block of 256 Gaussians) through
+    the sharded entry point -- the band pre-cull skips whole blocks by their bounds.  Every rank's band (8 and 3 ranks,
+    blocking and two frames in flight, a moved camera, bands that hold nothing) assembles to the single-GPU frame of the SAME
+    arrays bit for bit, the candidates the library reports are never more than without the bounds would give, and a scene
+    whose tensors were modified in place after prepare_scene silently loses its bounds instead of culling with stale ones."""
+    from mojosplat_amd.distributed import render_gaussians_sharded
+    from mojosplat_amd.scene_order import prepare_scene, prepared_bounds
+    from mojosplat_amd.utils import Camera
+    sc, cam = randscene_v1(200_000, 1280, 720, ell=-3.6, seed=11, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    ps = prepare_scene(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    g = ps.arrays
+    assert prepared_bounds(g[0], g[1]) is not None and ps.block_bounds.shape == (-(-200_000 // 256), 8)
+    # the bounds hold: every Gaussian inside its block's box, its largest scale under the block's
+    blk = torch.arange(200_000, device=device) // 256
+    lo, hi, sm = ps.block_bounds[blk, 0:3], ps.block_bounds[blk, 4:7], ps.block_bounds[blk, 3]
+    assert bool((g[0] >= lo).all()) and bool((g[0] <= hi).all()) and bool((g[1].exp().max(1).values <= sm).all())
+    th = -(-cam.H // 16)
+    cams = [cam]
+    c, s_ = math.cos(0.4), math.sin(0.4)
+    R2 = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]], device=device) @ cam.R
+    cams.append(Camera(R=R2.contiguous(), T=cam.T + torch.tensor([0.3, -0.2, -2.0], device=device), H=cam.H, W=cam.W, fx=cam.fx,
+                       fy=cam.fy, cx=cam.cx, cy=cam.cy, near=cam.near, far=cam.far))   # (closer: boxes straddle the near plane)
+    for cm in cams:
+        ref = ms.render_gaussians(*g, cm, background_color=bg, backend="hip")
+        same = ms.render_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"], cm, background_color=bg)
+        assert float((ref - same).abs().max()) <= 1e-5   # (a permutation moves the order of equal-depth ties at most)
+        for world in (8, 3):
+            frame = torch.empty_like(ref)
+            rows = -(-th // world)
+            for r in range(world):
+                band = render_gaussians_sharded(*g, cm, background_color=bg, rehearse=(r, world))
+                y0, y1 = min(r * rows * 16, cm.H), min((r + 1) * rows * 16, cm.H)
+                frame[y0:y1] = band[y0:y1]
+            assert torch.equal(frame, ref), f"world {world}: the prepared scene's bands differ from the single-GPU frame"
+        # two frames in flight on the lane streams
+        cur = None
+        for k in range(5):
+            nxt = render_gaussians_sharded(*g, cm, background_color=bg, rehearse=(3, 8), async_op=True)
+            if cur is not None:
+                b = cur.wait()
+                y0, y1 = 3 * (-(-th // 8)) * 16, min(4 * (-(-th // 8)) * 16, cm.H)
+                assert torch.equal(b[y0:y1], ref[y0:y1])
+            cur = nxt
+        cur.wait()
+    # an in-place update of the means voids the bounds (their box no longer holds): the scene renders as an unprepared one
+    g[0].add_(0.5)
+    assert prepared_bounds(g[0], g[1]) is None
+    ref = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    frame = torch.empty_like(ref)
+    rows = -(-th // 8)
+    for r in range(8):
+        band = render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, 8))
+        y0, y1 = min(r * rows * 16, cam.H), min((r + 1) * rows * 16, cam.H)
+        frame[y0:y1] = band[y0:y1]
+    assert torch.equal(frame, ref)
