@@ -595,9 +595,11 @@ def morton_leg(ms, _fused, g, cam, bg, ref_img, given_ms, frames=200):
     _fused._state.clear()
     # (a permutation reorders equal-depth ties and the float sums' order nowhere: lists are sorted by (depth bits, index) --
     # the INDEX differs, so two Gaussians at bit-equal depth may swap; compared to rounding, not bit for bit)
-    d = float((img - ref_img).abs().max())
+    d = (img - ref_img).abs().max(-1).values
     return {"frames": frames, "ms_per_frame": round(dt, 4), "frames_per_s": round(1e3 / dt, 1),
-            "vs_given_order": round(dt / given_ms, 4), "max_abs_vs_given_order_frame": d, "same_frame": d <= 1e-5}
+            "vs_given_order": round(dt / given_ms, 4),
+            "px_differing_from_the_given_order_frame": int((d > 0).sum()), "max_abs": float(d.max()),
+            "why_any": "lists are sorted by (depth bits, index): Gaussians at bit-equal depth swap when the indices are permuted"}
 
 
 def two_in_flight_leg(ms, g, cam, bg, ref_img, steps):

@@ -994,7 +994,10 @@ def test_prepared_scene_bands_equal_the_single_gpu_frame(device):
     for cm in cams:
         ref = ms.render_gaussians(*g, cm, background_color=bg, backend="hip")
         same = ms.render_gaussians(sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"], cm, background_color=bg)
-        assert float((ref - same).abs().max()) <= 1e-5   # (a permutation moves the order of equal-depth ties at most)
+        # (a permutation moves the order of Gaussians at bit-equal depth -- ties go by index -- and nothing else: a few
+        # pixels under such a pair change by up to an alpha, the rest of the frame is the same to the bit)
+        d = (ref - same).abs().max(-1).values
+        assert float((d > 0).float().mean()) <= 1e-3 and float(d.max()) <= 0.05
         for world in (8, 3):
             frame = torch.empty_like(ref)
             rows = -(-th // world)
