@@ -246,6 +246,23 @@ int ms_project_gaussians_bwd(int64_t N, const float *means3d, const float *scale
  * MOJOSPLAT_DEPTH_CUT_MIN_PAIRS, read once.  (For tests and measurements that switch inside one process.) */
 int ms_config_depth_cut(int mode, long long min_pairs);
 
+/* ms_render_bwd in two halves, for a multi-GPU rank's differentiable BAND frame (a 3-channel frame at a tile size that is a
+ * multiple of 16, rendered with render_alphas over tile rows [tile_row_begin, tile_row_end) -- or the whole frame: 0, tile_h):
+ *   ms_render_bwd_rows  : the backward rasteriser on the band's lists -> rows f32[N][16], the per-Gaussian RAW sums of the
+ *                         band's pixels (zeroed by the call).  Sums over disjoint bands ADD: a rank's caller all-reduces
+ *                         the rows over the ranks ("per-Gaussian grads need one all-reduce") ...
+ *   ms_render_bwd_finish: ... and the backward projection turns the summed rows into the gradients, identically on every rank.
+ * ms_render_bwd == rows(0, tile_h) + finish.  No reference counterpart (render.py:11; README.md:145). */
+size_t ms_render_bwd_rows_bytes(int64_t N);
+int ms_render_bwd_rows(int64_t N, int CDIM, int W, int H, int tile_size, int tile_row_begin, int tile_row_end,
+                       const float *backgrounds, const void *workspace, size_t workspace_bytes, const void *isect_buf,
+                       size_t isect_bytes, const int64_t *host_info, const float *render_colors, const float *render_alphas,
+                       const float *v_render_colors, const float *v_render_alphas, float *rows, void *stream);
+int ms_render_bwd_finish(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
+                         const float *opacities, int CDIM, const float *viewmat, float fx, float fy, float cx, float cy,
+                         int W, int H, float eps2d, const float *rows, float *v_means3d, float *v_scales, float *v_quats,
+                         float *v_opacities, float *v_colors, void *stream);
+
 /* Bins the clean-up pass of a finished ms_render_fwd frame had to redo (lazily sorted fronts that ran out with pixels
  * alive): host_counts i32[2] = {all redone bins, those redone for their depth cut-off}, copied asynchronously on `stream`
  * from the frame's `workspace` (host_counts: pinned HOST memory; valid once an event recorded behind the call has

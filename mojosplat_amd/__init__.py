@@ -13,10 +13,16 @@ from .render import render_gaussians, render_gaussians_batch, TILE_SIZE
 from .sh import evaluate_sh
 
 
+def prepare_scene(*args, **kw):
+    """Sort a scene along a Morton curve and compute its block bounds for the multi-GPU band path: scene_order.prepare_scene."""
+    from .scene_order import prepare_scene as _prepare
+    return _prepare(*args, **kw)
+
+
 def release_scratch():
     """Give the calling thread's cached render scratch (and the shared lanes') back to the allocator: _fused.release_scratch."""
     from ._fused import release_scratch as _release
     _release()
 
 __all__ = ["Camera", "look_at", "project_gaussians", "bin_gaussians_to_tiles",
-           "rasterize_gaussians", "render_gaussians", "render_gaussians_batch", "evaluate_sh", "release_scratch", "TILE_SIZE"]
+           "rasterize_gaussians", "render_gaussians", "render_gaussians_batch", "evaluate_sh", "release_scratch", "prepare_scene", "TILE_SIZE"]

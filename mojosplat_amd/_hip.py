@@ -113,6 +113,12 @@ class BandFrame(ctypes.Structure):
                 ("render_colors", c_void_p), ("stage_events", c_void_p)]
 
 
+_SIGNATURES["ms_render_bwd_rows_bytes"] = (c_size_t, [c_int64])
+_SIGNATURES["ms_render_bwd_rows"] = (c_int, [c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                             c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p])
+_SIGNATURES["ms_render_bwd_finish"] = (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
+                                               c_float, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p])
 _SIGNATURES["ms_scene_block_bounds_bytes"] = (c_size_t, [c_int64, c_int])
 _SIGNATURES["ms_scene_prepare"] = (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p])
 _SIGNATURES["ms_render_band_begin"] = (c_int, [ctypes.POINTER(BandFrame), ctypes.POINTER(BandLane), c_void_p])

@@ -182,7 +182,8 @@ int rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const float *
                         const int32_t *tile_ranges, const int32_t *ids, int id_stride, const int32_t *front_count,
                         int front_threshold, const int32_t *skip_flag, const float *render_colors,
                         const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
-                        float *packed_rows, const int32_t *order, void *stream);
+                        float *packed_rows, const int32_t *order, void *stream,
+                        int tile_row_begin = 0, int tile_row_end = -1);   // (a band of tile rows; -1: to the last row)
 
 // ... and its launch for the tiles the forward's clean-up pass redid (their sorted front ran out with pixels alive): a wave
 // per (tile, block, quad) walks the whole-tile sorted ids the forward's k_redo_sort left (redo_flag[tile] == 2); a tile that

@@ -579,6 +579,87 @@ extern "C" size_t ms_render_bwd_workspace_bytes(int64_t N, int CDIM) {
     return ms::align_up(ms_rasterize_bwd_workspace_bytes(N, CDIM), 256) + ms::align_up(n * 8, 256) + ms::align_up(n * 12, 256);
 }
 
+// The rasteriser half of a differentiable frame's backward -- the whole frame's, or a multi-GPU rank's BAND of tile rows --
+// into the packed per-Gaussian rows (f32[N][16]: the quad-wave kernel's raw sums), zeroed here.  Only frames the quad-wave
+// kernel takes: three channels, ready-made records, a tile size that is a multiple of 16, the frame's image at hand.
+static int render_bwd_rows_impl(int64_t N, int CDIM, int W, int H, int tile_size, int r0, int r1, const float *backgrounds,
+                                const void *workspace, size_t workspace_bytes, const void *isect_buf, size_t isect_bytes,
+                                const int64_t *host_info, const float *render_colors, const float *render_alphas,
+                                const float *v_render_colors, const float *v_render_alphas, float *rows, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t M = host_info[0], n_xl = host_info[4];
+    MS_REQUIRE(M > 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_bwd: bad intersection count %lld", (long long)M);
+    MS_REQUIRE(workspace && isect_buf && render_alphas && render_colors && v_render_colors && rows, MS_ERR_INVALID_ARG,
+               "render_bwd: null pointer");
+    MS_REQUIRE(CDIM == 3 && tile_size % 16 == 0, MS_ERR_INVALID_ARG, "render_bwd: the quad-wave backward takes 3 channels and 16-px blocks");
+    MS_REQUIRE(!(host_info[7] & 8), MS_ERR_INVALID_ARG, "render_bwd: the frame's lists are block lists of a split frame");
+    const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+    const WsLayout L = ws_layout(N, tw, th);
+    MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_bwd: workspace %zu < %zu", workspace_bytes, L.total);
+    const char *ws = (const char *)workspace;
+    const int32_t *ranges = (const int32_t *)(ws + L.off_ranges);
+    size_t ids_off;
+    if (host_info[7] & 4) {
+        ids_off = ms::align_up((size_t)M * 8, 256) * (n_xl > 0 && !(host_info[7] & 1024) ? 2 : 1);
+    } else {
+        MS_REQUIRE(isect_bytes > 512, MS_ERR_WORKSPACE, "render_bwd: intersection buffer too small");
+        int64_t cap = (int64_t)((isect_bytes - 512) / 12);
+        cap = cap > 0x7fffffffll ? 0x7fffffffll : cap;
+        ids_off = ms::align_up((size_t)cap * 8, 256);
+    }
+    MS_REQUIRE(ids_off + (size_t)M * 4 <= isect_bytes, MS_ERR_WORKSPACE, "render_bwd: intersection buffer %zu does not hold %lld ids",
+               isect_bytes, (long long)M);
+    const int32_t *ids = (const int32_t *)((const char *)isect_buf + ids_off);
+    const void *records = (const void *)(ws + L.off_records);
+    MS_HIP(hipMemsetAsync(rows, 0, (size_t)N * 16 * sizeof(float), stream));
+    // a lazily sorted frame: the lists are sorted as deep as the forward rasteriser walked them -- the tiles whose
+    // front ran out were redone by the forward's clean-up pass and are this call's second launch (normally empty)
+    ms::LazyLists ll;
+    ms::isect_lazy_arrays(const_cast<char *>(ws) + L.off_isect, N, tw, th, &ll);
+    const bool fronts = (host_info[7] & 512) != 0;
+    const int32_t *order = ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr;
+    if (int rc = ms::rasterize_bwd_quads(N, M, records, backgrounds, W, H, tile_size, ranges, ids, 1,
+                                         fronts ? ll.front_count : nullptr, ll.front_threshold, fronts ? ll.redo_flag : nullptr,
+                                         render_colors, render_alphas, v_render_colors, v_render_alphas, rows, order, stream_, r0, r1))
+        return rc;
+    if (fronts)
+        if (int rc = ms::rasterize_bwd_redo(N, M, records, backgrounds, W, H, tile_size, ranges,
+                                            (uint64_t *)const_cast<void *>(isect_buf), ids, ll.redo_list, ll.redo_count, ll.redo_flag,
+                                            render_colors, render_alphas, v_render_colors, v_render_alphas, rows, stream_))
+            return rc;
+    return MS_OK;
+}
+
+extern "C" size_t ms_render_bwd_rows_bytes(int64_t N) { return ms::align_up((size_t)(N > 0 ? N : 1) * 16 * sizeof(float), 256); }
+
+extern "C" int ms_render_bwd_rows(int64_t N, int CDIM, int W, int H, int tile_size, int tile_row_begin, int tile_row_end,
+                                  const float *backgrounds, const void *workspace, size_t workspace_bytes, const void *isect_buf,
+                                  size_t isect_bytes, const int64_t *host_info, const float *render_colors,
+                                  const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
+                                  float *rows, void *stream) {
+    MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && host_info && rows, MS_ERR_INVALID_ARG, "render_bwd_rows: bad argument");
+    if (N == 0) return MS_OK;
+    if (host_info[6] == 0 || host_info[0] == 0) {   // nothing on the grid / no pair in the band: no gradient from this band
+        MS_HIP(hipMemsetAsync(rows, 0, (size_t)N * 16 * sizeof(float), (hipStream_t)stream));
+        return MS_OK;
+    }
+    return render_bwd_rows_impl(N, CDIM, W, H, tile_size, tile_row_begin, tile_row_end, backgrounds, workspace, workspace_bytes,
+                                isect_buf, isect_bytes, host_info, render_colors, render_alphas, v_render_colors, v_render_alphas,
+                                rows, stream);
+}
+
+extern "C" int ms_render_bwd_finish(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
+                                    const float *opacities, int CDIM, const float *viewmat, float fx, float fy, float cx, float cy,
+                                    int W, int H, float eps2d, const float *rows, float *v_means3d, float *v_scales, float *v_quats,
+                                    float *v_opacities, float *v_colors, void *stream) {
+    MS_REQUIRE(N >= 0 && CDIM == 3 && v_means3d && v_scales && v_quats && v_opacities && v_colors, MS_ERR_INVALID_ARG,
+               "render_bwd_finish: bad argument");
+    if (N == 0) return MS_OK;
+    MS_REQUIRE(rows && opacities, MS_ERR_INVALID_ARG, "render_bwd_finish: null pointer");
+    return ms::project_bwd_from_rows(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, nullptr, rows, CDIM,
+                                     v_means3d, v_scales, v_quats, v_colors, v_opacities, stream, opacities);
+}
+
 extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
                              const float *opacities, const float *colors, int CDIM, const float *viewmat, float fx, float fy,
                              float cx, float cy, int W, int H, float eps2d, int tile_size, const float *backgrounds,
@@ -641,22 +722,9 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     // (MOJOSPLAT_BWD_QUADS=0: the older kernel, which needs last_ids)
     static const int quads_on = [] { const char *e = getenv("MOJOSPLAT_BWD_QUADS"); return e ? atoi(e) != 0 : 1; }();
     if (render_colors && records && packed_rows && tile_size % 16 == 0 && (quads_on || !last_ids)) {
-        MS_HIP(hipMemsetAsync(bw, 0, (size_t)N * 16 * sizeof(float), stream));
-        // a lazily sorted frame: the lists are sorted as deep as the forward rasteriser walked them -- the tiles whose
-        // front ran out were redone by the forward's clean-up pass and are this call's second launch (normally empty)
-        ms::LazyLists ll;
-        ms::isect_lazy_arrays(const_cast<char *>(ws) + L.off_isect, N, tw, th, &ll);
-        const bool fronts = (host_info[7] & 512) != 0;
-        const int32_t *order = ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr;
-        if (int rc = ms::rasterize_bwd_quads(N, M, records, backgrounds, W, H, tile_size, ranges, ids, 1,
-                                             fronts ? ll.front_count : nullptr, ll.front_threshold, fronts ? ll.redo_flag : nullptr,
-                                             render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw, order, stream_))
+        if (int rc = render_bwd_rows_impl(N, CDIM, W, H, tile_size, 0, th, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes,
+                                          host_info, render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw, stream_))
             return rc;
-        if (fronts)
-            if (int rc = ms::rasterize_bwd_redo(N, M, records, backgrounds, W, H, tile_size, ranges,
-                                                (uint64_t *)const_cast<void *>(isect_buf), ids, ll.redo_list, ll.redo_count, ll.redo_flag,
-                                                render_colors, render_alphas, v_render_colors, v_render_alphas, (float *)bw, stream_))
-                return rc;
         if (mid_event) MS_HIP(hipEventRecord((hipEvent_t)mid_event, stream));
         return ms::project_bwd_from_rows(N, means3d, scales, scales_are_log, quats, viewmat, fx, fy, cx, cy, W, H, eps2d, nullptr,
                                          (const float *)bw, CDIM, v_means3d, v_scales, v_quats, v_colors, v_opacities, stream_, opacities);

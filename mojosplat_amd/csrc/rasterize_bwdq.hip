@@ -77,6 +77,7 @@ struct BwdQArgs {
     float *packed;                  // f32[N][kRowQ], zeroed by the caller
     const int32_t *order;           // the binning grid's tiles, heaviest first (or null: image order)
     int W, H, ts, tw, nsx, nsub, ntiles, ngrid, max_isects, n_gauss;
+    int tile0;                      // first tile of the band the launch covers (image-order launches; an order lists its own tiles)
 };
 
 struct BwdQStage {
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(64, MS_BWDQ_WAVES) void k_rasterize_bwd_quads(BwdQA
         if (wg >= A.ntiles * A.nsub) return;
         tile = wg / A.nsub;
         sub = wg - tile * A.nsub;
+        tile += A.tile0;
     }
     if (A.skip_flag && A.skip_flag[tile]) return;
     bwd_quad(A, tile, sub, part, s_stage);
@@ -570,7 +572,7 @@ int ms::rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const flo
                             const int32_t *tile_ranges, const int32_t *ids, int id_stride, const int32_t *front_count,
                             int front_threshold, const int32_t *skip_flag, const float *render_colors,
                             const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
-                            float *packed_rows, const int32_t *order, void *stream) {
+                            float *packed_rows, const int32_t *order, void *stream, int tile_row_begin, int tile_row_end) {
     MS_REQUIRE(N > 0 && M > 0 && M <= 0x7fffffffll && N <= 0x3ffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd_quads: bad N/M");   // (rows are addressed by 32-bit byte offsets)
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0 && tile_size % 16 == 0, MS_ERR_INVALID_ARG,
                "rasterize_bwd_quads: the tile size must be a multiple of 16");
@@ -590,7 +592,13 @@ int ms::rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const flo
     const int th = (H + tile_size - 1) / tile_size;
     A.nsx = tile_size / 16;
     A.nsub = A.nsx * A.nsx;
-    const int64_t tiles = (int64_t)A.tw * th;
+    // a band of tile rows (a multi-GPU rank's differentiable band frame: ranges and order exist for its tiles only)
+    if (tile_row_end < 0) tile_row_end = th;
+    MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th, MS_ERR_INVALID_ARG,
+               "rasterize_bwd_quads: bad tile row band [%d,%d) of %d", tile_row_begin, tile_row_end, th);
+    if (tile_row_end == tile_row_begin) return MS_OK;
+    A.tile0 = tile_row_begin * A.tw;
+    const int64_t tiles = (int64_t)A.tw * (tile_row_end - tile_row_begin);
     MS_REQUIRE(tiles * A.nsub * 4 <= 0x7fffffff, MS_ERR_TOO_LARGE, "rasterize_bwd_quads: too many tiles");
     A.ntiles = (int)tiles;
     A.ngrid = order ? (int)(((tiles + 7) / 8) * 8 * A.nsub) : (int)(tiles * A.nsub);
@@ -631,6 +639,7 @@ int ms::rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const floa
     A.nsub = A.nsx * A.nsx;
     A.ntiles = A.tw * ((H + tile_size - 1) / tile_size);
     A.ngrid = 0;
+    A.tile0 = 0;
     A.max_isects = (int)M;
     A.n_gauss = (int)N;
     R.keys = keys; R.redo_list = redo_list; R.redo_count = redo_count; R.redo_flag = redo_flag;

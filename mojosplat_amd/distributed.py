@@ -540,3 +540,156 @@ def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, 
         work.wait()
         return full[:C]
     return PendingFrame(finalize=done) if async_op else done()
+
+
+# ---- sharded TRAINING step ("per-Gaussian grads need one all-reduce") -----------------------------
+class _ReduceGrad(torch.autograd.Function):
+    """Identity forward; the gradient is summed over the ranks on its way back (injected-stage path: each rank's autograd
+    yields the gradient of ITS band's pixels only)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+class _GatherBands(torch.autograd.Function):
+    """Forward: this rank's band rows [y0, y1) of `full_like` come from `band_img`, the others' from an all-gather of the
+    padded slabs; backward: the band's rows of dL/dimage (every rank computes the same loss on the same full image)."""
+
+    @staticmethod
+    def forward(ctx, band_img, H, slab, rank, world, group):
+        W, C = band_img.shape[1], band_img.shape[2]
+        buf = torch.zeros((world * slab, W, C), dtype=band_img.dtype, device=band_img.device)
+        y0 = min(rank * slab, H)
+        y1 = min(y0 + slab, H)
+        buf[y0:y1] = band_img[y0:y1]
+        dist.all_gather_into_tensor(buf.view(-1), buf[rank * slab:(rank + 1) * slab].reshape(-1).clone(), group=group)
+        ctx.rows = (y0, y1, band_img.shape[0])
+        return buf[:H].clone()
+
+    @staticmethod
+    def backward(ctx, v):
+        y0, y1, Hb = ctx.rows
+        g = torch.zeros((Hb,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        g[y0:y1] = v[y0:y1]
+        return g, None, None, None, None, None
+
+
+class _RenderBandHip(torch.autograd.Function):
+    """A rank's differentiable band frame on the HIP path: ms_render_fwd with render_alphas over the band's tile rows (own
+    scratch, lazily sorted fronts, the inference frame's binning), the framebuffer all-gather; backward: the band's
+    backward rasteriser into the packed per-Gaussian rows (ms_render_bwd_rows), ONE all_reduce of the rows over the
+    ranks, the backward projection on the summed rows (ms_render_bwd_finish) -- identical gradients on every rank."""
+
+    @staticmethod
+    def forward(ctx, means3d, scales, quats, opacities, colors, background, camera, tile_size, rank, world, group):
+        import numpy as np
+        from ._fused import WHOLE, _Frame
+        H, W = camera.H, camera.W
+        th = -(-H // tile_size)
+        rows, bands = band_plan(th, world)
+        band = _band_of(bands[rank], th)
+        slab = rows * tile_size
+        dev = means3d.device
+        buf = torch.empty((max(world * slab, H), W, 3), dtype=torch.float32, device=dev)
+        frame = _Frame(means3d.detach(), scales.detach(), quats.detach(), opacities.detach(), colors.detach(), camera, background,
+                       tile_size, None, band, buf, 0, own=True, own_last=False)
+        info = {}
+        _, M = frame.finish(WHOLE, info)
+        if world > 1:
+            dist.all_gather_into_tensor(buf[:world * slab], buf[rank * slab:(rank + 1) * slab], group=group)
+        img = buf[:H]
+        ctx.empty = info["on_grid"] == 0   # (a differentiable frame is never pre-culled: the count is the whole frame's, the same on every rank)
+        ctx.camera, ctx.tile_size, ctx.band, ctx.group, ctx.world = camera, tile_size, band, group, world
+        m3, sc, qu, op, col, bg = frame.keep[:6]
+        ctx.scratch = (frame.ws, frame.isect, np.array(frame.st["host_np"], dtype=np.int64, copy=True))
+        ctx.save_for_backward(m3, sc, qu, op, col, bg, frame.alphas, img)
+        if ctx.empty:
+            return torch.zeros_like(img)   # zeros, not the background (reference render.py:73-76)
+        return img
+
+    @staticmethod
+    def backward(ctx, v_img):
+        from . import _hip
+        from .projection import EPS2D
+        m3, sc, qu, op, col, bg, alphas, img = ctx.saved_tensors
+        cam, ts, (r0, r1) = ctx.camera, ctx.tile_size, ctx.band
+        ws, isect, host = ctx.scratch
+        L = _hip.lib()
+        N = m3.shape[0]
+        dev = m3.device
+        z = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)
+        v_means3d, v_scales, v_quats, v_opac, v_colors = z(N, 3), z(N, 3), z(N, 4), z(N), z(N, 3)
+        if ctx.empty or N == 0:
+            return (torch.zeros_like(m3), torch.zeros_like(sc), torch.zeros_like(qu), torch.zeros_like(op), torch.zeros_like(col),
+                    None if bg is None else torch.zeros_like(bg), None, None, None, None, None)
+        v_img = _hip.f32c(v_img)
+        rows = torch.empty(L.ms_render_bwd_rows_bytes(N) // 4, dtype=torch.float32, device=dev)
+        vm = cam._viewmat_f32().to(dev)
+        with _hip.on_device(dev):
+            _hip.check(L.ms_render_bwd_rows(N, 3, cam.W, cam.H, ts, r0, r1, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
+                                            0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(img), _hip.ptr(alphas),
+                                            _hip.ptr(v_img), None, _hip.ptr(rows), _hip.stream(dev)), "ms_render_bwd_rows")
+            if ctx.world > 1:
+                dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=ctx.group)   # 64 bytes per Gaussian: the one exchange of the step
+            _hip.check(L.ms_render_bwd_finish(N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(op), 3, _hip.ptr(vm), cam.fx,
+                                              cam.fy, cam.cx, cam.cy, cam.W, cam.H, EPS2D, _hip.ptr(rows), _hip.ptr(v_means3d),
+                                              _hip.ptr(v_scales), _hip.ptr(v_quats), _hip.ptr(v_opac), _hip.ptr(v_colors),
+                                              _hip.stream(dev)), "ms_render_bwd_finish")
+        v_bg = None
+        if bg is not None and ctx.needs_input_grad[5]:
+            y0, y1 = min(r0 * ts, cam.H), min(r1 * ts, cam.H)
+            v_bg = ((1.0 - alphas[y0:y1])[..., None] * v_img[y0:y1]).sum(dim=(0, 1))
+            if ctx.world > 1:
+                dist.all_reduce(v_bg, op=dist.ReduceOp.SUM, group=ctx.group)
+        return v_means3d, v_scales, v_quats, v_opac, v_colors, v_bg, None, None, None, None, None
+
+
+def render_gaussians_trainable_sharded(means3d, scales, quats, opacities, features, camera: Camera, background_color=None,
+                                       tile_size: int = 16, group=None, stages=None):
+    """The differentiable twin of render_gaussians_sharded: every rank returns the full (H, W, 3) image and, after
+    backward(), the FULL gradients of its (identical) inputs -- the training step of one frame cut into tile-row bands.
+    Rank r renders and differentiates only its band; the exchanges are the framebuffer all-gather of the forward and ONE
+    all-reduce of the per-Gaussian gradient rows in the backward.  Inputs, camera and the loss
+    must be identical on all ranks.  Bands are equal tile-row bands at the given tile size (which is also the binning
+    grid here: a differentiable band keeps whole tile rows).
+
+    `stages`: CPU tests inject differentiable torch stage functions (oracle/torch_oracle.py) --
+        project(means3d, scales, quats, opacities, camera) -> means2d, conics, depths, radii (radii / ids non-differentiable)
+        bin(means2d, radii, depths, tile_size, tw, th) -> ids, tile_ranges
+        raster(means2d, conics, colors, opacities, bg, ranges, ids, camera, tile_size) -> (H, W, C) image
+    The reference has no counterpart (no backward: render.py:11; no distributed path)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = means3d.device
+    C = features.shape[-1]
+    H, W = camera.H, camera.W
+    th = -(-H // tile_size)
+    bg = torch.zeros(C, device=dev) if background_color is None else torch.as_tensor(background_color, dtype=torch.float32, device=dev)
+    if stages is None:
+        from . import _hip
+        _hip.require_cuda(means3d, scales, quats, opacities, features, what="gaussian tensor")
+        if C != 3 or features.dtype != torch.float32 or tile_size % 16 != 0:
+            raise ValueError("render_gaussians_trainable_sharded: the HIP path takes three float32 channels and a tile size that is a multiple of 16")
+        return _RenderBandHip.apply(means3d, scales, quats, opacities.reshape(-1), features, bg, camera, tile_size, rank, world, group)
+    rows, bands = band_plan(th, world)
+    slab = rows * tile_size
+    if world > 1:
+        means3d, scales, quats, opacities, features = (_ReduceGrad.apply(t, group) for t in (means3d, scales, quats, opacities, features))
+    means2d, conics, depths, radii = stages.project(means3d, scales, quats, opacities, camera)
+    tw = -(-W // tile_size)
+    with torch.no_grad():
+        ids, ranges = stages.bin(means2d.detach(), radii, depths.detach(), tile_size, tw, th)
+    if ids.numel() == 0:
+        return (means3d.sum() + features.sum()) * 0 + torch.zeros(H, W, C, dtype=features.dtype, device=dev)
+    img = stages.raster(means2d, conics, features, opacities, bg.to(features.dtype), ranges, ids, camera, tile_size)
+    if world == 1:
+        return img
+    return _GatherBands.apply(img, H, slab, rank, world, group)

@@ -264,3 +264,74 @@ def test_balance_weights_use_one_unit_for_all_ranks():
     # torch tensors as the live path passes them (rec.tolist() of the gathered int64 records)
     rec = torch.tensor(mixed, dtype=torch.int64)
     assert D.balance_weights(rec.tolist()) == (w, False)
+
+
+# ---- the sharded TRAINING step (round 5): injected differentiable stages, world 2 over gloo ---------------------------------
+def train_stages():
+    """Differentiable CPU stages: the float64 torch restatement (oracle/torch_oracle.py) for what carries gradients, the C
+    oracle for the integer work (radii, lists) -- test infrastructure standing in for the HIP kernels."""
+    from oracle import torch_oracle
+
+    def project(m, s, q, o, cam):
+        m2, con, dep = torch_oracle.project(m, s, q, cam.view_matrix.double(), cam.fx, cam.fy, cam.cx, cam.cy, cam.W, cam.H)
+        out = oracle.project_fwd(m.detach().float().numpy(), s.detach().float().numpy(), q.detach().float().numpy(),
+                                 o.detach().float().numpy(), cam.view_matrix.numpy(), cam.fx, cam.fy, cam.cx, cam.cy, cam.W, cam.H,
+                                 near=cam.near, far=cam.far)
+        return m2, con, dep, torch.from_numpy(out[3])
+
+    def bin_(m2, rad, dep, ts, tw, th):
+        ids, ranges = oracle.bin_tiles(m2.float().numpy(), rad.numpy(), dep.float().numpy(), th * ts, tw * ts, ts)
+        return torch.from_numpy(ids), torch.from_numpy(ranges)
+
+    def raster(m2, con, col, op, bg, ranges, ids, cam, ts):
+        img, _ = torch_oracle.rasterize(m2, con, col, op, bg, ranges, ids, cam.H, cam.W, ts)
+        return img
+    return Stages(project=project, bin=bin_, raster=raster)
+
+
+def _train_step(world_call, H, W):
+    from mojosplat_amd.distributed import render_gaussians_trainable_sharded
+    sc, cam = randscene_v1(300, W, H, ell=-2.5, seed=7)
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    leaves = [sc[k].double().clone().requires_grad_(True) for k in names]
+    v_img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).double()
+    img = render_gaussians_trainable_sharded(*leaves, cam, background_color=torch.tensor([0.1, 0.2, 0.3]).double(),
+                                             stages=train_stages())
+    (img * v_img).sum().backward()
+    return img.detach().numpy().copy(), [l.grad.numpy().copy() for l in leaves]
+
+
+def _worker_train(rank, world, port, H, W, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _train_step(True, H, W))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (72, 80)])
+def test_sharded_training_step_equals_the_single_process_step(H, W):
+    """render_gaussians_trainable_sharded with injected differentiable stages, two ranks over gloo: every rank returns the
+    full image and, after backward(), the FULL gradients -- each rank differentiates its band's pixels, the per-Gaussian
+    gradients are summed over the ranks -- equal to the single-process step (float64: to rounding)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_train, args=(r, 2, port, H, W, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, img, grads = q.get(timeout=240)
+        got[r] = (img, grads)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_img, ref_grads = _train_step(False, H, W)     # no process group: world 1
+    assert np.abs(ref_img).max() > 0 and all(np.abs(g).max() > 0 for g in ref_grads)
+    for r in range(2):
+        img, grads = got[r]
+        np.testing.assert_allclose(img, ref_img, rtol=0, atol=1e-12)
+        for name, g, gr in zip(("means3d", "scales", "quats", "opacities", "features"), grads, ref_grads):
+            np.testing.assert_allclose(g, gr, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(gr).max()), err_msg=f"rank {r} {name}")

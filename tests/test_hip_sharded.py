@@ -50,3 +50,20 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["rccl"]["world"] == 2 and out["rccl"]["backend"] == "gloo"
     assert out["verified"] is True and out["max_abs_vs_stagewise"] == 0.0 and out["value"] > 0
     assert "REHEARSAL" in out["data"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_training_step_with_a_process_group(world):
+    """Round 5: render_gaussians_trainable_sharded on the HIP path -- each rank's band forward with its alphas kept, the band's
+    backward rasteriser, ONE all-reduce of the per-Gaussian gradient rows, the backward projection on the sum (SURVEY.md
+    section 8(e)); image bit for bit and gradients within the float atomics' order of the single-GPU step."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "scripts", "sharded_train_gloo_gpu.py")]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    for rank in range(world):
+        assert f"rank {rank}/{world}: sharded training steps equal the single-GPU step" in out, out[-3000:]
