@@ -148,6 +148,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef MS_RASTER_GROUP
 #define MS_RASTER_GROUP 2
 #endif
+#ifndef MS_RASTER_EXPANDED
+#define MS_RASTER_EXPANDED 0   // 1: the measurement variant of profiles/r05_raster_expanded.md (never the shipped library)
+#endif
 #ifndef MS_RASTER_UNROLL
 #define MS_RASTER_UNROLL 2
 #endif
@@ -202,6 +205,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     const int bx = tile_x * A.ts + sub_x * 16, by = tile_y * A.ts + sub_y * 16;
     const int ox = sub_x * 16 + lx, oy = sub_y * 16 + ly;
     const float px0 = (float)(bx + lx) + 0.5f, py0 = (float)(by + ly) + 0.5f;
+#if MS_RASTER_EXPANDED
+    const float ux = (float)lx - 3.5f, uy = (float)ly - 3.5f;   // the pixel centre's offset from its quad's centre
+#endif
 
     constexpr float kInf = __builtin_huge_valf();
     // kq: the lane's multiplier of the flush select (ms::kFlushK while the pixel is live, 0 once it has stopped
@@ -310,6 +316,12 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         unsigned long long B[NQ];
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) B[qi] = __ballot((mask >> qi) & 1);
+#if MS_RASTER_EXPANDED
+        // (measurement variant, round 5: log2(alpha) as the quadratic EXPANDED about the quad's centre -- five FMAs on two
+        // lane constants instead of two subtractions + five: the staging lane leaves a', b', c', D, E, F per reached quad.
+        // Batches that need the sigma >= 0 test keep the plain records.)
+        const bool expanded = PACKED && __ballot(npd) == 0;
+#endif
 
         wave_lds_sync();  // LDS reads of the previous batch are complete
         // every reached quad gets the record at its rank among the quad's entries (list order is kept); the
@@ -326,8 +338,22 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
             const int n = __popcll(b);
             if ((mask >> qi) & 1) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+#if MS_RASTER_EXPANDED
+                if (expanded) {
+                    const int q = qbase + qi;
+                    const float U = r_a.x - ((float)(bx + (q & 1) * 8) + 4.0f), V = r_a.y - ((float)(by + (q >> 1) * 8) + 4.0f);
+                    const float D = -fmaf(2.0f * r_a.z, U, r_a.w * V), E = -fmaf(2.0f * r_b.x, V, r_a.w * U);
+                    const float F = fmaf(U, fmaf(r_a.z, U, r_a.w * V), fmaf(r_b.x * V, V, r_b.y));
+                    S.a[pos] = make_float4(r_a.z, r_a.w, r_b.x, D);
+                    S.b[pos] = make_float4(E, F, r_b.z, r_b.w);
+                } else {
+                    S.a[pos] = r_a;
+                    S.b[pos] = r_b;
+                }
+#else
                 S.a[pos] = r_a;
                 S.b[pos] = r_b;
+#endif
                 if constexpr (CP == 3) {
                     if constexpr (AUX) reinterpret_cast<float2 *>(S.col)[pos] = make_float2(r_c.x, r_c.y);
                     else S.col[pos] = r_c.x;
@@ -405,9 +431,20 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                     float m[kGroup], v[kGroup];
 #pragma unroll
                     for (int j = 0; j < kGroup; ++j) {
+#if MS_RASTER_EXPANDED
+                        float la;
+                        if constexpr (!CHECK && PACKED) {
+                            // a' ux^2 + b' ux uy + c' uy^2 + D ux + E uy + F, Horner: (a, b, c, D) | (E, F, ...)
+                            la = fmaf(ux, fmaf(ra[j].x, ux, fmaf(ra[j].y, uy, ra[j].w)), fmaf(uy, fmaf(ra[j].z, uy, rb[j].x), rb[j].y));
+                        } else {
+                            const float dx = ra[j].x - px, dy = ra[j].y - py;
+                            la = fmaf(dx, fmaf(ra[j].z, dx, ra[j].w * dy), fmaf(rb[j].x * dy, dy, rb[j].y));
+                        }
+#else
                         const float dx = ra[j].x - px, dy = ra[j].y - py;
                         // log2(alpha) = log2(o) - sigma*log2(e), with log2(o) riding in the FMA chain
                         const float la = fmaf(dx, fmaf(ra[j].z, dx, ra[j].w * dy), fmaf(rb[j].x * dy, dy, rb[j].y));
+#endif
                         float alpha = __builtin_amdgcn_exp2f(la);
                         if constexpr (CHECK) {
                             alpha = fminf(ms::kMaxAlpha, alpha);
