@@ -298,3 +298,31 @@ def test_differentiable_frame_at_any_tile_size(device, ts):
         assert torch.equal(r[0], res[0][0])
         for name, a, b in zip(names, r[1], res[0][1]):
             assert_grad_close(name, a, b, rel=5e-4, **FUSED)
+
+
+def test_render_gaussians_itself_is_differentiable(device):
+    """Round 5 ("so render_gaussians can drop @torch.no_grad()"): the reference's entry point,
+    called with autograd enabled on inputs that require gradients, IS the differentiable frame -- same image, same gradients
+    as render_gaussians_trainable -- and stays the inference frame (no graph) for plain tensors or under no_grad."""
+    import mojosplat_amd as ms
+    names = ("means3d", "scales", "quats", "opacities", "features")
+    sc, cam = randscene_v1(5000, 256, 160, ell=-3.0, seed=3, device=device)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=device)
+    v_img = torch.rand(cam.H, cam.W, 3, generator=torch.Generator().manual_seed(8)).to(device)
+    res = []
+    for fn in (ms.render_gaussians, render_gaussians_trainable):
+        leaves = [sc[k].clone().requires_grad_(True) for k in names]
+        img = fn(*leaves, cam, background_color=bg)
+        assert img.requires_grad
+        img.backward(v_img)
+        res.append((img.detach(), [l.grad for l in leaves]))
+    assert torch.equal(res[0][0], res[1][0])
+    for name, a, b in zip(names, res[0][1], res[1][1]):
+        assert_grad_close(name, a, b, rel=1e-4, **FUSED)
+    plain = ms.render_gaussians(*[sc[k] for k in names], cam, background_color=bg)
+    assert not plain.requires_grad and torch.equal(plain, res[0][0])
+    with torch.no_grad():
+        leaves = [sc[k].clone().requires_grad_(True) for k in names]
+        assert not ms.render_gaussians(*leaves, cam, background_color=bg).requires_grad
+    with pytest.raises(ValueError):
+        ms.render_gaussians(*[sc[k].clone().requires_grad_(True) for k in names], cam, background_color=bg, async_op=True)
