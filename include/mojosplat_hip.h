@@ -252,12 +252,16 @@ int ms_config_depth_cut(int mode, long long min_pairs);
  *                         band's pixels (zeroed by the call).  Sums over disjoint bands ADD: a rank's caller all-reduces
  *                         the rows over the ranks ("per-Gaussian grads need one all-reduce") ...
  *   ms_render_bwd_finish: ... and the backward projection turns the summed rows into the gradients, identically on every rank.
- * ms_render_bwd == rows(0, tile_h) + finish.  No reference counterpart (render.py:11; README.md:145). */
+ * ms_render_bwd == rows(0, tile_h) + finish.  redo_counts_host (nullable): pinned HOST i32[2] that a lazily sorted frame's
+ * redo launch fills with the frame's clean-up counts (as ms_render_redo_counts would, without a copy of its own; valid once an
+ * event recorded behind the call has completed; untouched for a fully sorted frame).
+ * No reference counterpart (render.py:11; README.md:145). */
 size_t ms_render_bwd_rows_bytes(int64_t N);
 int ms_render_bwd_rows(int64_t N, int CDIM, int W, int H, int tile_size, int tile_row_begin, int tile_row_end,
                        const float *backgrounds, const void *workspace, size_t workspace_bytes, const void *isect_buf,
                        size_t isect_bytes, const int64_t *host_info, const float *render_colors, const float *render_alphas,
-                       const float *v_render_colors, const float *v_render_alphas, float *rows, void *stream);
+                       const float *v_render_colors, const float *v_render_alphas, float *rows, int32_t *redo_counts_host,
+                       void *stream);
 int ms_render_bwd_finish(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,
                          const float *opacities, int CDIM, const float *viewmat, float fx, float fy, float cx, float cy,
                          int W, int H, float eps2d, const float *rows, float *v_means3d, float *v_scales, float *v_quats,

@@ -215,16 +215,21 @@ def own_mode(st, shape):
     return bool(m["full"]), int(m["level"])
 
 
-def own_report(st, dev, shape, mode, level, heavy, ws, grid):
-    """Behind a differentiable frame's backward: ask for the frame's redo counts (asynchronously, on the current stream)."""
+def own_mirror(st):
+    """The thread's pinned i32[2] that a differentiable frame's backward fills with its clean-up counts (ms_render_bwd_rows)."""
     buf = st.get("own_redo_buf")
     if buf is None:
         buf = st["own_redo_buf"] = torch.zeros(2, dtype=torch.int32).pin_memory()
         st["own_redo_np"] = buf.numpy()
         st["own_redo_ev"] = torch.cuda.Event()
-    N, tw, th = grid
-    _hip.check(_hip.lib().ms_render_redo_counts(_hip.ptr(ws), ws.numel(), N, tw, th, ctypes.c_void_p(buf.data_ptr()),
-                                                _hip.stream(dev)), "ms_render_redo_counts")
+    return buf
+
+
+def own_report(st, shape, mode, level, heavy):
+    """Behind a differentiable frame's backward (whose redo launch has written the frame's clean-up counts into own_mirror's
+    words): an event on the current stream marks when they are valid; the next differentiable frame that finds it complete
+    applies the lane's rule (own_mode)."""
+    own_mirror(st)
     st["own_redo_ev"].record()
     st["own_pending"] = dict(ev=st["own_redo_ev"], buf=st["own_redo_np"], shape=shape, lazy=not (mode & FULL_SORT), level=level,
                              heavy=heavy)

@@ -115,7 +115,7 @@ class BandFrame(ctypes.Structure):
 
 _SIGNATURES["ms_render_bwd_rows_bytes"] = (c_size_t, [c_int64])
 _SIGNATURES["ms_render_bwd_rows"] = (c_int, [c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
-                                             c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p])
+                                             c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p])
 _SIGNATURES["ms_render_bwd_finish"] = (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                                c_float, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p])

@@ -173,9 +173,35 @@ class _RenderFusedHip(torch.autograd.Function):
         with _hip.on_device(dev):
             if bev:
                 bev[0].record()
+            lean_own = ctx.own_learn is not None and C == 3 and last is None
+            if lean_own:
+                # (round 5: the two halves of ms_render_bwd, so that a lazily sorted frame's redo launch can leave the frame's
+                # clean-up counts in this thread's pinned words on its way -- what the next differentiable frame learns from)
+                from . import _fused
+                st, shape, mode, level, heavy, grid = ctx.own_learn
+                fronts = bool(int(host[7]) & 512)
+                mirror = _fused.own_mirror(st) if fronts else None
+                rows = bws[:L.ms_render_bwd_rows_bytes(N)].view(torch.float32)
+                th_ = -(-cam.H // ts)
+                _hip.check(L.ms_render_bwd_rows(N, 3, cam.W, cam.H, ts, 0, th_, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
+                                                0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(img), _hip.ptr(alphas),
+                                                _hip.ptr(v_img), None, _hip.ptr(rows),
+                                                None if mirror is None else ctypes.c_void_p(mirror.data_ptr()), _hip.stream(dev)),
+                           "ms_render_bwd_rows")
+                if bev:
+                    bev[1].record()
+                _hip.check(L.ms_render_bwd_finish(N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(op), 3, _hip.ptr(vm), cam.fx,
+                                                  cam.fy, cam.cx, cam.cy, cam.W, cam.H, EPS2D, _hip.ptr(rows), _hip.ptr(v_means3d),
+                                                  _hip.ptr(v_scales), _hip.ptr(v_quats), _hip.ptr(v_opac), _hip.ptr(v_colors),
+                                                  _hip.stream(dev)), "ms_render_bwd_finish")
+                if bev:
+                    bev[2].record()
+                if fronts:
+                    _fused.own_report(st, shape, mode, level, heavy)
             # one library call: the backward rasteriser (staging from the frame's ready-made records) and the backward
             # projection, on the scratch the forward call left behind
-            _hip.check(L.ms_render_bwd(
+            else:
+              _hip.check(L.ms_render_bwd(
                 N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(op), _hip.ptr(col), C, _hip.ptr(vm), cam.fx, cam.fy,
                 cam.cx, cam.cy, cam.W, cam.H, EPS2D, ts, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
                 0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(img) if C == 3 else None, _hip.ptr(alphas),
@@ -183,12 +209,8 @@ class _RenderFusedHip(torch.autograd.Function):
                 None, _hip.ptr(v_means3d), _hip.ptr(v_scales), _hip.ptr(v_quats), _hip.ptr(v_opac), _hip.ptr(v_colors),
                 _hip.ptr(bws), bws_bytes, ctypes.c_void_p(bev[1].cuda_event) if bev else None, _hip.stream(dev)),
                 "ms_render_bwd")
-            if bev:
+              if bev:
                 bev[2].record()
-            if ctx.own_learn is not None and (int(host[7]) & 512):   # the frame ran on lazily sorted fronts
-                from . import _fused
-                st, shape, mode, level, heavy, grid = ctx.own_learn
-                _fused.own_report(st, dev, shape, mode, level, heavy, ws, grid)
         v_bg = None
         if bg is not None and ctx.needs_input_grad[5]:
             v_bg = ((1.0 - alphas)[..., None] * v_img).sum(dim=(0, 1))

@@ -192,7 +192,7 @@ int rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const float *b
                        const int32_t *tile_ranges, uint64_t *keys, const int32_t *ids, const int32_t *redo_list,
                        const int32_t *redo_count, const int32_t *redo_flag, const float *render_colors,
                        const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
-                       float *packed_rows, void *stream);
+                       float *packed_rows, void *stream, int32_t *count_mirror = nullptr);
 
 // Block lists of a split frame (ms_render_fwd): what the sort kernels of 32-px bins write instead of
 // flatten_ids.  Bin `b` with list [start, start + n) owns block_ids[4 start, 4 (start + n)): its block q

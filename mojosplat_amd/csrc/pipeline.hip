@@ -585,9 +585,16 @@ extern "C" size_t ms_render_bwd_workspace_bytes(int64_t N, int CDIM) {
 static int render_bwd_rows_impl(int64_t N, int CDIM, int W, int H, int tile_size, int r0, int r1, const float *backgrounds,
                                 const void *workspace, size_t workspace_bytes, const void *isect_buf, size_t isect_bytes,
                                 const int64_t *host_info, const float *render_colors, const float *render_alphas,
-                                const float *v_render_colors, const float *v_render_alphas, float *rows, void *stream_) {
+                                const float *v_render_colors, const float *v_render_alphas, float *rows, void *stream_,
+                                int32_t *redo_counts_host = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t M = host_info[0], n_xl = host_info[4];
+    int32_t *count_mirror = nullptr;
+    if (redo_counts_host) {   // (mapped pinned memory: the device-side address of the same words)
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, redo_counts_host, 0) == hipSuccess) count_mirror = (int32_t *)dp;
+        else (void)hipGetLastError();
+    }
     MS_REQUIRE(M > 0 && M <= 0x7fffffffll, MS_ERR_TOO_LARGE, "render_bwd: bad intersection count %lld", (long long)M);
     MS_REQUIRE(workspace && isect_buf && render_alphas && render_colors && v_render_colors && rows, MS_ERR_INVALID_ARG,
                "render_bwd: null pointer");
@@ -625,7 +632,7 @@ static int render_bwd_rows_impl(int64_t N, int CDIM, int W, int H, int tile_size
     if (fronts)
         if (int rc = ms::rasterize_bwd_redo(N, M, records, backgrounds, W, H, tile_size, ranges,
                                             (uint64_t *)const_cast<void *>(isect_buf), ids, ll.redo_list, ll.redo_count, ll.redo_flag,
-                                            render_colors, render_alphas, v_render_colors, v_render_alphas, rows, stream_))
+                                            render_colors, render_alphas, v_render_colors, v_render_alphas, rows, stream_, count_mirror))
             return rc;
     return MS_OK;
 }
@@ -636,7 +643,7 @@ extern "C" int ms_render_bwd_rows(int64_t N, int CDIM, int W, int H, int tile_si
                                   const float *backgrounds, const void *workspace, size_t workspace_bytes, const void *isect_buf,
                                   size_t isect_bytes, const int64_t *host_info, const float *render_colors,
                                   const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
-                                  float *rows, void *stream) {
+                                  float *rows, int32_t *redo_counts_host, void *stream) {
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0 && host_info && rows, MS_ERR_INVALID_ARG, "render_bwd_rows: bad argument");
     if (N == 0) return MS_OK;
     if (host_info[6] == 0 || host_info[0] == 0) {   // nothing on the grid / no pair in the band: no gradient from this band
@@ -645,7 +652,7 @@ extern "C" int ms_render_bwd_rows(int64_t N, int CDIM, int W, int H, int tile_si
     }
     return render_bwd_rows_impl(N, CDIM, W, H, tile_size, tile_row_begin, tile_row_end, backgrounds, workspace, workspace_bytes,
                                 isect_buf, isect_bytes, host_info, render_colors, render_alphas, v_render_colors, v_render_alphas,
-                                rows, stream);
+                                rows, stream, redo_counts_host);
 }
 
 extern "C" int ms_render_bwd_finish(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,

@@ -505,11 +505,19 @@ struct BwdRedoArgs {
     BwdQArgs a;            // ids: the frame's id array (stride 1)
     uint64_t *keys;
     const int32_t *redo_list, *redo_count, *redo_flag;
+    int32_t *count_mirror;   // null, or a device-visible address of pinned host memory: receives redo_count[0..1] (the frame's caller learns from it)
 };
 
 __global__ __launch_bounds__(kRedoThreads) void k_rasterize_bwd_redo(BwdRedoArgs R) {
     __shared__ BwdQStage s_stage[kRedoThreads / 64];
     const int n_redo = *R.redo_count;
+    if (R.count_mirror && blockIdx.x == 0 && threadIdx.x == 0) {
+        // (a zero-copy store into the caller's pinned memory: visible to the host once an event behind this launch has
+        // completed -- round 5's first cut read the two words back with a copy of their own: 4.5 us of copy kernel per step)
+        R.count_mirror[0] = n_redo;
+        R.count_mirror[1] = R.redo_count[1];
+        __threadfence_system();
+    }
     if (n_redo <= 0) return;
     const int tid = threadIdx.x, w = tid >> 6;
     // (1) the tiles whose ids are sorted: a wave per (tile, block, quad)
@@ -617,7 +625,7 @@ int ms::rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const floa
                            const int32_t *tile_ranges, uint64_t *keys, const int32_t *ids, const int32_t *redo_list,
                            const int32_t *redo_count, const int32_t *redo_flag, const float *render_colors,
                            const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
-                           float *packed_rows, void *stream) {
+                           float *packed_rows, void *stream, int32_t *count_mirror) {
     MS_REQUIRE(N > 0 && M > 0 && M <= 0x7fffffffll && N <= 0x3ffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd_redo: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0 && tile_size % 16 == 0, MS_ERR_INVALID_ARG,
                "rasterize_bwd_redo: the tile size must be a multiple of 16");
@@ -643,6 +651,7 @@ int ms::rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const floa
     A.max_isects = (int)M;
     A.n_gauss = (int)N;
     R.keys = keys; R.redo_list = redo_list; R.redo_count = redo_count; R.redo_flag = redo_flag;
+    R.count_mirror = count_mirror;
     // (every workgroup leaves at once on the frames with an empty redo list -- almost all: what the launch costs then is its
     // kernel boundary, whatever the grid)
     hipLaunchKernelGGL(k_rasterize_bwd_redo, dim3(1024), dim3(kRedoThreads), 0, (hipStream_t)stream, R);

@@ -636,7 +636,7 @@ class _RenderBandHip(torch.autograd.Function):
         with _hip.on_device(dev):
             _hip.check(L.ms_render_bwd_rows(N, 3, cam.W, cam.H, ts, r0, r1, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
                                             0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(img), _hip.ptr(alphas),
-                                            _hip.ptr(v_img), None, _hip.ptr(rows), _hip.stream(dev)), "ms_render_bwd_rows")
+                                            _hip.ptr(v_img), None, _hip.ptr(rows), None, _hip.stream(dev)), "ms_render_bwd_rows")
             if ctx.world > 1:
                 dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=ctx.group)   # 64 bytes per Gaussian: the one exchange of the step
             _hip.check(L.ms_render_bwd_finish(N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(op), 3, _hip.ptr(vm), cam.fx,
