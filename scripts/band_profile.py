@@ -13,6 +13,9 @@ dev = torch.device("cuda", 0)
 sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=dev)
 bg = torch.tensor(BACKGROUND_V1, device=dev)
 g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+if os.environ.get("SCENE_ORDER") == "prepared":   # (round 5: Morton order + block bounds: scene_order.prepare_scene)
+    from mojosplat_amd.scene_order import prepare_scene
+    g = prepare_scene(*g).arrays
 for _ in range(44):
     render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(rank, world))
 torch.cuda.synchronize()
