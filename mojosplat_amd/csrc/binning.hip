@@ -539,8 +539,6 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
                                                                const float *__restrict__ block_bounds, int block_shift) {
     __shared__ uint32_t s_w[4 * 16];
     __shared__ unsigned char s_blk[kMaxBlocksPerChunk];
-    __shared__ unsigned short s_live[kMaxBlocksPerChunk];
-    __shared__ unsigned int s_nlive;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float V[12];
 #pragma unroll
@@ -593,42 +591,18 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
             s_blk[b] = keep ? 1 : 0;
         }
         __syncthreads();
-        // ... and only the blocks that passed are walked at all (the pass is a chain of load -> test -> count round trips
-        // with two barriers per 4 096 positions, not a bandwidth problem: skipping the LOADS of the failed blocks took the
-        // centre band of eight from 32.4 to 27.8 us, walking the survivors densely takes it further): their indices, compacted in order
-        if (w == 0) {
-            unsigned int n_live = 0;
-            for (int b0 = 0; b0 < nb; b0 += 64) {
-                const bool k = b0 + lane < nb && s_blk[b0 + lane];
-                const unsigned long long bal = __ballot(k);
-                if (k) s_live[n_live + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)(b0 + lane);
-                n_live += (unsigned int)__popcll(bal);
-            }
-            if (lane == 0) s_nlive = n_live;
-        }
-        __syncthreads();
     }
-    // positions of this workgroup's walk: its chunk, or -- a prepared scene -- the surviving blocks' Gaussians back to back
-    const int64_t n_walk = blocks ? ((int64_t)s_nlive << block_shift) : i1 - i0;
-    const int64_t bmask = blocks ? (((int64_t)1 << block_shift) - 1) : 0;
-    auto index_of = [&](int64_t p) __attribute__((always_inline)) -> int64_t {
-        if (p >= n_walk) return -1;
-        if (!blocks) return i0 + p;
-        const int64_t i = ((blk0 + (int64_t)s_live[p >> block_shift]) << block_shift) + (p & bmask);
-        return (i >= i0 && i < i1) ? i : -1;   // (the chunk's first and last block may stick out of it)
-    };
     // kSub sub-steps of 1024 Gaussians share one pair of barriers (the pass is a chain of load -> test -> count
     // round trips, not a bandwidth problem: LDS-staged 16-byte loads made it 1.5x SLOWER)
     constexpr int kSub = 4;
-    for (int64_t base = 0; base < n_walk; base += (int64_t)kSub * kHistThreads) {
+    for (int64_t base = i0; base < i1; base += (int64_t)kSub * kHistThreads) {
         bool keep[kSub];
         unsigned long long bal[kSub];
-        int64_t idx[kSub];
 #pragma unroll
         for (int k = 0; k < kSub; ++k) {
-            const int64_t i = idx[k] = index_of(base + (int64_t)k * kHistThreads + threadIdx.x);
+            const int64_t i = base + (int64_t)k * kHistThreads + threadIdx.x;
             keep[k] = false;
-            if (i >= 0) {
+            if (i < i1 && (!blocks || s_blk[(i >> block_shift) - blk0])) {
                 const float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
                 const float mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
                 const float my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
@@ -666,7 +640,7 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
             }
             if (keep[k])
                 seg[before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], 0u))] =
-                    (int32_t)idx[k];
+                    (int32_t)(base + (int64_t)k * kHistThreads + threadIdx.x);
             written += total;
         }
     }
