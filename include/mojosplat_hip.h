@@ -379,10 +379,16 @@ enum { MS_RENDER_WHOLE = 0, MS_RENDER_RESUME = 1, MS_RENDER_BEGIN = 2, MS_RENDER
        MS_RENDER_FULL_SORT = 0x100, /* or-ed into `resume`: no lazy sorting for this frame */
        MS_RENDER_FRONT_LEVEL = 0x200, /* x 0..3, or-ed into `resume`: lazily sorted fronts 2^level times as deep
                                         (a caller whose previous frame needed the clean-up pass, host_info[5] > 0) */
-       MS_RENDER_ROWS16 = 0x800 /* or-ed into `resume`: [tile_row_begin, tile_row_end) counts rows of 16 pixels whatever
+       MS_RENDER_ROWS16 = 0x800, /* or-ed into `resume`: [tile_row_begin, tile_row_end) counts rows of 16 pixels whatever
                                    tile_size (a multiple of 16) is: the band is binned on the tile rows that cover
                                    it and rasterised on exactly those 16-px rows -- a multi-GPU rank keeps its band
-                                   while the bin size follows the scene (32- / 64-px bins for dense scenes) */ };
+                                   while the bin size follows the scene (32- / 64-px bins for dense scenes) */
+       MS_RENDER_DEFER_CLEANUP = 0x1000 /* ms_band_frame.flags only (ms_render_fwd ignores it): the band's clean-up launches --
+                                   up to four, empty on almost every frame -- are not enqueued behind the rasteriser;
+                                   ms_render_band_finish waits for the END of the band instead of its size record, reads the
+                                   rasteriser's verdict from word 8 of the lane's pinned record (host_info must then be
+                                   i64[16]) and enqueues them only when a bin asked for them.  For bands in flight behind
+                                   each other on two lanes: the GPU has the other band to run while the host waits. */ };
 size_t ms_render_workspace_bytes(int64_t N, int tile_w, int tile_h);
 size_t ms_render_isect_bytes(int64_t M, int with_merge_scratch);
 int ms_render_fwd(int64_t N, const float *means3d, const float *scales, int scales_are_log,
@@ -458,7 +464,9 @@ int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *sca
  *                        again with resume = 1), then lane -> caller_stream (out_event); status i64[4] (HOST) = {Gaussians on
  *                        the grid -- of a pre-culled band: of its candidates --, 1 if the library pre-culled the band, pairs
  *                        in the band, the frame's flag word (host_info[7])}.
- * flags: MS_RENDER_ROWS16 / MS_RENDER_FULL_SORT / MS_RENDER_FRONT_LEVEL bits, as ms_render_fwd's `resume`.
+ * flags: MS_RENDER_ROWS16 / MS_RENDER_FULL_SORT / MS_RENDER_FRONT_LEVEL bits, as ms_render_fwd's `resume`; MS_RENDER_DEFER_CLEANUP
+ *        (the lane's host_info is then i64[16]; when the verdict is clean the finishing half enqueues NOTHING: the host has
+ *        seen the band end, so whatever it enqueues on caller_stream afterwards is behind it).
  * render_colors addresses image row 0 (rows outside the band are never touched), as for ms_render_fwd.
  * ------------------------------------------------------------------------------------- */
 typedef struct ms_scene {

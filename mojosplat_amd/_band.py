@@ -89,6 +89,11 @@ def _lane_rec(dev, slot):
     return rec
 
 
+def _defer_enabled():
+    import os
+    return os.environ.get("MOJOSPLAT_DEFER_CLEANUP", "1") != "0"
+
+
 class BandHandle:
     __slots__ = ("rec", "shape", "level", "mode", "keep", "channels", "done")
 
@@ -134,7 +139,10 @@ def band_begin(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
     f.fx, f.fy, f.cx, f.cy = camera.fx, camera.fy, camera.cx, camera.cy
     f.W, f.H = W, H
     f.eps2d, f.near_plane, f.far_plane = EPS2D, camera.near, camera.far
-    f.tile_size, f.row_begin, f.row_end, f.flags = tile_size, r0, r1, mode
+    # a band on a lane of its own (frames in flight behind each other): the clean-up launches wait for the rasteriser's verdict
+    # (MS_RENDER_DEFER_CLEANUP; MOJOSPLAT_DEFER_CLEANUP=0: enqueued behind every band as on the blocking path)
+    defer = _fused.DEFER_CLEANUP if (lane_stream is not None and _defer_enabled()) else 0
+    f.tile_size, f.row_begin, f.row_end, f.flags = tile_size, r0, r1, mode | defer
     f.backgrounds = None if bgc is None else bgc.data_ptr()
     if out_y0 is not None:
         px = tile_size if not flags else 16

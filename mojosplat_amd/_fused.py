@@ -94,7 +94,7 @@ def _dev_state(dev, lane=0):
         ev = torch.cuda.Event()
         with torch.cuda.device(dev):
             ev.record()  # materialises the hipEvent_t the library re-records for its size hand-off
-        host = torch.zeros(8, dtype=torch.int64).pin_memory()
+        host = torch.zeros(16, dtype=torch.int64).pin_memory()   # (words 8..: the band pair's deferred clean-up verdict)
         # host_np: the same pinned memory as a numpy array (reading a torch tensor element costs ~1.5 us, and a
         # frame reads eight of them)
         st = dict(ws=None, isect=None, host=host, host_np=host.numpy(), ev=ev)
@@ -165,6 +165,10 @@ def _count_frame(stats, frame, host, grew):
             stats["regen_mismatch"] = stats.get("regen_mismatch", 0) + 1
     if flags & 64:
         stats["depth_cut"] = stats.get("depth_cut", 0) + 1
+    if (flags & 4096) and not (flags & 4):   # the band pair left the clean-up launches to its finishing half (_band.py)
+        stats["cleanup_deferred"] = stats.get("cleanup_deferred", 0) + 1
+        if len(host) > 8 and int(host[8]) != 0:   # ... which found the rasteriser asking for them
+            stats["cleanup_enqueued_late"] = stats.get("cleanup_enqueued_late", 0) + 1
 
 
 WHOLE, RESUME, BEGIN, FINISH = 0, 1, 2, 3  # ms_render_fwd phases (include/mojosplat_hip.h)
@@ -172,6 +176,7 @@ RETRY_FULL_SORT = 64   # frames a lane stays on full sorts before it tries lazil
 SWAP_FULL_SORT = 4     # ... after a scene swap (nearly every heavy bin regenerated at once): fixed, short
 FULL_SORT = 0x100
 FRONT_LEVEL = 0x200  # x level (0..3): deeper lazily sorted fronts
+DEFER_CLEANUP = 0x1000  # the band pair only (_band.py): clean-up launches enqueued by the finishing half, if the rasteriser asks
 ROWS16 = 0x800       # row_range counts rows of 16 px whatever the tile size (a band keeps its rows, the bins follow the scene)
 
 

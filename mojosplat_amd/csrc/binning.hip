@@ -2079,6 +2079,8 @@ void ms::isect_lazy_arrays(void *workspace, int64_t N, int tile_w, int tile_h, m
     out->far_cur = out->far_cnt + p.T;
     out->far_start = out->far_cnt + 2 * (size_t)p.T;
     out->cut_inputs = nullptr;
+    out->verdict = nullptr;
+    out->cut_inputs = nullptr;
 }
 
 // Can a frame on this grid take the depth cut (12-byte box records, room for the cut-offs in the count kernel's LDS)?

@@ -134,7 +134,14 @@ struct LazyLists {
     uint64_t *log_keys;     // == keys, writable
     uint32_t *far_cnt, *far_cur, *far_start;
     const CutInputs *cut_inputs;   // (a HOST pointer, read when the clean-up launches are enqueued)
+    // DEFERRED clean-up (a band frame in flight behind another: ms_render_band_begin / _finish, pipeline.hip): non-null = a
+    // device-visible address of a word of the lane's pinned record.  The rasteriser stores 1 there when it puts a bin on the
+    // redo list, its launch is NOT followed by the clean-up launches, and the finishing half -- which has waited for the
+    // rasteriser -- enqueues them only if the word is set (rasterize_deferred_cleanup).
+    int32_t *verdict;
 };
+// rasterize.hip: the clean-up launches a frame enqueued with lazy.verdict set left out, on `stream`; `key` = that pointer
+int rasterize_deferred_cleanup(const void *key, void *stream);
 int far_regen(const LazyLists &lazy, int tw, int n_tiles, int64_t cap, void *stream);
 // project_bwd.hip: the backward projection straight from the backward rasteriser's packed gradient rows
 int project_bwd_from_rows(int64_t N, const float *means3d, const float *scales, int scales_are_log, const float *quats,

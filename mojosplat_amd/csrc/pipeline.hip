@@ -189,7 +189,7 @@ extern "C" int ms_render_redo_counts(const void *workspace, size_t workspace_byt
                MS_ERR_INVALID_ARG, "render_redo_counts: bad argument");
     const WsLayout L = ws_layout(N, tile_w, tile_h);
     MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_redo_counts: workspace %zu < %zu", workspace_bytes, L.total);
-    ms::LazyLists ll;
+    ms::LazyLists ll{};
     ms::isect_lazy_arrays(const_cast<char *>((const char *)workspace) + L.off_isect, N, tile_w, tile_h, &ll);
     MS_HIP(hipMemcpyAsync(host_counts, ll.redo_count, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return MS_OK;
@@ -221,6 +221,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
     int no_split = restart & 1;
     const int no_cut = (restart >> 1) & 1;
     const int phase = resume & 0xff;
+    const bool defer_cleanup = (resume & MS_RENDER_DEFER_CLEANUP) != 0;   // (the band pair only: its record has the sixteen words)
     MS_REQUIRE(phase >= MS_RENDER_WHOLE && phase <= MS_RENDER_FINISH, MS_ERR_INVALID_ARG, "render_fwd: bad phase %d",
                phase);
     MS_REQUIRE(N >= 0 && W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "render_fwd: bad sizes");
@@ -303,7 +304,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
     const int cull = ((use_records && !aux_frame && N >= 32768 && N < (1ll << 28) && 10 * (r1 - r0) < 6 * th && ms_band_cull_enabled()) ? 32 : 0) | lean;
     const int bin_flags = 1 | 2 | 4 | ((tw & 1) ? 8 : 0) | ((th & 1) ? 16 : 0) | cull;
     int32_t *bin_ranges = (int32_t *)(ws + L.off_bin_ranges), *bin_more = (int32_t *)(ws + L.off_bin_more);
-    ms::LazyLists lazy_lists;
+    ms::LazyLists lazy_lists{};
     if (lazy) ms::isect_lazy_arrays(ws + L.off_isect, N, split ? bw : tw, split ? bh : th, &lazy_lists);
     // (host_info[5] of the record left by the previous frame: the clean-up count it reported, or the buffer size
     // an exact-path frame asked for -- either way "not a quiet run of frames")
@@ -439,6 +440,13 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                 // its predecessor, and its backward walks the whole-bin sorted ids k_redo_sort leaves instead of sorting the
                 // bin's keys again in global memory: rasterize_bwdq.hip, k_rasterize_bwd_redo)
                 lazy_lists.redo_sort = (cut_stamp != 0u || prev_redos > 0 || tile_size >= 48 || aux_frame) && ms_redo_sort_enabled() ? 1 : 0;
+                // DEFERRED clean-up (MS_RENDER_DEFER_CLEANUP: ms_render_band_begin, whose finishing half waits for the rasteriser):
+                // up to four launches that are empty on almost every frame are left out; the rasteriser says in word 8 of the
+                // pinned record whether they are needed after all
+                if (defer_cleanup && mirror && !bet_light && phase == MS_RENDER_BEGIN) {
+                    host_info[8] = 0;
+                    lazy_lists.verdict = (int32_t *)((int64_t *)mirror + 8);
+                }
             }
             if (int rc = ms::rasterize_fwd(N, c, prev[0] > 0 ? prev[0] : c, means2d, conics, colors, color_dtype, CDIM,
                                            opacities, backgrounds, W, H, tile_size, r0, r1, ranges, ids,
@@ -450,7 +458,8 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
             // (bit 9: the rasteriser was given lazily sorted fronts -- front counts and redo flags are this frame's; bit 10: a
             // lazily sorted frame -- no merge scratch in the exact layout.  ms_render_bwd reads both.)
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits |
-                           (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0) | ((cull & 32) ? 2048 : 0);
+                           (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0) | ((cull & 32) ? 2048 : 0) |
+                           (lazy_lists.verdict ? 4096 : 0);   // (bit 12: the clean-up launches were left to the finishing half)
 #ifdef MS_DIAG
             {
                 MS_HP_T(hp_t6);
@@ -564,7 +573,7 @@ extern "C" int ms_render_fwd(int64_t N, const float *means3d, const float *scale
                              void **stage_events, void *sync_event, void *stream_) {
     return render_fwd_impl(nullptr, 0, N, means3d, scales, scales_are_log, quats, opacities, colors, color_dtype, CDIM, viewmat, fx,
                            fy, cx, cy, W, H, eps2d, near_plane, far_plane, tile_size, tile_row_begin, tile_row_end,
-                           backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info, resume,
+                           backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info, resume & ~MS_RENDER_DEFER_CLEANUP,
                            render_colors, render_alphas, last_ids, stage_events, sync_event, stream_);
 }
 
@@ -621,7 +630,7 @@ static int render_bwd_rows_impl(int64_t N, int CDIM, int W, int H, int tile_size
     MS_HIP(hipMemsetAsync(rows, 0, (size_t)N * 16 * sizeof(float), stream));
     // a lazily sorted frame: the lists are sorted as deep as the forward rasteriser walked them -- the tiles whose
     // front ran out were redone by the forward's clean-up pass and are this call's second launch (normally empty)
-    ms::LazyLists ll;
+    ms::LazyLists ll{};
     ms::isect_lazy_arrays(const_cast<char *>(ws) + L.off_isect, N, tw, th, &ll);
     const bool fronts = (host_info[7] & 512) != 0;
     const int32_t *order = ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr;
@@ -783,7 +792,10 @@ extern "C" int ms_render_band_begin(const ms_band_frame *f, const ms_band_lane *
     // everything the band reads was produced on (or before) the caller's stream: the lane waits for it
     MS_HIP(hipEventRecord((hipEvent_t)lane->in_event, (hipStream_t)caller_stream));
     MS_HIP(hipStreamWaitEvent((hipStream_t)lane->stream, (hipEvent_t)lane->in_event, 0));
-    return band_call(f, lane, MS_RENDER_BEGIN);
+    if (int rc = band_call(f, lane, MS_RENDER_BEGIN)) return rc;
+    // (deferred clean-up: the finishing half waits for the END of the band -- its rasteriser -- before it looks at the verdict)
+    if (lane->host_info[7] & 4096) MS_HIP(hipEventRecord((hipEvent_t)lane->out_event, (hipStream_t)lane->stream));
+    return MS_OK;
 }
 
 extern "C" int ms_render_band_finish(const ms_band_frame *f, const ms_band_lane *lane, void *caller_stream, int resume,
@@ -792,11 +804,29 @@ extern "C" int ms_render_band_finish(const ms_band_frame *f, const ms_band_lane 
     MS_REQUIRE(status, MS_ERR_INVALID_ARG, "render_band_finish: null status");
     // the wait for the band's size record, the check, the exact redo if the speculation did not hold (MS_ERR_WORKSPACE:
     // lane->host_info[5] bytes of isect_buf needed -- grow it, update the lane, call again with resume = 1)
-    if (int rc = band_call(f, lane, resume ? MS_RENDER_RESUME : MS_RENDER_FINISH)) return rc;
-    // the band is complete on the lane's stream: whatever the caller enqueues next (the exchange) comes behind it
-    MS_HIP(hipEventRecord((hipEvent_t)lane->out_event, (hipStream_t)lane->stream));
-    MS_HIP(hipStreamWaitEvent((hipStream_t)caller_stream, (hipEvent_t)lane->out_event, 0));
     const int64_t *h = lane->host_info;
+    // MS_RENDER_DEFER_CLEANUP: the band's clean-up launches -- up to four, empty on almost every frame: 19 us of a 118 us band
+    // and as many microseconds of host time -- were not enqueued.  Wait for the band's rasteriser (with another band in flight
+    // on the other lane the GPU does not idle meanwhile), read its verdict from the pinned record, enqueue them only if a bin
+    // asked for them.
+    const bool deferred = !resume && (h[7] & 4096) != 0;
+    if (deferred) MS_HIP(hipEventSynchronize((hipEvent_t)lane->out_event));
+    if (int rc = band_call(f, lane, resume ? MS_RENDER_RESUME : MS_RENDER_FINISH)) return rc;
+    bool settled = false;   // the host has SEEN the lane's work end: nothing to order the caller's stream behind
+    if ((h[7] & 4096) && !(h[7] & 4)) {   // (bit 2: the band was redone on the exact path, clean-up launches and all)
+        if (h[8] != 0) {
+            void *mirror = nullptr;
+            MS_HIP(hipHostGetDevicePointer(&mirror, lane->host_info, 0));
+            if (int rc = ms::rasterize_deferred_cleanup((int64_t *)mirror + 8, lane->stream)) return rc;
+        } else {
+            settled = deferred;
+        }
+    }
+    if (!settled) {
+        // the band is complete on the lane's stream: whatever the caller enqueues next (the exchange) comes behind it
+        MS_HIP(hipEventRecord((hipEvent_t)lane->out_event, (hipStream_t)lane->stream));
+        MS_HIP(hipStreamWaitEvent((hipStream_t)caller_stream, (hipEvent_t)lane->out_event, 0));
+    }
     status[0] = h[6];                      // Gaussians on the grid (a pre-culled band: of its candidates)
     status[1] = (h[7] & 2048) ? 1 : 0;     // the library pre-culled the band
     status[2] = h[0];                      // pairs in the band

@@ -48,6 +48,9 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "ms_common.hpp"
 
@@ -539,6 +542,8 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
             // overwrites what is stored below); once per tile, whichever wave gets there first
             if (lane == 0 && atomicExch(&A.lazy.redo_flag[redo_tile], 1) == 0) {
                 A.lazy.redo_list[atomicAdd(A.lazy.redo_count, 1)] = redo_tile;
+                // (deferred clean-up: the host looks at this word of its pinned record once the launch has ended)
+                if (A.lazy.verdict) *(volatile int32_t *)A.lazy.verdict = 1;
                 if (cut_short) atomicAdd(A.lazy.redo_count + 1, 1);   // (reported apart: the caller's front depth is not to blame)
             }
         }
@@ -1212,6 +1217,37 @@ static int raster_parts_override() {
 
 static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 4096 ? A.lazy.redo_grid : 64); }
 
+// The clean-up launches behind a lazily sorted frame's rasteriser: empty on almost every frame.
+template <int CP, typename ColorT>
+void cleanup_launches(const RasterArgs &A, hipStream_t stream) {
+    if constexpr (CP <= 4) {
+        // (depth-cut frame: the pairs -- and records -- the redone bins are short of, first: binning.hip, k_far_regen)
+        if (A.lazy.cut_stamp) (void)ms::far_regen(A.lazy, A.tw, A.tw * ((A.H + A.ts - 1) / A.ts), (int64_t)A.max_isects, stream);
+        // (frames that can expect stranded bins: their keys sorted whole first, then a workgroup per 16x16 block)
+        if (A.lazy.redo_sort) hipLaunchKernelGGL(k_redo_sort, dim3(512), dim3(kSortThreads), 0, stream, A);
+        hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(A.lazy.redo_sort ? 1024u : redo_grid(A)), dim3(256), 0, stream, A);
+    }
+}
+
+// Deferred clean-up: what a frame whose caller will look at the rasteriser's verdict itself (LazyLists::verdict) would have
+// launched, kept per verdict word -- a lane's pinned record, one frame at a time -- until the finishing half asks for it.
+struct CleanupMemo {
+    const void *key;
+    RasterArgs A;
+    ms::CutInputs cut;
+    void (*launch)(const RasterArgs &, hipStream_t);
+};
+std::mutex g_cleanup_mu;
+std::vector<CleanupMemo> g_cleanup;
+
+void stash_cleanup(const RasterArgs &A, void (*launch)(const RasterArgs &, hipStream_t)) {
+    CleanupMemo m{A.lazy.verdict, A, A.lazy.cut_inputs ? *A.lazy.cut_inputs : ms::CutInputs{}, launch};
+    std::lock_guard<std::mutex> lock(g_cleanup_mu);
+    for (auto &e : g_cleanup)
+        if (e.key == m.key) { e = m; return; }
+    g_cleanup.push_back(m);
+}
+
 template <int CP, typename ColorT>
 void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
     const bool aux = A.last_ids != nullptr;   // (the per-entry index bookkeeping; render_alphas alone costs the plain kernel one store)
@@ -1246,11 +1282,8 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
         // (measured by leaving it out: the launch costs the frame 2.4 us -- 0.1826 -> 0.1802 ms at config 3 -- although
         // rocprofv3 shows the empty kernel at 4.5 us)
         if (A.lazy.front_count) {
-            // (depth-cut frame: the pairs -- and records -- the redone bins are short of, first: binning.hip, k_far_regen)
-            if (A.lazy.cut_stamp) (void)ms::far_regen(A.lazy, A.tw, A.tw * ((A.H + A.ts - 1) / A.ts), (int64_t)A.max_isects, stream);
-            // (frames that can expect stranded bins: their keys sorted whole first, then a workgroup per 16x16 block)
-            if (A.lazy.redo_sort) hipLaunchKernelGGL(k_redo_sort, dim3(512), dim3(kSortThreads), 0, stream, A);
-            hipLaunchKernelGGL((k_tile_redo<CP, ColorT>), dim3(A.lazy.redo_sort ? 1024u : redo_grid(A)), dim3(256), 0, stream, A);
+            if (A.lazy.verdict) stash_cleanup(A, &cleanup_launches<CP, ColorT>);   // (deferred: rasterize_deferred_cleanup)
+            else cleanup_launches<CP, ColorT>(A, stream);
         }
     }
 }
@@ -1273,6 +1306,21 @@ void launch_redo(const RasterArgs &A, hipStream_t stream) {
 }
 
 }  // namespace
+
+int ms::rasterize_deferred_cleanup(const void *key, void *stream) {
+    CleanupMemo m;
+    {
+        std::lock_guard<std::mutex> lock(g_cleanup_mu);
+        auto it = std::find_if(g_cleanup.begin(), g_cleanup.end(), [&](const CleanupMemo &e) { return e.key == key; });
+        MS_REQUIRE(it != g_cleanup.end(), MS_ERR_INVALID_ARG, "rasterize_deferred_cleanup: no frame left its clean-up for this record");
+        m = *it;
+    }
+    if (m.A.lazy.cut_inputs) m.A.lazy.cut_inputs = &m.cut;   // (the frame's own copy: the original lived on the enqueuing call's stack)
+    m.A.lazy.verdict = nullptr;
+    m.launch(m.A, (hipStream_t)stream);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
 
 namespace {
 // Waves per 16x16 block.  One wave per block leaves a one-round launch (<= 8192 wave slots on

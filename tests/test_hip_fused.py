@@ -1027,3 +1027,54 @@ def test_prepared_scene_bands_equal_the_single_gpu_frame(device):
         y0, y1 = min(r * rows * 16, cam.H), min((r + 1) * rows * 16, cam.H)
         frame[y0:y1] = band[y0:y1]
     assert torch.equal(frame, ref)
+
+
+@pytest.mark.parametrize("world,rank", [(4, 1), (8, 4), (3, 0)])
+def test_band_pair_defers_its_clean_up_to_the_finishing_half(device, monkeypatch, world, rank):
+    """Round 5: a band in flight behind another (two lanes, ms_render_band_begin / _finish) does not enqueue the clean-up
+    launches -- up to four, empty on almost every frame -- behind its rasteriser (MS_RENDER_DEFER_CLEANUP): the finishing half
+    waits for the band's end, reads the rasteriser's verdict from the lane's pinned record and enqueues them only when a bin
+    asked for them.  Depth cuts forced, a still camera, an orbit and a swap to a scene whose near half has all but vanished
+    (stale cut-offs: stranded bins, the clean-up IS needed): every pipelined band equals the single-GPU frame's rows bit for
+    bit, with the deferral and without it (MOJOSPLAT_DEFER_CLEANUP=0), and the deferred run did enqueue clean-ups late."""
+    from mojosplat_amd.distributed import render_gaussians_sharded
+    N, W, H = 400_000, 1280, 720
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    sc, cam = randscene_v1(N, W, H, ell=-3.5, seed=42, device=device)
+    faint = dict(sc)
+    depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
+    faint["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.02, sc["opacities"])
+    seq = [(sc, cam)] * 5 + [(sc, _orbit(cam, 0.004 * i)) for i in range(1, 5)] + [(faint, cam)] * 4 + [(sc, cam)] * 3
+    arrays = lambda s_: (s_["means3d"], s_["scales"], s_["quats"], s_["opacities"], s_["features"])
+    _hip_mod.config_depth_cut(0)
+    refs = [ms.render_gaussians(*arrays(s_), c_, background_color=bg, backend="hip") for s_, c_ in seq]
+    th = -(-H // 16)
+    rows = -(-th // world)
+    y0, y1 = min(rank * rows * 16, H), min((rank + 1) * rows * 16, H)
+    results = {}
+    try:
+        for defer in ("0", "1"):
+            monkeypatch.setenv("MOJOSPLAT_DEFER_CLEANUP", defer)
+            _hip_mod.config_depth_cut(2)
+            _fused._state.clear()
+            _fused.FRAME_STATS = st = {}
+            cur, k_cur = None, -1
+            for k, (s_, c_) in enumerate(seq):
+                nxt = render_gaussians_sharded(*arrays(s_), c_, background_color=bg, rehearse=(rank, world), async_op=True)
+                if cur is not None:
+                    b = cur.wait()
+                    assert torch.equal(b[y0:y1], refs[k_cur][y0:y1]), (defer, k_cur, float((b[y0:y1] - refs[k_cur][y0:y1]).abs().max()))
+                cur, k_cur = nxt, k
+            b = cur.wait()
+            assert torch.equal(b[y0:y1], refs[k_cur][y0:y1]), (defer, k_cur)
+            torch.cuda.synchronize()
+            results[defer] = dict(st)
+    finally:
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
+    off, on = results["0"], results["1"]
+    assert off.get("cleanup_deferred", 0) == 0, off
+    assert on.get("cleanup_deferred", 0) >= len(seq) // 2, on          # most frames ran sync-free with the clean-up left out
+    assert on.get("cleanup_enqueued_late", 0) > 0, on                   # ... and the swap's frames asked for it after all
+    assert on.get("cleanup_enqueued_late", 0) < on["cleanup_deferred"], on   # (quiet frames enqueue nothing)
+    assert on.get("regen_mismatch", 0) == 0 and off.get("regen_mismatch", 0) == 0
