@@ -26,6 +26,7 @@ import torch
 
 from . import _fused, _hip
 from .projection import EPS2D
+from .utils import getenv
 
 _scenes = {}    # key -> (Scene struct, tensors kept alive)
 _SCENE_CAP = 16
@@ -75,6 +76,7 @@ class _LaneRec:
         self.frame = _hip.BandFrame()
         self.status = (ctypes.c_int64 * 4)()
         self.ws_id = self.isect_id = None
+        self.ws_key, self.ws_need = None, 0
 
 
 _lane_recs = {}
@@ -90,8 +92,7 @@ def _lane_rec(dev, slot):
 
 
 def _defer_enabled():
-    import os
-    return os.environ.get("MOJOSPLAT_DEFER_CLEANUP", "1") != "0"
+    return getenv(b"MOJOSPLAT_DEFER_CLEANUP", "1") != "0"
 
 
 class BandHandle:
@@ -112,7 +113,9 @@ def band_begin(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
     rec = _lane_rec(dev, slot)
     st = rec.st
     assert not st.get("busy"), "a begun frame still occupies this lane: finish it first"
-    ws = _fused._grow(st, "ws", L.ms_render_workspace_bytes(N, tw, th), dev)
+    if rec.ws_key != (N, tw, th):
+        rec.ws_key, rec.ws_need = (N, tw, th), L.ms_render_workspace_bytes(N, tw, th)
+    ws = _fused._grow(st, "ws", rec.ws_need, dev)
     lane = rec.lane
     if rec.ws_id != ws.data_ptr():
         lane.workspace, lane.workspace_bytes = ws.data_ptr(), ws.numel()

@@ -361,7 +361,12 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
         uint32_t cut_stamp = 0;
         if (cut)
             while ((cut_stamp = ++cut_stamps) == 0u) {}
-        const ms::DeferredTotal defer{1, info, (int64_t *)mirror, sync_event, cut_stamp};
+        // DEFERRED clean-up (MS_RENDER_DEFER_CLEANUP: ms_render_band_begin, whose finishing half waits for the rasteriser): up to
+        // four launches that are empty on almost every frame are left out; the rasteriser says in word 8 of the pinned record
+        // whether they are needed after all.  (Such a frame's size record needs no event of its own: the finishing half waits
+        // for the band's end.)
+        const bool late_cleanup = defer_cleanup && mirror && phase == MS_RENDER_BEGIN && speculate && !split && lazy && !bet_light;
+        const ms::DeferredTotal defer{1, info, (int64_t *)mirror, late_cleanup ? nullptr : sync_event, cut_stamp};
         const int defer_bit = (deferred ? ms::kTightDeferTotal : 0) | (cut && cut_in ? ms::kTightDepthCutBuf : 0);
         const ms::CutInputs cut_inputs{means3d, scales, quats, opacities, viewmat, colors, color_dtype == MS_COLOR_F16 ? 1 : 0, fx, fy, cx, cy, W, H,
                                        eps2d, near_plane, far_plane, scales_are_log, records, tile_size, r0, r1, N, ws + L.off_isect, (cull & 32) ? 1 : 0};
@@ -383,7 +388,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
         // (bit 11: the band's Gaussians were pre-culled -- host_info[6] counts the band's candidates on the grid, not all Gaussians')
         host_info[7] = (no_split ? 16 : 0) | ((cull & 32) ? 2048 : 0);
         if (!mirror) MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-        if (sync_event && !deferred) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));   // (deferred: behind the scatter launch)
+        if (sync_event && !deferred && !late_cleanup) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));   // (deferred: behind the scatter launch)
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
         // sized by an earlier frame), enqueue emit + rasterise against that capacity NOW and only
         // then wait for the size record -- the GPU never idles on the hand-off.  Every kernel
@@ -440,10 +445,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                 // its predecessor, and its backward walks the whole-bin sorted ids k_redo_sort leaves instead of sorting the
                 // bin's keys again in global memory: rasterize_bwdq.hip, k_rasterize_bwd_redo)
                 lazy_lists.redo_sort = (cut_stamp != 0u || prev_redos > 0 || tile_size >= 48 || aux_frame) && ms_redo_sort_enabled() ? 1 : 0;
-                // DEFERRED clean-up (MS_RENDER_DEFER_CLEANUP: ms_render_band_begin, whose finishing half waits for the rasteriser):
-                // up to four launches that are empty on almost every frame are left out; the rasteriser says in word 8 of the
-                // pinned record whether they are needed after all
-                if (defer_cleanup && mirror && !bet_light && phase == MS_RENDER_BEGIN) {
+                if (late_cleanup) {
                     host_info[8] = 0;
                     lazy_lists.verdict = (int32_t *)((int64_t *)mirror + 8);
                 }

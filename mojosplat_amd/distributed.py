@@ -39,7 +39,7 @@ from typing import Callable, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from .utils import Camera
+from .utils import Camera, getenv as _getenv
 
 
 def band_plan(tile_rows: int, world: int) -> Tuple[int, list]:
@@ -90,16 +90,14 @@ def rebalance(bounds, pairs, damping: float = 0.7, min_rows: int = 1):
 
 
 def _gather_mode():
-    import os
-    v = os.environ.get("MOJOSPLAT_GATHER", "allgather")
+    v = _getenv(b"MOJOSPLAT_GATHER", "allgather")
     if v not in ("allgather", "ring", "direct"):
         raise ValueError("MOJOSPLAT_GATHER must be 'allgather' or 'direct'")
     return "direct" if v == "direct" else "allgather"
 
 
 def _balance_enabled():
-    import os
-    return os.environ.get("MOJOSPLAT_BALANCE", "1") != "0"
+    return _getenv(b"MOJOSPLAT_BALANCE", "1") != "0"
 
 
 def _force_exchange():
@@ -107,8 +105,7 @@ def _force_exchange():
     in-place all_gather_into_tensor of the framebuffer onto itself.  For the world-1 RCCL test (tests/test_hip_rccl.py):
     one GPU is all a test box has, RCCL refuses two ranks per device, and this way its collectives, their stream
     semantics and the in-place aliasing run on hardware."""
-    import os
-    return os.environ.get("MOJOSPLAT_FORCE_EXCHANGE", "0") == "1"
+    return _getenv(b"MOJOSPLAT_FORCE_EXCHANGE", "0") == "1"
 
 
 def balance_weights(records):

@@ -22,7 +22,7 @@ import torch
 from .binning import bin_gaussians_to_tiles, lds_row_bands
 from .projection import project_gaussians
 from .rasterization import rasterize_gaussians
-from .utils import Camera
+from .utils import Camera, getenv
 
 TILE_SIZE = 16
 
@@ -181,7 +181,7 @@ def _bin_key(means3d, camera):
 
 
 def _env_bin_px():
-    v = os.environ.get("MOJOSPLAT_BIN_PX")
+    v = getenv(b"MOJOSPLAT_BIN_PX")
     if not v:
         return None
     if int(v) not in _BIN_MODES:

@@ -76,3 +76,20 @@ def look_at(eye: torch.Tensor, target: torch.Tensor, up: torch.Tensor) -> torch.
     vm[:3, :3] = Rt
     vm[:3, 3] = -(Rt @ eye)
     return vm
+
+
+# The package's switches are environment variables read on EVERY frame (a test or a host can flip them at run time);
+# os.environ.get costs ~1.2 us (encode, lookup, decode) and a band frame asks four times.  The same live lookup on the bytes
+# dictionary underneath (CPython on posix) costs 0.1 us.
+_ENV_BYTES = getattr(__import__("os").environ, "_data", None)
+if not isinstance(_ENV_BYTES, dict):
+    _ENV_BYTES = None
+
+
+def getenv(name: bytes, default=None):
+    """os.environ.get(name.decode(), default) -- `name` as bytes, the value as str."""
+    if _ENV_BYTES is not None:
+        v = _ENV_BYTES.get(name)
+        return default if v is None else v.decode()
+    import os
+    return os.environ.get(name.decode(), default)
