@@ -530,16 +530,22 @@ __device__ __forceinline__ void for_each_isect(int64_t i0, int64_t i1, const flo
 // waves then skip the loads of every block that cannot reach the band: at config 5 cut 8 ways the centre band skips 54 %
 // of the 120 MB this pass streams, an edge band 92 % (the pass was 32 of a band frame's 148 us whatever the band).
 constexpr int kMaxBlocksPerChunk = 4096;
-__global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const float *__restrict__ means3d,
+#ifndef MS_PRECULL_SUB
+#define MS_PRECULL_SUB 4
+#endif
+// (8 waves a SIMD: at 98 scalar registers the kernel held 7, i.e. ONE 1 024-thread workgroup a CU and two rounds of its 512)
+__global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, const float *__restrict__ means3d,
                                                                const float *__restrict__ scales,
                                                                const float *__restrict__ viewmat, ms::ProjParams P,
                                                                float y_lo, float y_hi, int64_t chunk,
                                                                int32_t *__restrict__ cand,
                                                                int32_t *__restrict__ seg_count,
                                                                const float *__restrict__ block_bounds, int block_shift) {
-    __shared__ uint32_t s_w[4 * 16];
+    constexpr int kSub = MS_PRECULL_SUB;
+    __shared__ uint32_t s_w[kSub * 16];
     __shared__ unsigned char s_blk[kMaxBlocksPerChunk];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    MS_BIN_STAMP(4, 0);
     float V[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = viewmat[k];
@@ -592,23 +598,36 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
         }
         __syncthreads();
     }
+    MS_BIN_STAMP(4, 1);
     // kSub sub-steps of 1024 Gaussians share one pair of barriers (the pass is a chain of load -> test -> count
     // round trips, not a bandwidth problem: LDS-staged 16-byte loads made it 1.5x SLOWER)
-    constexpr int kSub = 4;
     for (int64_t base = i0; base < i1; base += (int64_t)kSub * kHistThreads) {
         bool keep[kSub];
         unsigned long long bal[kSub];
+        // ALL the sub-steps' loads first, unconditionally, on an index that is always valid (a lane past the chunk's end or in
+        // a rejected block fetches the chunk's first Gaussian: one cached line): a load inside `if (live)` cannot be hoisted
+        // above the previous sub-step's test, and a wave then pays one memory round trip per sub-step -- measured with
+        // per-workgroup stamps, a workgroup whose 9 766 Gaussians all survive the block verdicts took 22 us for its ten
+        // steps whether the other workgroups were loading or not (scripts/precull_phases.py).
+        bool live[kSub];
+        float p0[kSub], p1[kSub], p2[kSub], s0[kSub], s1[kSub], s2_[kSub];
 #pragma unroll
         for (int k = 0; k < kSub; ++k) {
             const int64_t i = base + (int64_t)k * kHistThreads + threadIdx.x;
+            live[k] = i < i1 && (!blocks || s_blk[(min(i, i1 - 1) >> block_shift) - blk0]);
+            const int64_t j = live[k] ? i : i0;
+            p0[k] = means3d[3 * j]; p1[k] = means3d[3 * j + 1]; p2[k] = means3d[3 * j + 2];
+            s0[k] = scales[3 * j]; s1[k] = scales[3 * j + 1]; s2_[k] = scales[3 * j + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < kSub; ++k) {
             keep[k] = false;
-            if (i < i1 && (!blocks || s_blk[(i >> block_shift) - blk0])) {
-                const float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
-                const float mx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
-                const float my = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
-                const float z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
-                if (!(z < P.near_plane || z > P.far_plane)) {   // the exact projection's own depth cull
-                    float sm = fmaxf(scales[3 * i], fmaxf(scales[3 * i + 1], scales[3 * i + 2]));
+            {
+                const float mx = V[0] * p0[k] + V[1] * p1[k] + V[2] * p2[k] + V[3];
+                const float my = V[4] * p0[k] + V[5] * p1[k] + V[6] * p2[k] + V[7];
+                const float z = V[8] * p0[k] + V[9] * p1[k] + V[10] * p2[k] + V[11];
+                if (live[k] && !(z < P.near_plane || z > P.far_plane)) {   // the exact projection's own depth cull
+                    float sm = fmaxf(s0[k], fmaxf(s1[k], s2_[k]));
                     if (P.scales_are_log) sm = __expf(sm);
                     const float rz = __builtin_amdgcn_rcpf(z);
                     const float u = fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz)), v = fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
@@ -645,6 +664,10 @@ __global__ __launch_bounds__(kHistThreads) void k_band_precull(int64_t N, const 
         }
     }
     if (threadIdx.x == 0) seg_count[blockIdx.x] = (int32_t)written;
+    MS_BIN_STAMP(4, 2);
+#ifdef MS_DIAG
+    if (g_diag_bin && threadIdx.x == 0 && blockIdx.x < 1024) g_diag_bin[(4 * 1024 + blockIdx.x) * 8 + 3] = written;
+#endif
 }
 
 // Fused projection + tile counting (the first two kernels of a frame in one): every lane projects

@@ -49,14 +49,14 @@ def main():
         frame = lambda: ms.render_gaussians(*g, cam, background_color=bg)
     for _ in range(8):
         frame()
-    buf = torch.zeros(4 * 1024 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(5 * 1024 * 8, dtype=torch.int64, device=dev)   # (slot 4: k_band_precull, scripts/precull_phases.py)
     _hip.check(L.ms_diag_set_bin_stamps(ctypes.c_void_p(buf.data_ptr())), "diag")
     frame()
     torch.cuda.synchronize()
     _hip.check(L.ms_diag_set_bin_stamps(None), "diag")
     raw = buf.cpu().numpy()
     # k_tile_front (kernel 3): up to three blocks per slot (blockIdx & 1023, blockIdx >> 10): start, end, list length
-    fr = raw[3 * 1024 * 8:].reshape(1024, 8)
+    fr = raw[3 * 1024 * 8:4 * 1024 * 8].reshape(1024, 8)
     rows = []
     for q in range(2):
         blk = fr[:, 3 * q:3 * q + 3]
