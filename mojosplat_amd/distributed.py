@@ -310,8 +310,14 @@ def _lane_events(dev, lane):
 def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera: Camera,
                              background_color: Optional[torch.Tensor] = None, tile_size: int = 16,
                              group=None, stages: Optional[Stages] = None, async_op: bool = False,
-                             rehearse: Optional[Tuple[int, int]] = None, bounds: Optional[list] = None):
+                             rehearse: Optional[Tuple[int, int]] = None, bounds: Optional[list] = None,
+                             exchange_dtype: Optional[torch.dtype] = None):
     """Every rank returns the full (H, W, C) image.  Inputs must be identical on all ranks.
+    exchange_dtype: None -- the bands travel as they are rendered, float32, and the image is the single-GPU frame bit for bit --
+    or torch.float16 / torch.bfloat16: every rank rounds ITS band to that type (one cast of 1 / world of the frame) before
+    the exchange and every rank returns the image IN that type.  Half the bytes over xGMI: the exchange is what bounds the
+    8-GPU frame rate of a large frame (config 5: 87 MB per GPU in float32, at least 81 us over 7 x 153 GB/s against a
+    ~118 us band), and a frame that goes to a display or an 8-bit encoder loses nothing to float16.
     rehearse=(rank, world) acts as that rank WITHOUT a process group and without the exchange
     (only its own slab of the image is rendered): single-GPU timing of one rank's share.
     bounds: the world + 1 band boundaries in tile rows (rehearsals, tests); default: the scene's current plan --
@@ -341,6 +347,10 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         bg = torch.as_tensor(background_color, device=dev).to(features.dtype).to(torch.float32)
     if bg.shape[0] != C:
         raise ValueError(f"Background color channels ({bg.shape[0]}) must match gaussian color channels ({C})")
+    if exchange_dtype not in (None, torch.float32, torch.float16, torch.bfloat16):
+        raise ValueError("exchange_dtype must be None, torch.float32, torch.float16 or torch.bfloat16")
+    xdt = torch.float32 if exchange_dtype is None else exchange_dtype
+    x16 = xdt != torch.float32
 
     # ---- this frame's bands: equal until the ranks' pair counts say otherwise (rebalance, module docstring)
     live = (world > 1 or (_force_exchange() and dist.is_initialized())) and rehearse is None   # a real process group: status records are exchanged
@@ -376,7 +386,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                 # locally; the band (background where nothing reaches it) is what this rank contributes
                 return buf[:H], []
             if on_grid == 0:
-                return torch.zeros(H, W, C, device=dev, dtype=torch.float32), []   # zeros, not background (render.py:73-76)
+                return torch.zeros(H, W, C, device=dev, dtype=xdt), []   # zeros, not background (render.py:73-76)
             return buf[:H], []
         # The status record, 32 bytes per rank: Gaussians on the grid (the zeros-image rule's OR); the Gaussians that reach
         # the band if the LIBRARY pre-culled it (it says so in the size record's flag word: bit 11), else -1; the band's
@@ -433,7 +443,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
                 if not plan["settled"]:
                     plan["bounds"] = nb
             if int(rec[:, 0].max()) == 0:
-                return torch.zeros(H, W, C, device=dev, dtype=torch.float32)
+                return torch.zeros(H, W, C, device=dev, dtype=xdt)
             return frame
         return image, works
 
@@ -443,18 +453,29 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
         return img() if callable(img) else img
 
     def framebuffer():
-        # fresh per frame (caching allocator: no hipMalloc), handed out as a view
+        # fresh per frame (caching allocator: no hipMalloc), handed out as a view; in the exchange's type
         if padded:
-            return torch.empty((world, slab, W, C), dtype=torch.float32, device=dev)
-        return torch.empty((H_pad, W, C), dtype=torch.float32, device=dev)
+            return torch.empty((world, slab, W, C), dtype=xdt, device=dev)
+        return torch.empty((H_pad, W, C), dtype=xdt, device=dev)
+
+    n_own = y1s[rank] - y0s[rank]
+
+    def own_slot(buf):
+        return buf[rank, :n_own] if padded else buf[y0s[rank]:y1s[rank]]
 
     if stages is not None or not async_op:
         buf = framebuffer()
-        if padded and stages is not None:
+        if stages is not None and (padded or x16):
             tmp = torch.empty((H, W, C), dtype=torch.float32, device=dev)     # (CPU test stages address the full image)
             on_grid, m_band, culled = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
                                                    bands[rank], tmp)
-            buf[rank, :y1s[rank] - y0s[rank]] = tmp[y0s[rank]:y1s[rank]]
+            own_slot(buf).copy_(tmp[y0s[rank]:y1s[rank]])
+        elif x16:
+            # a 16-bit exchange: the band in float32 into a slab of its own, ONE rounding pass into its slot of the framebuffer
+            own = torch.empty((max(n_own, 1), W, C), dtype=torch.float32, device=dev)
+            on_grid, m_band, culled = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
+                                                   bands[rank], own, y0s[rank])
+            own_slot(buf).copy_(own[:n_own])
         else:
             on_grid, m_band, culled = _render_band(stages, means3d, scales, quats, opacities, features, camera, bg, tile_size,
                                                    bands[rank], buf[rank] if padded else buf, y0s[rank] if padded else None)
@@ -474,20 +495,24 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
     raw = _hip._raw_stream(idx) if _hip._raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
     lanes = _lane_streams(dev)
     buf = framebuffer()
+    own = torch.empty((max(n_own, 1), W, C), dtype=torch.float32, device=dev) if x16 else None   # (see the blocking path)
     my_band = _band_of(bands[rank], th)
     bkey, bmode = _band_bin(means3d, camera, my_band, tile_size)
     with _frame_lock:   # (the shared lanes are one thread at a time: the lane pick and the frame's claim on it)
         lane = _turn.get(dev, 0)
         _turn[dev] = 1 - lane
         from . import render as _render   # bench.py's in-situ kernel timing hook (None otherwise)
-        h = _band.band_begin(means3d, scales, quats, opacities, features, camera, bg, bmode, my_band, buf[rank] if padded else buf,
-                             y0s[rank] if padded else None, tile_size == 16, 1 + lane, lanes[lane].cuda_stream, raw,
+        h = _band.band_begin(means3d, scales, quats, opacities, features, camera, bg, bmode, my_band,
+                             own if x16 else (buf[rank] if padded else buf),
+                             y0s[rank] if (padded or x16) else None, tile_size == 16, 1 + lane, lanes[lane].cuda_stream, raw,
                              _render._STAGE_HOOK() if _render._STAGE_HOOK is not None else None)
 
     def finalize():
         now = _hip._raw_stream(idx) if _hip._raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
         on_grid, culled, m, flags = _band.band_finish(h, now)   # size-record check (+ exact redo on the lane); lane -> `now`
         _band_learn(bkey, bmode, m, {"on_grid": on_grid, "flags": flags}, camera, my_band)
+        if x16:
+            own_slot(buf).copy_(own[:n_own])                    # (on `now`, which band_finish has ordered behind the lane)
         img, works = exchange(buf, on_grid, m, culled)          # the collectives' stream waits for `now`
         return resolve(img, works)                              # ... and `now` for the exchange
     return PendingFrame(finalize=finalize, on_drop=lambda st=h.rec.st: st.__setitem__("busy", False))
@@ -496,7 +521,7 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
 @torch.no_grad()
 def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, cameras,
                                    background_color: Optional[torch.Tensor] = None, tile_size: int = 16, group=None,
-                                   async_op: bool = False):
+                                   async_op: bool = False, exchange_dtype: Optional[torch.dtype] = None):
     """Multi-view rendering sharded by VIEW instead of by tile row -- the second sharding axis SURVEY.md section 8(f)
     row 4 names: the same Gaussians from C cameras, every rank returns all C views, (C, H, W, channels) f32.
 
@@ -509,8 +534,13 @@ def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, 
     (every rank renders whole frames).  Inputs must be identical on all ranks.
     async_op=True returns a PendingFrame right after the gather is enqueued on the collective's stream: `.wait()`
     makes the current stream wait for it and hands out the views, so the next call's rendering overlaps this call's
-    exchange (use it one call ahead, as with render_gaussians_sharded)."""
+    exchange (use it one call ahead, as with render_gaussians_sharded).
+    exchange_dtype: as render_gaussians_sharded's -- torch.float16 / torch.bfloat16 halve the bytes of the exchange; the views
+    are then returned in that type (a world of one included, so that a caller sees one type whatever the group)."""
     from .render import render_gaussians_batch
+    if exchange_dtype not in (None, torch.float32, torch.float16, torch.bfloat16):
+        raise ValueError("exchange_dtype must be None, torch.float32, torch.float16 or torch.bfloat16")
+    xdt = torch.float32 if exchange_dtype is None else exchange_dtype
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     cams = list(cameras)
@@ -523,13 +553,18 @@ def render_gaussians_batch_sharded(means3d, scales, quats, opacities, features, 
     if world == 1 and not (_force_exchange() and dist.is_initialized()):
         out = render_gaussians_batch(means3d, scales, quats, opacities, features, cams,
                                      background_color=background_color, tile_size=tile_size)
+        out = out if xdt == torch.float32 else out.to(xdt)
         return PendingFrame(image=out) if async_op else out
     per = -(-C // world)
-    full = torch.empty((world * per, H, W, ch), dtype=torch.float32, device=dev)
+    full = torch.empty((world * per, H, W, ch), dtype=xdt, device=dev)
     mine = cams[rank * per:(rank + 1) * per]
-    if mine:
+    if mine and xdt == torch.float32:
         render_gaussians_batch(means3d, scales, quats, opacities, features, mine, background_color=background_color,
                                tile_size=tile_size, out=full[rank * per:rank * per + len(mine)])
+    elif mine:
+        part = render_gaussians_batch(means3d, scales, quats, opacities, features, mine, background_color=background_color,
+                                      tile_size=tile_size)
+        full[rank * per:rank * per + len(mine)].copy_(part)   # (the one rounding pass, over this rank's views)
     # in place, as the band gather
     work = dist.all_gather_into_tensor(full, full[rank * per:(rank + 1) * per], group=group, async_op=True)
 

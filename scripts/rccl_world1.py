@@ -58,6 +58,14 @@ try:
             assert ok, f"{gather}: frames on a side stream differ"
             out["frames_compared"] += 2
             out["modes"].append(f"{N}@{W}x{H}:{gather}")
+        # a 16-bit exchange over RCCL (half-precision buffers through the same in-place all-gather)
+        os.environ["MOJOSPLAT_GATHER"] = "allgather"
+        for dt in (torch.float16, torch.bfloat16):
+            a = render_gaussians_sharded(*g, cam, background_color=bg, exchange_dtype=dt)
+            b = render_gaussians_sharded(*g, cam, background_color=bg, exchange_dtype=dt, async_op=True).wait()
+            assert a.dtype == dt and torch.equal(a, ref.to(dt)) and torch.equal(b, ref.to(dt)), f"{dt} exchange differs"
+            out["frames_compared"] += 2
+        out["modes"].append(f"{N}@{W}x{H}:f16+bf16 exchange")
         # an empty frame (nothing on the grid): the zeros rule read from the gathered records
         far = (g[0] + torch.tensor([0.0, 0.0, 500.0], device=dev),) + g[1:]
         z = render_gaussians_sharded(*far, cam, background_color=bg)

@@ -60,6 +60,19 @@ try:
             assert torch.equal(cur.wait(), ref), f"balanced pipelined frame {k - 1} differs"
         cur = nxt
     assert torch.equal(cur.wait(), ref)
+    # round 5: a 16-bit exchange (every rank rounds its band once, the image comes back in that type) -- equal bands and
+    # ragged ones, blocking and two frames in flight
+    for dt in (torch.float16, torch.bfloat16):
+        want = ref.to(dt)
+        got = render_gaussians_sharded(*g, cam, background_color=bg, exchange_dtype=dt, bounds=ragged)
+        assert got.dtype == dt and torch.equal(got, want), f"{dt}: ragged blocking frame is not the rounded float32 frame"
+        cur = None
+        for k in range(4):
+            nxt = render_gaussians_sharded(*g, cam, background_color=bg, exchange_dtype=dt, async_op=True)
+            if cur is not None:
+                assert torch.equal(cur.wait(), want), f"{dt}: pipelined frame {k - 1} differs"
+            cur = nxt
+        assert torch.equal(cur.wait(), want)
     gathered = [None] * world
     dist.all_gather_object(gathered, plans)
     assert all(p == gathered[0] for p in gathered), "the ranks' plans diverged"
@@ -116,6 +129,8 @@ try:
     for v, c in enumerate(cams):
         assert torch.equal(views[v], ms.render_gaussians(*g, c, background_color=bg)), f"view {v} differs"
     assert (views[4] == 0).all(), "a view that sees nothing is the zeros image"
+    v16 = render_gaussians_batch_sharded(*g, cams, background_color=bg, exchange_dtype=torch.float16)
+    assert v16.dtype == torch.float16 and torch.equal(v16, views.half()), "the view batch's 16-bit exchange is not the rounded batch"
     pend = None
     for k in range(3):   # one call ahead
         nxt = render_gaussians_batch_sharded(*g, cams, background_color=bg, async_op=True)

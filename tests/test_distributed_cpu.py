@@ -142,7 +142,13 @@ def _worker_balance(rank, world, port, H, W, mode, q):
             frames.append(render_gaussians_sharded(*args, **kw).numpy().copy())
         pend = [render_gaussians_sharded(*args, async_op=True, **kw) for _ in range(2)]
         frames += [p.wait().numpy().copy() for p in pend]
-        q.put((rank, frames, seq))
+        # round 5: a 16-bit exchange -- every rank rounds its band before it travels and returns the image in that type
+        half = []
+        for dt, extra in ((torch.float16, dict(bounds=ragged)), (torch.bfloat16, dict()), (torch.float16, dict(async_op=True))):
+            img = render_gaussians_sharded(*args, exchange_dtype=dt, **extra, **kw)
+            img = img.wait() if extra.get("async_op") else img
+            half.append((str(dt), str(img.dtype), img.float().numpy().copy()))
+        q.put((rank, frames, seq, half))
     finally:
         dist.destroy_process_group()
 
@@ -160,9 +166,11 @@ def test_balanced_ragged_bands_equal_single_frame(world, mode):
     for p in procs:
         p.start()
     got = {}
+    halves = {}
     for _ in range(world):
-        r, frames, seq = q.get(timeout=180)
+        r, frames, seq, half = q.get(timeout=180)
         got[r] = (frames, seq)
+        halves[r] = half
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -180,6 +188,12 @@ def test_balanced_ragged_bands_equal_single_frame(world, mode):
             assert np.array_equal(f, ref), f"rank {r} frame {k} differs from the unsharded render"
     seq = got[0][1]
     assert seq[0] != seq[-1], f"the plan never moved: {seq}"
+    # the 16-bit exchange: the float32 frame rounded once, on every rank, in the type asked for
+    for r in range(world):
+        for asked, dtype, img in halves[r]:
+            assert dtype == asked
+            want = torch.from_numpy(ref).to(getattr(torch, asked.split(".")[1])).float().numpy()
+            assert np.array_equal(img, want), f"rank {r}: the {asked} exchange is not the rounded float32 frame"
 
 
 def _worker_two_groups(rank, world, port, H, W, q):
