@@ -34,7 +34,11 @@ def main():
     # given: the scene as randscene_v1 draws it (random order); morton: sorted along a Morton curve of the means by the
     # CALLER (no bounds); prepared: scene_order.prepare_scene -- the same order plus the block bounds the band pre-cull uses
     ap.add_argument("--order", default="given", choices=["given", "morton", "prepared"])
+    # f16: the band is rounded to float16 for the exchange (render_gaussians_sharded's exchange_dtype): the rank's frame then
+    # includes that one cast of its band
+    ap.add_argument("--exchange", default="f32", choices=["f32", "f16", "bf16"])
     args = ap.parse_args()
+    xdt = {"f32": None, "f16": torch.float16, "bf16": torch.bfloat16}[args.exchange]
     dev = torch.device("cuda", 0)
     N, W, H, ell, fp16 = WORKLOADS[args.workload]
     sc, cam = randscene_v1(N, W, H, ell=ell, seed=42, device=dev)
@@ -52,7 +56,7 @@ def main():
     th = -(-H // 16)
 
     def render(r, world, bounds, **kw):
-        return render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world), bounds=bounds, **kw)
+        return render_gaussians_sharded(*g, cam, background_color=bg, rehearse=(r, world), bounds=bounds, exchange_dtype=xdt, **kw)
 
     def pairs_of(r, world, bounds):
         """the weight a live rank reports for its band: the Gaussians that reach it (pre-culled band) or its pairs"""
@@ -128,7 +132,7 @@ def main():
         worst_b = max(x["blocking_us_median"] for x in ranks)
         worst_p = max(x["pipelined_us"] for x in ranks)
         best_b = min(x["blocking_us_median"] for x in ranks)
-        print(json.dumps(dict(workload=args.workload, order=args.order, world=world, plan=label, bounds=bounds, frames=args.frames,
+        print(json.dumps(dict(workload=args.workload, order=args.order, exchange=args.exchange, world=world, plan=label, bounds=bounds, frames=args.frames,
                               slowest_blocking_us_median=worst_b, rank_spread=round(worst_b / best_b, 3),
                               slowest_pipelined_us=worst_p, fps_bound_pipelined=round(1e6 / worst_p, 1), ranks=ranks)),
               flush=True)
