@@ -621,7 +621,7 @@ class _RenderBandHip(torch.autograd.Function):
     ranks, the backward projection on the summed rows (ms_render_bwd_finish) -- identical gradients on every rank."""
 
     @staticmethod
-    def forward(ctx, means3d, scales, quats, opacities, colors, background, camera, tile_size, rank, world, group):
+    def forward(ctx, means3d, scales, quats, opacities, colors, background, camera, tile_size, rank, world, group, live=True):
         import numpy as np
         from ._fused import WHOLE, _Frame
         H, W = camera.H, camera.W
@@ -635,11 +635,14 @@ class _RenderBandHip(torch.autograd.Function):
                        tile_size, None, band, buf, 0, own=True, own_last=False)
         info = {}
         _, M = frame.finish(WHOLE, info)
-        if world > 1:
+        if world > 1 and live:
             dist.all_gather_into_tensor(buf[:world * slab], buf[rank * slab:(rank + 1) * slab], group=group)
+        elif world > 1:
+            buf[:min(rank * slab, H)].zero_()      # (a rehearsed rank: the other ranks' rows are never rendered)
+            buf[min((rank + 1) * slab, H):H].zero_()
         img = buf[:H]
         ctx.empty = info["on_grid"] == 0   # (a differentiable frame is never pre-culled: the count is the whole frame's, the same on every rank)
-        ctx.camera, ctx.tile_size, ctx.band, ctx.group, ctx.world = camera, tile_size, band, group, world
+        ctx.camera, ctx.tile_size, ctx.band, ctx.group, ctx.world = camera, tile_size, band, group, (world if live else 1)
         m3, sc, qu, op, col, bg = frame.keep[:6]
         ctx.scratch = (frame.ws, frame.isect, np.array(frame.st["host_np"], dtype=np.int64, copy=True))
         ctx.save_for_backward(m3, sc, qu, op, col, bg, frame.alphas, img)
@@ -661,7 +664,7 @@ class _RenderBandHip(torch.autograd.Function):
         v_means3d, v_scales, v_quats, v_opac, v_colors = z(N, 3), z(N, 3), z(N, 4), z(N), z(N, 3)
         if ctx.empty or N == 0:
             return (torch.zeros_like(m3), torch.zeros_like(sc), torch.zeros_like(qu), torch.zeros_like(op), torch.zeros_like(col),
-                    None if bg is None else torch.zeros_like(bg), None, None, None, None, None)
+                    None if bg is None else torch.zeros_like(bg), None, None, None, None, None, None)
         v_img = _hip.f32c(v_img)
         rows = torch.empty(L.ms_render_bwd_rows_bytes(N) // 4, dtype=torch.float32, device=dev)
         vm = cam._viewmat_f32().to(dev)
@@ -681,11 +684,11 @@ class _RenderBandHip(torch.autograd.Function):
             v_bg = ((1.0 - alphas[y0:y1])[..., None] * v_img[y0:y1]).sum(dim=(0, 1))
             if ctx.world > 1:
                 dist.all_reduce(v_bg, op=dist.ReduceOp.SUM, group=ctx.group)
-        return v_means3d, v_scales, v_quats, v_opac, v_colors, v_bg, None, None, None, None, None
+        return v_means3d, v_scales, v_quats, v_opac, v_colors, v_bg, None, None, None, None, None, None
 
 
 def render_gaussians_trainable_sharded(means3d, scales, quats, opacities, features, camera: Camera, background_color=None,
-                                       tile_size: int = 16, group=None, stages=None):
+                                       tile_size: int = 16, group=None, stages=None, rehearse: Optional[Tuple[int, int]] = None):
     """The differentiable twin of render_gaussians_sharded: every rank returns the full (H, W, 3) image and, after
     backward(), the FULL gradients of its (identical) inputs -- the training step of one frame cut into tile-row bands.
     Rank r renders and differentiates only its band; the exchanges are the framebuffer all-gather of the forward and ONE
@@ -697,9 +700,15 @@ def render_gaussians_trainable_sharded(means3d, scales, quats, opacities, featur
         project(means3d, scales, quats, opacities, camera) -> means2d, conics, depths, radii (radii / ids non-differentiable)
         bin(means2d, radii, depths, tile_size, tw, th) -> ids, tile_ranges
         raster(means2d, conics, colors, opacities, bg, ranges, ids, camera, tile_size) -> (H, W, C) image
+    rehearse=(rank, world) (HIP path): that rank's share of the step WITHOUT a process group and without the two exchanges --
+    its band's forward and backward, gradients of its band's pixels only: single-GPU timing of one rank (scripts/band_train_bench.py).
     The reference has no counterpart (no backward: render.py:11; no distributed path)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if rehearse is not None:
+        if stages is not None:
+            raise ValueError("rehearse= is for the HIP path")
+        rank, world = rehearse
     dev = means3d.device
     C = features.shape[-1]
     H, W = camera.H, camera.W
@@ -710,7 +719,8 @@ def render_gaussians_trainable_sharded(means3d, scales, quats, opacities, featur
         _hip.require_cuda(means3d, scales, quats, opacities, features, what="gaussian tensor")
         if C != 3 or features.dtype != torch.float32 or tile_size % 16 != 0:
             raise ValueError("render_gaussians_trainable_sharded: the HIP path takes three float32 channels and a tile size that is a multiple of 16")
-        return _RenderBandHip.apply(means3d, scales, quats, opacities.reshape(-1), features, bg, camera, tile_size, rank, world, group)
+        return _RenderBandHip.apply(means3d, scales, quats, opacities.reshape(-1), features, bg, camera, tile_size, rank, world, group,
+                                    rehearse is None)
     rows, bands = band_plan(th, world)
     slab = rows * tile_size
     if world > 1:
