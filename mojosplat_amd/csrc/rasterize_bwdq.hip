@@ -40,7 +40,10 @@
 
 namespace {
 
-constexpr int kBatch = 64;     // list entries staged per round
+#ifndef MS_BWDQ_BATCH
+#define MS_BWDQ_BATCH 64
+#endif
+constexpr int kBatch = MS_BWDQ_BATCH;   // list entries staged per round (<= 64: one per lane)
 constexpr int kGroup = 2;      // records per trip of the walk
 constexpr int kTile = 8;       // entries per matrix tile (rows 0-7 of Y: vs, rows 8-15: 255 w)
 constexpr int kYStride = 68;   // floats per row of Y: the A fragments are read as ds_read_b128 at (row, 16 g + 4 i)
@@ -304,7 +307,7 @@ __device__ __forceinline__ void bwd_quad(const BwdQArgs &A, const int tile, cons
     for (int b0 = start; b0 < end && live; b0 += kBatch) {
         // --- the quad test of the forward kernel (exact ellipse-vs-rectangle, in log2 units on the record)
         bool reach = false, npd = false;
-        if (b0 + lane < end) {
+        if (b0 + lane < end && (kBatch == 64 || lane < kBatch)) {
             const float smax = r_c.y, nb_c = r_c.z, nb_a = r_c.w;
             if (smax == kInf) {
                 reach = true;
