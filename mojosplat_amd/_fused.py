@@ -139,7 +139,7 @@ def _grow(st, key, nbytes, dev, slack=1.0):
 FRAME_STATS = None
 
 
-def _count_frame(stats, frame, host, grew):
+def _count_frame(stats, frame, host, grew, counts_valid=True):
     flags, heavy = int(host[7]), int(host[2]) + int(host[3]) + int(host[4])
     stats["frames"] = stats.get("frames", 0) + 1
     if grew:
@@ -158,7 +158,9 @@ def _count_frame(stats, frame, host, grew):
             else:
                 why = "other_miss"
             stats[why] = stats.get(why, 0) + 1
-    if not flags & 4:
+    # (host[5] = what the PREVIOUS frame on this workspace redid; the count lives at an offset that follows the grid, so the
+    # first frame on another grid -- a bin size the rule has just switched to -- reads a word nobody has written)
+    if not flags & 4 and counts_valid:
         stats["redo_tiles"] = stats.get("redo_tiles", 0) + (int(host[5]) & 0xffffffff)
         stats["cut_redo_tiles"] = stats.get("cut_redo_tiles", 0) + ((int(host[5]) >> 32) & 0x3fffffff)
         if (int(host[5]) >> 62) & 1:   # the clean-up launches of the previous frame disagreed with its count kernel (never seen)
@@ -254,10 +256,10 @@ def _after_frame(st, host, rc, grew, *, shape, level, mode, own, channels, frame
     # full sorts.  (The count lives in the lane's workspace, whose layout follows the frame's shape: it
     # only means something when the previous frame had the same shape, and a new shape starts afresh.)
     heavy = int(host[2]) + int(host[3]) + int(host[4])
+    same_shape = (not own) and st.get("shape") == shape
     if FRAME_STATS is not None:
-        _count_frame(FRAME_STATS, frame, host, grew)
+        _count_frame(FRAME_STATS, frame, host, grew, same_shape)
     if not own:
-        same_shape = st.get("shape") == shape
         memo = st.setdefault("learnt", {})   # shape -> (full_sort, front_level): a lane that alternates between
         if not same_shape:                   # shapes (render.py's race between grids) does not learn them anew
             st["full_sort"], st["front_level"] = memo.get(shape, (False, 0))

@@ -946,6 +946,12 @@ __global__ __launch_bounds__(kHistThreads) void k_isect_hist(
 // the band count 0), tile_ranges, totals and the work lists of over-sized tiles.  Each wave owns
 // a contiguous run of tiles and walks it 64 tiles at a time (coalesced loads / int2 stores,
 // wave-level scans), so the kernel is three dependent memory round trips long.
+// The clean-up counts a frame leaves for the next one (redo_count[0..1]) live in the isect workspace at an offset that follows the
+// PLAN's grid -- the tile grid, or a split frame's 32-px bins -- so a frame whose predecessor on this workspace planned another
+// grid (lazy -> full sorts on 16-px tiles: split -> not split) would read a word of some other array as "bins redone".  The total
+// pass signs what it resets (redo_count[2]) and only reports counts that carry its own grid's signature.
+__device__ __forceinline__ int redo_signature(const Grid &g) { return (int)(0x80000000u | ((unsigned)g.tw & 0x7fffu) | (((unsigned)g.th & 0xffffu) << 15)); }
+
 struct ScanTotalArgs {
     Grid g;
     const uint32_t *tile_count;
@@ -1002,7 +1008,7 @@ __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
     const int w0 = t_lo + w * per_wave, w1 = min(t_hi, w0 + per_wave);
     if (threadIdx.x == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; }
     // (loads whose values are only needed at the end go out first: the pass is a chain of dependent round trips)
-    const int prev_redo = threadIdx.x == 0 ? *redo_count : 0;
+    const int prev_redo = (threadIdx.x == 0 && redo_count[2] == redo_signature(g)) ? *redo_count : 0;
     unsigned int on_grid_part = (int)threadIdx.x < G ? wg_on_grid[threadIdx.x] : 0u;   // G <= kMaxG <= blockDim
     // (s_bkt is zeroed above and first added to after the __syncthreads() between the two passes)
     auto count_of = [&](int t) -> unsigned int {
@@ -1112,6 +1118,7 @@ __device__ __forceinline__ void tile_scan_total(const ScanTotalArgs &A) {
         }
         redo_count[0] = 0;
         redo_count[1] = 0;
+        redo_count[2] = redo_signature(g);
         info[6] = (int64_t)s_on_grid;  // Gaussians whose tile box touches the FULL grid (band-independent)
         info[7] = 0;
         if (info_mirror) {
@@ -1311,7 +1318,7 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
         for (int t = tid; t < 2 * A.g.tw * A.g.th; t += kHistThreads) A.far_zero[t] = 0u;
     __shared__ unsigned int s_nmedium, s_nlarge, s_nxl, s_max, s_on_grid, s_far;
     if (tid == 0) { s_nmedium = 0; s_nlarge = 0; s_nxl = 0; s_max = 0; s_on_grid = 0; s_far = 0; }
-    const int prev_redo = tid == 0 ? *A.redo_count : 0;
+    const int prev_redo = (tid == 0 && A.redo_count[2] == redo_signature(A.g)) ? *A.redo_count : 0;
     unsigned int on_grid_part = tid < A.G ? A.wg_on_grid[tid] : 0u;   // G <= kMaxG <= blockDim
     unsigned int far_part = (A.wg_far && tid < A.G) ? A.wg_far[tid] : 0u;   // depth-cut frame: the far log's length
     const unsigned long long grand = tile_prefix_lds(A.tile_count, T_local, s);   // (its barriers also publish the zeros above)
@@ -1363,6 +1370,7 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
         A.info[10] = 0;   // (the clean-up launch's cursor into the regenerated far pairs)
         A.redo_count[0] = 0;
         A.redo_count[1] = 0;
+        A.redo_count[2] = redo_signature(A.g);
         if (A.info_mirror) {
 #pragma unroll
             for (int k = 0; k < 7; ++k) A.info_mirror[k] = rec[k];

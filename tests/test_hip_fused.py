@@ -1078,3 +1078,65 @@ def test_band_pair_defers_its_clean_up_to_the_finishing_half(device, monkeypatch
     assert on.get("cleanup_enqueued_late", 0) > 0, on                   # ... and the swap's frames asked for it after all
     assert on.get("cleanup_enqueued_late", 0) < on["cleanup_deferred"], on   # (quiet frames enqueue nothing)
     assert on.get("regen_mismatch", 0) == 0 and off.get("regen_mismatch", 0) == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pipelined_band_fuzz_with_deferred_clean_up(device, seed, dense=False):
+    """Random scenes, image sizes, world sizes and ranks through the ASYNCHRONOUS sharded entry point (two lanes, the band pair
+    with its clean-up launches left to the finishing half), depth cuts forced, a camera that drifts every frame, a swap to the
+    same Gaussians with the near half nearly transparent half-way and back: the band's rows of every frame equal the
+    single-GPU frame's bit for bit, in float32 and -- every other seed -- through a float16 exchange (the rounded rows)."""
+    import math
+    from mojosplat_amd.distributed import band_plan, render_gaussians_sharded
+    from mojosplat_amd.utils import Camera
+    g = torch.Generator().manual_seed(91000 + seed)
+    r = lambda lo, hi: lo + (hi - lo) * torch.rand(1, generator=g).item()
+    if dense:
+        N, W, H, ell = int(10 ** r(5.3, 5.9)), int(r(1000, 1920)), int(r(600, 1080)), r(-3.8, -3.0)
+    else:
+        N, W, H, ell = int(10 ** r(4.6, 5.6)), int(r(500, 1500)), int(r(300, 900)), r(-4.0, -2.8)
+    world = [2, 3, 4, 8][seed % 4]
+    rank = int(r(0, world - 1e-3))
+    sc, cam = randscene_v1(N, W, H, ell=ell, seed=2300 + seed, device=device)
+    sc["opacities"] = (sc["opacities"] * r(0.5, 1.0)).clamp(max=1.0)
+    faint = dict(sc)
+    depth = (sc["means3d"] @ cam.R.T + cam.T)[:, 2]
+    faint["opacities"] = torch.where(depth < depth.median(), sc["opacities"] * 0.03, sc["opacities"])
+    bg = torch.tensor([r(0, 1), r(0, 1), r(0, 1)], device=device)
+    xdt = torch.float16 if seed % 2 else None
+    th = -(-H // 16)
+    _, bands = band_plan(th, world)
+    y0, y1 = min(bands[rank][0] * 16, H), min(bands[rank][1] * 16, H)
+    arrays = lambda s_: (s_["means3d"], s_["scales"], s_["quats"], s_["opacities"], s_["features"])
+    frames = []
+    for k in range(10):
+        a = 0.008 * k * (1 if seed % 3 else -1)
+        c, s = math.cos(a), math.sin(a)
+        ry = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], device=device)
+        cm = Camera(R=cam.R @ ry, T=cam.T + torch.tensor([0.0, 0.0, 0.015 * k], device=device), H=H, W=W, fx=cam.fx, fy=cam.fy,
+                    cx=cam.cx, cy=cam.cy, near=cam.near, far=cam.far)
+        frames.append((faint if 4 <= k < 7 else sc, cm))
+    _hip_mod.config_depth_cut(0)
+    refs = [ms.render_gaussians(*arrays(s_), cm, background_color=bg, backend="hip") for s_, cm in frames]
+    _hip_mod.config_depth_cut(2)
+    _fused._state.clear()
+    _fused.FRAME_STATS = st = {}
+    try:
+        cur, k_cur = None, -1
+
+        def check(b, k):
+            want = refs[k][y0:y1] if xdt is None else refs[k][y0:y1].to(xdt)
+            assert b.dtype == want.dtype and torch.equal(b[y0:y1], want), (seed, k, N, W, H, world, rank, dict(st))
+        for k, (s_, cm) in enumerate(frames):
+            nxt = render_gaussians_sharded(*arrays(s_), cm, background_color=bg, rehearse=(rank, world), async_op=True, exchange_dtype=xdt)
+            if cur is not None:
+                check(cur.wait(), k_cur)
+            cur, k_cur = nxt, k
+        check(cur.wait(), k_cur)
+        torch.cuda.synchronize()
+        assert st.get("regen_mismatch", 0) == 0, st
+    finally:
+        LAST_CUT_FUZZ_STATS.clear()
+        LAST_CUT_FUZZ_STATS.update(_fused.FRAME_STATS or {})
+        _fused.FRAME_STATS = None
+        _fused._state.clear()
