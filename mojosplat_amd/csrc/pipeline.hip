@@ -777,6 +777,8 @@ static int band_validate(const ms_band_frame *f, const ms_band_lane *lane, const
     MS_REQUIRE(lane->workspace && lane->host_info && lane->in_event && lane->out_event,
                MS_ERR_INVALID_ARG, "%s: the lane lacks scratch or an event", who);
     MS_REQUIRE(f->render_colors && f->viewmat, MS_ERR_INVALID_ARG, "%s: null image / view matrix", who);
+    MS_REQUIRE(f->W > 0 && f->H > 0 && f->tile_size > 0 && f->row_begin >= 0 && f->row_begin <= f->row_end, MS_ERR_INVALID_ARG,
+               "%s: bad sizes / row band", who);
     return MS_OK;
 }
 

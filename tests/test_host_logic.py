@@ -213,6 +213,66 @@ def test_c_abi_argument_validation_returns_status_codes():
         host[k] = 0
 
 
+def test_c_abi_argument_validation_of_the_round5_entry_points():
+    """The band pair, the prepared-scene call and the two halves of the backward validate before they touch the device."""
+    import ctypes
+    L = _hip.load()
+    P = ctypes.c_void_p(0x1000)
+    N = ctypes.c_int64(10)
+    OK, INVALID, WORKSPACE = 0, 1, 2
+    err = lambda: L.ms_last_error_string().decode()
+    # prepared scenes
+    assert L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 256) == 4 * 32 and L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 100) == 0
+    assert L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 32) == 0 and L.ms_scene_block_bounds_bytes(ctypes.c_int64(0), 256) == 0
+    assert L.ms_scene_prepare(N, P, P, 1, 100, P, None) == INVALID and "power of two" in err()
+    assert L.ms_scene_prepare(N, None, P, 1, 256, P, None) == INVALID and "null" in err()
+    assert L.ms_scene_prepare(ctypes.c_int64(0), None, None, 1, 256, None, None) == OK
+    # the band pair: structs as _band.py builds them
+    scene = _hip.Scene(10, 0x1000, 0x1000, 1, 0x1000, 0x1000, 0x1000, 0, 3, None, 0, 0)
+    lane = _hip.BandLane(0x1000, 1 << 20, None, 0, 0x1000, None, None, 0x1000, 0x1000)
+    frame = _hip.BandFrame()
+    frame.scene = ctypes.pointer(scene)
+    frame.viewmat, frame.render_colors = 0x1000, 0x1000
+    frame.W, frame.H, frame.tile_size, frame.row_begin, frame.row_end = 64, 64, 16, 0, 4
+    status = (ctypes.c_int64 * 4)()
+    assert L.ms_render_band_begin(None, ctypes.byref(lane), None) == INVALID and "null frame" in err()
+    assert L.ms_render_band_finish(ctypes.byref(frame), None, None, 0, status) == INVALID
+    bad = _hip.BandLane(None, 0, None, 0, 0x1000, None, None, 0x1000, 0x1000)
+    assert L.ms_render_band_begin(ctypes.byref(frame), ctypes.byref(bad), None) == INVALID and "scratch" in err()
+    bad = _hip.BandLane(0x1000, 1 << 20, None, 0, 0x1000, None, None, None, 0x1000)
+    assert L.ms_render_band_begin(ctypes.byref(frame), ctypes.byref(bad), None) == INVALID and "event" in err()
+    frame.render_colors = None
+    assert L.ms_render_band_begin(ctypes.byref(frame), ctypes.byref(lane), None) == INVALID and "image" in err()
+    frame.render_colors, frame.row_begin = 0x1000, 5
+    assert L.ms_render_band_begin(ctypes.byref(frame), ctypes.byref(lane), None) == INVALID and "row band" in err()
+    frame.row_begin = 0
+    assert L.ms_render_band_finish(ctypes.byref(frame), ctypes.byref(lane), None, 0, None) == INVALID and "status" in err()
+    # the backward's two halves
+    host = (ctypes.c_int64 * 8)()
+    rows_bytes = L.ms_render_bwd_rows_bytes(N)
+    assert rows_bytes >= 10 * 64 and rows_bytes % 256 == 0
+
+    def rows(n=N, hinfo=host, out=P, cdim=3, ts=16, wsb=1 << 30):
+        return L.ms_render_bwd_rows(n, cdim, 64, 64, ts, 0, 4, None, P, wsb, P, 1 << 20, hinfo, P, P, P, None, out, None, None)
+    assert rows(hinfo=None) == INVALID and rows(out=None) == INVALID
+    assert rows(n=ctypes.c_int64(0)) == OK
+    host[0], host[6], host[7] = 100, 5, 4
+    assert rows(cdim=4) == INVALID and "3 channels" in err()
+    assert rows(ts=24) == INVALID
+    assert rows(wsb=8) == WORKSPACE and "workspace" in err()
+    host[7] = 4 | 8
+    assert rows() == INVALID and "split" in err()
+
+    def finish(n=N, cdim=3, r=P, op=P, vm=P):
+        return L.ms_render_bwd_finish(n, P, P, 1, P, op, cdim, P, 1., 1., 0., 0., 64, 64, .3, r, vm, P, P, P, P, None)
+    assert finish(cdim=4) == INVALID and finish(vm=None) == INVALID
+    assert finish(r=None) == INVALID and "null" in err()
+    assert finish(n=ctypes.c_int64(0)) == OK
+    counts = (ctypes.c_int32 * 2)()
+    assert L.ms_render_redo_counts(P, 8, N, 4, 4, counts, None) == WORKSPACE
+    assert L.ms_render_redo_counts(None, 1 << 30, N, 4, 4, counts, None) == INVALID
+
+
 def test_bin_rule_on_the_baseline_configs():
     """render.py's binning-granularity rule: the footprint diameter estimated from a frame's size record
     (pairs M on the grid it ran on, Gaussians on the grid) picks split / 32 / 64 px.  The records below are
