@@ -453,8 +453,7 @@ int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *sca
  * The bounds must describe the arrays AS THEY ARE: recompute them after the means or scales change.
  *   block_bounds f32[n_blocks][8] = {min x, min y, min z of the block's means, its largest LINEAR scale, max x, max y, max z, 0}
  *
- * ms_band_lane: one scratch set (as ms_render_fwd wants it: workspace, isect_buf, pinned host_info -- i64[16] here: word 8 is the
- * rasteriser's verdict of a band whose clean-up launches were deferred, MS_RENDER_DEFER_CLEANUP --, sync_event) with the
+ * ms_band_lane: one scratch set (as ms_render_fwd wants it: workspace, isect_buf, pinned host_info i64[8], sync_event) with the
  * hipStream_t the band runs on and two hipEvent_t for the ordering around it; built once per lane, isect_buf / isect_bytes
  * updated when the buffer grows.  One frame at a time per lane; frames on different lanes overlap.
  *
