@@ -451,7 +451,9 @@ int ms_render_fwd_batch(int C, int64_t N, const float *means3d, const float *sca
  * are small, the band pre-cull skips every block that cannot reach the band without reading it, and the count kernel's
  * gathers through the band's candidate list coalesce.  block_bounds == NULL: any order, no bounds (as ms_render_fwd).
  * The bounds must describe the arrays AS THEY ARE: recompute them after the means or scales change.
- *   block_bounds f32[n_blocks][8] = {min x, min y, min z of the block's means, its largest LINEAR scale, max x, max y, max z, 0}
+ *   block_bounds: the buffer ms_scene_prepare fills (ms_scene_block_bounds_bytes of it): f32[n_blocks][8] = {min x, min y, min z
+ *   of the block's means, its largest LINEAR scale, max x, max y, max z, 0}, then f32[N][4] = every Gaussian's mean and largest
+ *   linear scale -- the band pre-cull's own 16-byte record (one load instead of 24 bytes in two)
  *
  * ms_band_lane: one scratch set (as ms_render_fwd wants it: workspace, isect_buf, pinned host_info i64[8], sync_event) with the
  * hipStream_t the band runs on and two hipEvent_t for the ordering around it; built once per lane, isect_buf / isect_bytes

@@ -533,7 +533,11 @@ constexpr int kMaxBlocksPerChunk = 4096;
 #ifndef MS_PRECULL_SUB
 #define MS_PRECULL_SUB 4
 #endif
+#ifndef MS_PRECULL_SUB_PREPARED   // (a prepared scene's sub-step is ONE 16-byte load: four registers)
+#define MS_PRECULL_SUB_PREPARED 4
+#endif
 // (8 waves a SIMD: at 98 scalar registers the kernel held 7, i.e. ONE 1 024-thread workgroup a CU and two rounds of its 512)
+template <bool PREPARED>   // a prepared scene: block verdicts first, the survivors' 16-byte pre-cull records instead of means + scales
 __global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, const float *__restrict__ means3d,
                                                                const float *__restrict__ scales,
                                                                const float *__restrict__ viewmat, ms::ProjParams P,
@@ -541,8 +545,9 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, con
                                                                int32_t *__restrict__ cand,
                                                                int32_t *__restrict__ seg_count,
                                                                const float *__restrict__ block_bounds, int block_shift) {
-    constexpr int kSub = MS_PRECULL_SUB;
-    __shared__ uint32_t s_w[kSub * 16];
+    constexpr int kSub = PREPARED ? MS_PRECULL_SUB_PREPARED : MS_PRECULL_SUB;
+    __shared__ uint32_t s_w[2][kSub * 16];   // (two buffers, alternating: ONE barrier a round -- a wave writes a buffer again only
+                                             // behind the next round's barrier, which every wave reaches after it has read this one)
     __shared__ unsigned char s_blk[kMaxBlocksPerChunk];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     MS_BIN_STAMP(4, 0);
@@ -561,11 +566,15 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, con
     const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(N, i0 + chunk);
     int32_t *seg = cand + i0;
     uint32_t written = 0;   // survivors of this segment so far (uniform)
-    const int64_t blk0 = block_bounds ? (i0 >> block_shift) : 0;
-    const bool blocks = block_bounds != nullptr && i1 > i0 && ((i1 - 1) >> block_shift) - blk0 < kMaxBlocksPerChunk;   // (uniform)
+    const int64_t blk0 = PREPARED ? (i0 >> block_shift) : 0;
+    // (a prepared scene's buffer: the bounds of its ceil(N / block) blocks, then a 16-byte pre-cull record per Gaussian)
+    // (16-byte aligned: the buffer is, and a block's bounds are 32 bytes)
+    const float4 *__restrict__ cull = PREPARED ? reinterpret_cast<const float4 *>(__builtin_assume_aligned(block_bounds + 8 * (((N - 1) >> block_shift) + 1), 16)) : nullptr;
+    const bool blocks = PREPARED && i1 > i0 && ((i1 - 1) >> block_shift) - blk0 < kMaxBlocksPerChunk;   // (uniform)
     if (blocks) {
         const int nb = (int)(((i1 - 1) >> block_shift) - blk0) + 1;
         const float vlx = fmaxf(P.lim_x_pos, P.lim_x_neg), vly = fmaxf(P.lim_y_pos, P.lim_y_neg);
+        int any_kept = 0;
         for (int b = threadIdx.x; b < nb; b += kHistThreads) {
             const float *q = block_bounds + 8 * (blk0 + b);
             const float lo[3] = {q[0], q[1], q[2]}, hi[3] = {q[4], q[5], q[6]}, smax = q[3];
@@ -595,12 +604,21 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, con
                 keep = !(ymax + ry < y_lo || ymin - ry > y_hi || xmax + rx < 0.f || xmin - rx > P.W);
             }
             s_blk[b] = keep ? 1 : 0;
+            any_kept |= keep ? 1 : 0;
         }
-        __syncthreads();
+        // (a chunk none of whose blocks can reach the band -- 212 of the centre band's 512 at config 5, more at an edge -- is
+        // done: its three empty rounds cost 8 us of sixteen waves that the other lane's kernels can use)
+        if (!__syncthreads_or(any_kept)) {
+            if (threadIdx.x == 0) seg_count[blockIdx.x] = 0;
+            MS_BIN_STAMP(4, 1);
+            MS_BIN_STAMP(4, 2);
+            return;
+        }
     }
     MS_BIN_STAMP(4, 1);
     // kSub sub-steps of 1024 Gaussians share one pair of barriers (the pass is a chain of load -> test -> count
     // round trips, not a bandwidth problem: LDS-staged 16-byte loads made it 1.5x SLOWER)
+    int round = 0;
     for (int64_t base = i0; base < i1; base += (int64_t)kSub * kHistThreads) {
         bool keep[kSub];
         unsigned long long bal[kSub];
@@ -616,8 +634,13 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, con
             const int64_t i = base + (int64_t)k * kHistThreads + threadIdx.x;
             live[k] = i < i1 && (!blocks || s_blk[(min(i, i1 - 1) >> block_shift) - blk0]);
             const int64_t j = live[k] ? i : i0;
-            p0[k] = means3d[3 * j]; p1[k] = means3d[3 * j + 1]; p2[k] = means3d[3 * j + 2];
-            s0[k] = scales[3 * j]; s1[k] = scales[3 * j + 1]; s2_[k] = scales[3 * j + 2];
+            if constexpr (PREPARED) {   // mean + largest linear scale in ONE 16-byte load
+                const float4 r = cull[j];
+                p0[k] = r.x; p1[k] = r.y; p2[k] = r.z; s0[k] = r.w; s1[k] = 0.f; s2_[k] = 0.f;
+            } else {
+                p0[k] = means3d[3 * j]; p1[k] = means3d[3 * j + 1]; p2[k] = means3d[3 * j + 2];
+                s0[k] = scales[3 * j]; s1[k] = scales[3 * j + 1]; s2_[k] = scales[3 * j + 2];
+            }
         }
 #pragma unroll
         for (int k = 0; k < kSub; ++k) {
@@ -627,8 +650,11 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, con
                 const float my = V[4] * p0[k] + V[5] * p1[k] + V[6] * p2[k] + V[7];
                 const float z = V[8] * p0[k] + V[9] * p1[k] + V[10] * p2[k] + V[11];
                 if (live[k] && !(z < P.near_plane || z > P.far_plane)) {   // the exact projection's own depth cull
-                    float sm = fmaxf(s0[k], fmaxf(s1[k], s2_[k]));
-                    if (P.scales_are_log) sm = __expf(sm);
+                    float sm = s0[k];
+                    if constexpr (!PREPARED) {
+                        sm = fmaxf(s0[k], fmaxf(s1[k], s2_[k]));
+                        if (P.scales_are_log) sm = __expf(sm);
+                    }
                     const float rz = __builtin_amdgcn_rcpf(z);
                     const float u = fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz)), v = fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
                     const float s2 = lam * sm * sm;
@@ -642,21 +668,27 @@ __global__ __launch_bounds__(kHistThreads, 8) void k_band_precull(int64_t N, con
             }
             bal[k] = __ballot(keep[k]);
         }
-        __syncthreads();   // s_w of the previous step has been read
+        uint32_t *sw = s_w[round & 1];
+        ++round;
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < kSub; ++k) s_w[k * 16 + w] = (uint32_t)__popcll(bal[k]);
+            for (int k = 0; k < kSub; ++k) sw[k * 16 + w] = (uint32_t)__popcll(bal[k]);
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kSub; ++k) {   // list order = Gaussian order: sub-step by sub-step, wave by wave
-            uint32_t before = written, total = 0;
+            // the sixteen waves' counts of the sub-step: one per lane, a prefix across the lanes, this wave's offset and the
+            // total out of it by readlane (every lane summing all sixteen words itself was ~60 instructions a sub-step --
+            // more than the test: the pass is bound by what it issues between its round trips, not by its bytes)
+            uint32_t incl = lane < 16 ? sw[k * 16 + lane] : 0u;
 #pragma unroll
-            for (int ww = 0; ww < 16; ++ww) {
-                const uint32_t c = s_w[k * 16 + ww];
-                if (ww < w) before += c;
-                total += c;
+            for (int d = 1; d < 16; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += o;
             }
+            const int wu = __builtin_amdgcn_readfirstlane(w);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+            const uint32_t before = written + (wu > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, wu - 1) : 0u);
             if (keep[k])
                 seg[before + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[k], 0u))] =
                     (int32_t)(base + (int64_t)k * kHistThreads + threadIdx.x);
@@ -2370,21 +2402,27 @@ extern "C" int ms_diag_set_bin_stamps(void *device_buffer) {
 // order -- scene_order.prepare_scene sorts along a Morton curve -- so that the boxes are small; any order is correct.)
 namespace {
 __global__ __launch_bounds__(256) void k_block_bounds(int64_t N, const float *__restrict__ means3d, const float *__restrict__ scales,
-                                                      int scales_are_log, int block_size, float *__restrict__ out) {
+                                                      int scales_are_log, int block_size, float *__restrict__ out,
+                                                      float4 *__restrict__ cull) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t i0 = b * block_size, i1 = min(N, i0 + block_size);
     if (i0 >= N) return;   // (uniform per wave)
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, sm = 0.f;
     for (int64_t i = i0 + lane; i < i1; i += 64) {
+        float p[3], raw = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float p = means3d[3 * i + k];
-            lo[k] = fminf(lo[k], p); hi[k] = fmaxf(hi[k], p);
+            p[k] = means3d[3 * i + k];
+            lo[k] = fminf(lo[k], p[k]); hi[k] = fmaxf(hi[k], p[k]);
             float sc = scales[3 * i + k];
+            raw = fmaxf(raw, sc);
             if (scales_are_log) sc = expf(sc);
             sm = fmaxf(sm, sc);
         }
+        // the band pre-cull's own record of the Gaussian: its mean and its largest LINEAR scale, the very value that pass
+        // computes from the scales (k_band_precull) -- 16 bytes in one load instead of 24 in two
+        cull[i] = make_float4(p[0], p[1], p[2], scales_are_log ? __expf(raw) : raw);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -2403,9 +2441,10 @@ __global__ __launch_bounds__(256) void k_block_bounds(int64_t N, const float *__
 }
 }  // namespace
 
+// (the buffer: f32[n_blocks][8] bounds, then f32[N][4] pre-cull records -- mean, largest linear scale -- of the Gaussians)
 extern "C" size_t ms_scene_block_bounds_bytes(int64_t N, int block_size) {
     if (N <= 0 || block_size < 64 || (block_size & (block_size - 1))) return 0;
-    return (size_t)ms::ceil_div(N, block_size) * 8 * sizeof(float);
+    return (size_t)ms::ceil_div(N, block_size) * 8 * sizeof(float) + (size_t)N * 4 * sizeof(float);
 }
 
 extern "C" int ms_scene_prepare(int64_t N, const float *means3d, const float *scales, int scales_are_log, int block_size,
@@ -2417,7 +2456,7 @@ extern "C" int ms_scene_prepare(int64_t N, const float *means3d, const float *sc
     const int64_t nb = ms::ceil_div(N, block_size);
     MS_REQUIRE(nb <= 0x7fffffffll, MS_ERR_TOO_LARGE, "scene_prepare: too many blocks");
     hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)ms::ceil_div(nb, 4)), dim3(256), 0, (hipStream_t)stream, N, means3d, scales,
-                       scales_are_log, block_size, block_bounds);
+                       scales_are_log, block_size, block_bounds, reinterpret_cast<float4 *>(block_bounds + 8 * nb));
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -2542,9 +2581,9 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
     if ((tight & kBandCull) && N >= (1ll << 28)) tight &= ~kBandCull;   // (the candidates' gather indexes with 32-bit byte offsets)
     if ((tight & kBandCull) && N > 0) {
         int32_t *seg_count = (int32_t *)(ws + p.off_cand_count);
-        hipLaunchKernelGGL(k_band_precull, dim3(p.G), dim3(kHistThreads), 0, stream, N, means3d, scales, viewmat, P,
-                           (float)(row_begin * tile_size) - 1.0f, (float)(row_end * tile_size) + 1.0f, p.chunk,
-                           (int32_t *)(ws + p.off_cand), seg_count, block_bounds, block_shift);
+        hipLaunchKernelGGL(block_bounds ? k_band_precull<true> : k_band_precull<false>, dim3(p.G), dim3(kHistThreads), 0, stream, N,
+                           means3d, scales, viewmat, P, (float)(row_begin * tile_size) - 1.0f, (float)(row_end * tile_size) + 1.0f,
+                           p.chunk, (int32_t *)(ws + p.off_cand), seg_count, block_bounds, block_shift);
         MS_LAUNCH_CHECK();
         cand = Candidates{(const int32_t *)(ws + p.off_cand), seg_count, p.G, p.chunk};
     }

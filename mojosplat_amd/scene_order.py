@@ -80,7 +80,10 @@ def prepare_scene(means3d, scales, quats, opacities, features, block_size: int =
     with _hip.on_device(m.device):
         _hip.check(L.ms_scene_prepare(N, _hip.ptr(m), _hip.ptr(sc), 1, block_size, _hip.ptr(bounds), _hip.stream(m.device)),
                    "ms_scene_prepare")
-    ps = PreparedScene(m, sc, quats, opacities, features, perm, bounds.view(-1, 8), block_size)
+    # (the library's buffer: the blocks' bounds, then a 16-byte pre-cull record -- mean, largest linear scale -- per Gaussian;
+    # the view below keeps all of it alive and starts where the buffer does)
+    nb = -(-N // block_size) if N > 0 else 0
+    ps = PreparedScene(m, sc, quats, opacities, features, perm, bounds[:max(nb, 1) * 8].view(-1, 8), block_size)
     if len(_registry) > 64:
         _registry.clear()
     _registry[id(m)] = (weakref.ref(m), m._version, weakref.ref(sc), sc._version, ps)

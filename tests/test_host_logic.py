@@ -222,7 +222,8 @@ def test_c_abi_argument_validation_of_the_round5_entry_points():
     OK, INVALID, WORKSPACE = 0, 1, 2
     err = lambda: L.ms_last_error_string().decode()
     # prepared scenes
-    assert L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 256) == 4 * 32 and L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 100) == 0
+    # (4 blocks' bounds of 32 bytes, then a 16-byte pre-cull record per Gaussian)
+    assert L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 256) == 4 * 32 + 1000 * 16 and L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 100) == 0
     assert L.ms_scene_block_bounds_bytes(ctypes.c_int64(1000), 32) == 0 and L.ms_scene_block_bounds_bytes(ctypes.c_int64(0), 256) == 0
     assert L.ms_scene_prepare(N, P, P, 1, 100, P, None) == INVALID and "power of two" in err()
     assert L.ms_scene_prepare(N, None, P, 1, 256, P, None) == INVALID and "null" in err()
