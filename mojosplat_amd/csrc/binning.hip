@@ -172,6 +172,9 @@ __device__ __forceinline__ int chunk_of_block(int b, int G) {
 #ifndef MS_DEAL
 #define MS_DEAL 64
 #endif
+#ifndef MS_PH_TICKETS   // k_project_hist: a workgroup's slices go to its waves by ticket (0: two fixed slices a wave, as Deal lays them out)
+#define MS_PH_TICKETS 1
+#endif
 constexpr int kDeal = MS_DEAL;
 static_assert(kDeal >= 64 && kDeal <= 1024 && (kDeal & (kDeal - 1)) == 0, "a slice is a power-of-two number of waves");
 struct Deal {
@@ -735,7 +738,8 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     // Should a pixel outlive a marked tile's list, the clean-up launch regenerates the tile's far pairs from the box
     // records every Gaussian still writes (rasterize.hip, k_far_regen).
     __shared__ unsigned int s_near_n;
-    if (threadIdx.x == 0) s_near_n = 0;
+    __shared__ unsigned int s_next_slice;   // (the workgroup's slices handed to its waves as they come free: below)
+    if (threadIdx.x == 0) { s_near_n = 0; s_next_slice = 0; }
     uint32_t *s_tau = s_cnt + T_local + 4;
     unsigned char *s_farflag = reinterpret_cast<unsigned char *>(s_tau + T_local);
     uint32_t far_pairs = 0;
@@ -766,8 +770,24 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
         if (db <= s_tau[t]) { atomicAdd(&s_cnt[t], 1u); dmin = min(dmin, db); dmax = max(dmax, db); }
         else { ++far_pairs; s_farflag[t] = 1; }
     };
-    for (int it = 0; it < deal.iters; ++it) {
-        const int64_t base = deal.base(it);   // (wave-uniform: this wave's slice of 64 positions)
+    // WHICH wave of the workgroup takes which of its slices is decided as the waves come free (an LDS ticket per slice): the
+    // slices' costs differ -- a few large boxes, a slice of culled Gaussians -- and with two fixed slices per wave the
+    // workgroup waited 4.7 us of its 20 at the loop's barrier for its slowest wave (profiles/r05_bin_phases_given.txt).
+    // The workgroup's SET of slices is Deal's, so its histogram row -- and what the scatter kernel does with it -- is the same.
+    constexpr bool kTickets = kDeal == 64 && MS_PH_TICKETS != 0;
+    const int n_slices = deal.iters * (kHistThreads / kDeal);
+    for (int it = 0;; ++it) {
+        int64_t base;
+        if constexpr (kTickets) {
+            int k = 0;
+            if (lane_u == 0) k = (int)atomicAdd(&s_next_slice, 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= n_slices) break;
+            base = ((int64_t)k * (int)gridDim.x + wg) * kDeal;   // slice k of this workgroup: Deal's (trip k / 16, part k % 16)
+        } else {
+            if (it >= deal.iters) break;
+            base = deal.base(it);   // (wave-uniform: this wave's slice of 64 positions)
+        }
         const int64_t j = base + lane_u;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0, edges = 0, gi = 0;
         bool on_grid = false;
