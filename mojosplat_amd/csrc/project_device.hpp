@@ -84,7 +84,15 @@ __device__ __forceinline__ float rcp_nr(float x) {   // 1 / x to ~0.5 ulp: v_rcp
     return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
 
-template <class Idx>
+// FLAT (-DMS_PROJECT_FLAT=1, a measurement of round 5, off by default): one verdict at the end instead of the nested exits.
+// Config 4's frame gains 2.6-3.8 % with it (0.227 -> 0.219 ms: its depth-cut count kernel), config 3's loses 0.5 % (count
+// kernel 27.85 -> 28.35 us, rasteriser +0.5 on lists that differ by a few pairs).  The two forms are NOT interchangeable
+// within a build: the contraction of their products differs in the last bit of a conic (a depth-cut frame projected one
+// way and its uncut twin the other differed by 2e-3 at a pixel), so every user of project_one takes the build's one form.
+#ifndef MS_PROJECT_FLAT
+#define MS_PROJECT_FLAT 0
+#endif
+template <class Idx, bool FLAT = (MS_PROJECT_FLAT != 0)>
 __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ means3d,
                                                const float *__restrict__ scales, const float *__restrict__ quats,
                                                const float *__restrict__ opacities,
@@ -104,12 +112,18 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
         z = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
     }
 
-    float o_m0 = 0.f, o_m1 = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_d = 0.f;
-    int o_r0 = 0, o_r1 = 0;
-
-    bool alive = !(z < P.near_plane || z > P.far_plane);
-    if (alive) {
+    if constexpr (FLAT) {
+        // FLAT (round 5): ONE verdict at the end instead of the nested `if (alive)` blocks below.  The nest cost every wave its exits' bookkeeping
+        // whether a lane took them or not -- the eight outputs zeroed again at each level (~40 v_mov), an exec-mask save / restore
+        // per level -- and put the quaternion, scale and opacity loads BEHIND the tests before them: three dependent memory round
+        // trips a slice.  A culled lane now computes on whatever its Gaussian holds (its loads are valid for any index below N;
+        // infinities and NaNs it may produce are never selected) and the loads leave together with the mean's.
         const float4 q4 = ld_f32x4(quats, i);
+        const F3 s3 = ld_f32x3(scales, i);
+        float op = 1.0f;
+        if (P.has_opacity) op = ld_f32(opacities, i, 1, 0);   // (uniform)
+        bool alive = !(z < P.near_plane || z > P.far_plane);
+
         float w = q4.x, x = q4.y, y = q4.z, zq = q4.w;
         const float inv_norm = __builtin_amdgcn_rsqf(x * x + y * y + zq * zq + w * w);
         w *= inv_norm; x *= inv_norm; y *= inv_norm; zq *= inv_norm;
@@ -119,14 +133,12 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
         const float R10 = 2.f * (xy + wz), R11 = 1.f - 2.f * (x2 + z2), R12 = 2.f * (yz - wx);
         const float R20 = 2.f * (xz - wy), R21 = 2.f * (yz + wx), R22 = 1.f - 2.f * (x2 + y2);
 
-        const F3 s3 = ld_f32x3(scales, i);
         float s0 = s3.x, s1 = s3.y, s2 = s3.z;
         if (P.scales_are_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
 
         // pinhole Jacobian with the 1.3x FOV clamp; T = J Wv (2x3)
         float rz, m2x, m2y;
         {   // means2d: IEEE 1 / z and the reference's products, uncontracted -- bit for bit the oracle's
-#pragma clang fp contract(off)
             rz = 1.0f / z;
             m2x = P.fx * mx * rz + P.cx;
             m2y = P.fy * my * rz + P.cy;
@@ -147,35 +159,95 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
         const float c = A10 * A10 + A11 * A11 + A12 * A12 + P.eps2d;
 
         const float det = a * c - b * b;
-        alive = det > 0.f;
+        alive = alive && det > 0.f;
 
         float extend = 3.33f;
-        if (alive && P.has_opacity) {
-            const float op = ld_f32(opacities, i, 1, 0);
-            if (op < kAlphaThreshold) {
-                alive = false;
-            } else {
-                extend = fminf(extend, __builtin_amdgcn_sqrtf(2.0f * __logf(op * 255.0f)));
-            }
+        if (P.has_opacity) {   // (uniform)
+            alive = alive && !(op < kAlphaThreshold);
+            extend = fminf(extend, __builtin_amdgcn_sqrtf(2.0f * __logf(op * 255.0f)));   // (a NaN -- op below 1 / 255 -- leaves 3.33; the lane is dead)
         }
+        const float rx = ceilf(extend * __builtin_amdgcn_sqrtf(a)), ry = ceilf(extend * __builtin_amdgcn_sqrtf(c));
+        alive = alive && !(rx <= P.radius_clip && ry <= P.radius_clip);
+        alive = alive && !(m2x + rx <= 0.f || m2x - rx >= P.W || m2y + ry <= 0.f || m2y - ry >= P.H);
+        const float inv_det = rcp_nr(det);
+        const float o_c0 = alive ? c * inv_det : 0.f, o_c1 = alive ? -b * inv_det : 0.f, o_c2 = alive ? a * inv_det : 0.f;
+        const int o_r0 = alive ? (int)rx : 0, o_r1 = alive ? (int)ry : 0;
+        const float o_m0 = alive ? m2x : 0.f, o_m1 = alive ? m2y : 0.f, o_d = alive ? z : 0.f;
+        return ProjOut{o_m0, o_m1, o_c0, o_c1, o_c2, o_d, o_r0, o_r1};
+    } else {
+        float o_m0 = 0.f, o_m1 = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_d = 0.f;
+        int o_r0 = 0, o_r1 = 0;
+
+        bool alive = !(z < P.near_plane || z > P.far_plane);
         if (alive) {
-            const float rx = ceilf(extend * __builtin_amdgcn_sqrtf(a)), ry = ceilf(extend * __builtin_amdgcn_sqrtf(c));
-            if (rx <= P.radius_clip && ry <= P.radius_clip) alive = false;
-            if (m2x + rx <= 0.f || m2x - rx >= P.W || m2y + ry <= 0.f || m2y - ry >= P.H) alive = false;
+            const float4 q4 = ld_f32x4(quats, i);
+            float w = q4.x, x = q4.y, y = q4.z, zq = q4.w;
+            const float inv_norm = __builtin_amdgcn_rsqf(x * x + y * y + zq * zq + w * w);
+            w *= inv_norm; x *= inv_norm; y *= inv_norm; zq *= inv_norm;
+            const float x2 = x * x, y2 = y * y, z2 = zq * zq;
+            const float xy = x * y, xz = x * zq, yz = y * zq, wx = w * x, wy = w * y, wz = w * zq;
+            const float R00 = 1.f - 2.f * (y2 + z2), R01 = 2.f * (xy - wz), R02 = 2.f * (xz + wy);
+            const float R10 = 2.f * (xy + wz), R11 = 1.f - 2.f * (x2 + z2), R12 = 2.f * (yz - wx);
+            const float R20 = 2.f * (xz - wy), R21 = 2.f * (yz + wx), R22 = 1.f - 2.f * (x2 + y2);
+
+            const F3 s3 = ld_f32x3(scales, i);
+            float s0 = s3.x, s1 = s3.y, s2 = s3.z;
+            if (P.scales_are_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
+
+            // pinhole Jacobian with the 1.3x FOV clamp; T = J Wv (2x3)
+            float rz, m2x, m2y;
+            {   // means2d: IEEE 1 / z and the reference's products, uncontracted -- bit for bit the oracle's
+    #pragma clang fp contract(off)
+                rz = 1.0f / z;
+                m2x = P.fx * mx * rz + P.cx;
+                m2y = P.fy * my * rz + P.cy;
+            }
+            const float tx = z * fminf(P.lim_x_pos, fmaxf(-P.lim_x_neg, mx * rz));
+            const float ty = z * fminf(P.lim_y_pos, fmaxf(-P.lim_y_neg, my * rz));
+            const float J00 = P.fx * rz, J02 = -(J00 * tx) * rz;
+            const float J11 = P.fy * rz, J12 = -(J11 * ty) * rz;
+            const float T00 = J00 * V[0] + J02 * V[8], T01 = J00 * V[1] + J02 * V[9], T02 = J00 * V[2] + J02 * V[10];
+            const float T10 = J11 * V[4] + J12 * V[8], T11 = J11 * V[5] + J12 * V[9], T12 = J11 * V[6] + J12 * V[10];
+            // A = T R diag(s)
+            const float A00 = (T00 * R00 + T01 * R10 + T02 * R20) * s0, A01 = (T00 * R01 + T01 * R11 + T02 * R21) * s1,
+                        A02 = (T00 * R02 + T01 * R12 + T02 * R22) * s2;
+            const float A10 = (T10 * R00 + T11 * R10 + T12 * R20) * s0, A11 = (T10 * R01 + T11 * R11 + T12 * R21) * s1,
+                        A12 = (T10 * R02 + T11 * R12 + T12 * R22) * s2;
+            const float a = A00 * A00 + A01 * A01 + A02 * A02 + P.eps2d;
+            const float b = A00 * A10 + A01 * A11 + A02 * A12;
+            const float c = A10 * A10 + A11 * A11 + A12 * A12 + P.eps2d;
+
+            const float det = a * c - b * b;
+            alive = det > 0.f;
+
+            float extend = 3.33f;
+            if (alive && P.has_opacity) {
+                const float op = ld_f32(opacities, i, 1, 0);
+                if (op < kAlphaThreshold) {
+                    alive = false;
+                } else {
+                    extend = fminf(extend, __builtin_amdgcn_sqrtf(2.0f * __logf(op * 255.0f)));
+                }
+            }
             if (alive) {
-                const float inv_det = rcp_nr(det);
-                o_c0 = c * inv_det;
-                o_c1 = -b * inv_det;
-                o_c2 = a * inv_det;
-                o_r0 = (int)rx;
-                o_r1 = (int)ry;
-                o_m0 = m2x;
-                o_m1 = m2y;
-                o_d = z;
+                const float rx = ceilf(extend * __builtin_amdgcn_sqrtf(a)), ry = ceilf(extend * __builtin_amdgcn_sqrtf(c));
+                if (rx <= P.radius_clip && ry <= P.radius_clip) alive = false;
+                if (m2x + rx <= 0.f || m2x - rx >= P.W || m2y + ry <= 0.f || m2y - ry >= P.H) alive = false;
+                if (alive) {
+                    const float inv_det = rcp_nr(det);
+                    o_c0 = c * inv_det;
+                    o_c1 = -b * inv_det;
+                    o_c2 = a * inv_det;
+                    o_r0 = (int)rx;
+                    o_r1 = (int)ry;
+                    o_m0 = m2x;
+                    o_m1 = m2y;
+                    o_d = z;
+                }
             }
         }
+        return ProjOut{o_m0, o_m1, o_c0, o_c1, o_c2, o_d, o_r0, o_r1};
     }
-    return ProjOut{o_m0, o_m1, o_c0, o_c1, o_c2, o_d, o_r0, o_r1};
 }
 
 }  // namespace ms
