@@ -835,7 +835,8 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             const float *opac_b = opacities ? opacities + b0 : nullptr;
             const int64_t i = j;
             gi = (int)i;
-            const ms::ProjOut o = ms::project_one<uint32_t>(src, means3d + 3 * b0, scales + 3 * b0, quats + 4 * b0, opac_b, viewmat, P);
+            // (a depth-cut frame -- a scene of millions of Gaussians -- fetches everything with the mean: project_device.hpp)
+            const ms::ProjOut o = ms::project_one<uint32_t, CUT>(src, means3d + 3 * b0, scales + 3 * b0, quats + 4 * b0, opac_b, viewmat, P);
             // (a lean frame whose caller reads the projected arrays all the same -- a differentiable frame: its backward
             // and its intermediates -- writes both: the scatter kernel then still walks 12-byte records)
             bool arrays = LEAN == 0;

@@ -92,7 +92,7 @@ __device__ __forceinline__ float rcp_nr(float x) {   // 1 / x to ~0.5 ulp: v_rcp
 #ifndef MS_PROJECT_FLAT
 #define MS_PROJECT_FLAT 0
 #endif
-template <class Idx, bool FLAT = (MS_PROJECT_FLAT != 0)>
+template <class Idx, bool LOADS_FIRST = false, bool FLAT = (MS_PROJECT_FLAT != 0)>
 __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ means3d,
                                                const float *__restrict__ scales, const float *__restrict__ quats,
                                                const float *__restrict__ opacities,
@@ -179,8 +179,21 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
         int o_r0 = 0, o_r1 = 0;
 
         bool alive = !(z < P.near_plane || z > P.far_plane);
+        // LOADS_FIRST (the depth-cut count kernel, i.e. scenes of millions of Gaussians): the quaternion, the scales and the
+        // opacity fetched WITH the mean instead of behind the tests before them -- valid for any index below N; the arithmetic
+        // and its nesting are the same, and so are the bits (tests: a depth-cut frame equals its uncut twin).  Config 4's
+        // frame 0.2265 -> 0.2215 ms; on config 3's plain kernel the same change costs 0.8 us, so that one keeps the
+        // dependent loads.
+        float4 q4 = make_float4(0.f, 0.f, 0.f, 1.f);
+        F3 s3{0.f, 0.f, 0.f};
+        float op_first = 1.0f;
+        if constexpr (LOADS_FIRST) {
+            q4 = ld_f32x4(quats, i);
+            s3 = ld_f32x3(scales, i);
+            if (P.has_opacity) op_first = ld_f32(opacities, i, 1, 0);
+        }
         if (alive) {
-            const float4 q4 = ld_f32x4(quats, i);
+            if constexpr (!LOADS_FIRST) q4 = ld_f32x4(quats, i);
             float w = q4.x, x = q4.y, y = q4.z, zq = q4.w;
             const float inv_norm = __builtin_amdgcn_rsqf(x * x + y * y + zq * zq + w * w);
             w *= inv_norm; x *= inv_norm; y *= inv_norm; zq *= inv_norm;
@@ -190,7 +203,7 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
             const float R10 = 2.f * (xy + wz), R11 = 1.f - 2.f * (x2 + z2), R12 = 2.f * (yz - wx);
             const float R20 = 2.f * (xz - wy), R21 = 2.f * (yz + wx), R22 = 1.f - 2.f * (x2 + y2);
 
-            const F3 s3 = ld_f32x3(scales, i);
+            if constexpr (!LOADS_FIRST) s3 = ld_f32x3(scales, i);
             float s0 = s3.x, s1 = s3.y, s2 = s3.z;
             if (P.scales_are_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
 
@@ -222,7 +235,8 @@ __device__ __forceinline__ ProjOut project_one(Idx i, const float *__restrict__ 
 
             float extend = 3.33f;
             if (alive && P.has_opacity) {
-                const float op = ld_f32(opacities, i, 1, 0);
+                float op = op_first;
+                if constexpr (!LOADS_FIRST) op = ld_f32(opacities, i, 1, 0);
                 if (op < kAlphaThreshold) {
                     alive = false;
                 } else {
