@@ -40,7 +40,11 @@ are taken with, so that their kernel averages are those of the headline frame al
                         bit against the per-stage path;
   extras.cfg3_fwd_bwd   BASELINE config 3 as it is named (forward + backward, grads for means / scales / quats /
                         opacities / colours): ms per step, stage times from HIP events, rooflines of the two
-                        backward kernels on SURVEY 8(d)'s bytes.
+                        backward kernels on SURVEY 8(d)'s bytes;
+  extras.two_frames_in_flight, extras.morton_order   the asynchronous entry point; the same scene sorted along a Morton curve.
+N > 1 runs, unless --no-extras: extras.cfg5 (BASELINE config 5 on the N ranks' bands: frames/s, the same frame on one GPU in
+the same run, the bands bit-identical to it; round 5: the same on a PREPARED scene and with a float16 exchange) and
+extras.view_sharded (whole views per rank, one all-gather per call).
 """
 import argparse
 import json
@@ -160,7 +164,7 @@ def main():
             sc["features"] = sc["features"].half()
         return sc, cam, (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
 
-    def make_step(g, cam):
+    def make_step(g, cam, **kw):
         if world == 1:
             return lambda: ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
 
@@ -169,8 +173,8 @@ def main():
         # barrier() drains the last one, so exactly K complete frames are inside the timed region.
         def step():
             if not mode["async"]:
-                return render_gaussians_sharded(*g, cam, background_color=bg)
-            in_flight.append(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True))
+                return render_gaussians_sharded(*g, cam, background_color=bg, **kw)
+            in_flight.append(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True, **kw))
             if len(in_flight) > 1:
                 return in_flight.pop(0).wait()
         return step
@@ -422,6 +426,29 @@ def main():
                 extras["cfg5"]["speedup_vs_1_gpu"] = round(fps5 / one, 3)
                 verified = verified and extras["cfg5"]["bands_equal_single_gpu_frame"]
             barrier()
+            # not the headline: round 5's two options for the band path on this very frame -- a PREPARED scene (Morton order +
+            # block bounds: the band pre-cull skips blocks, the count kernel's gathers coalesce; a one-time preprocessing
+            # of the scene, untimed) and a float16 EXCHANGE (each rank rounds its band once; half the bytes over xGMI; the
+            # image comes back in float16)
+            try:
+                from mojosplat_amd.scene_order import prepare_scene
+                gp = prepare_scene(*g5).arrays
+                stepp = make_step(gp, cam5)
+                for _ in range(4):
+                    stepp()
+                extras["cfg5"]["prepared_scene_frames_per_s"] = round(timed_fps(stepp, 30, 5), 2)
+                step16 = make_step(gp, cam5, exchange_dtype=torch.float16)
+                for _ in range(4):
+                    step16()
+                extras["cfg5"]["prepared_scene_f16_exchange_frames_per_s"] = round(timed_fps(step16, 30, 5), 2)
+                img16 = render_gaussians_sharded(*gp, cam5, background_color=bg, exchange_dtype=torch.float16)
+                if rank == 0:
+                    fullp = ms.render_gaussians(*gp, cam5, background_color=bg, backend="hip")
+                    extras["cfg5"]["f16_exchange_is_the_rounded_frame"] = bool(torch.equal(img16, fullp.half()))
+                del gp, img16
+                barrier()
+            except Exception as e:  # noqa: BLE001  (same inputs, same code on every rank: they fail alike)
+                extras["cfg5"]["prepared_scene_error"] = repr(e)
         elif args.extras:
             # not the headline: the multi-view entry point (16 cameras per call, two views in flight)
             sc, cam, g = load(args.workload)
