@@ -53,6 +53,10 @@ def scene_struct(means3d, scales, quats, opacities, colors):
     S = _hip.Scene(N, m.data_ptr() if N else None, sc.data_ptr() if N else None, 1, q.data_ptr() if N else None,
                    op.data_ptr() if N else None, col.data_ptr() if N else None, cdt, C,
                    pb[0].data_ptr() if pb else None, pb[1] if pb else 0, pb[0].shape[0] if pb else 0)
+    # an earlier VERSION of these very tensors (updated in place since: an animated or a training scene) is stale for good --
+    # and may hold marshalled copies (float64 / strided inputs): drop it instead of waiting for sixteen newer scenes
+    for k_old in [k_ for k_, v_ in _scenes.items() if v_[1][0] is means3d]:
+        _scenes.pop(k_old)
     if len(_scenes) >= _SCENE_CAP:
         _scenes.pop(next(iter(_scenes)))
     # (the originals too: a marshalled copy's source must not change under the key's version check unnoticed)
