@@ -169,7 +169,10 @@ int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means
                   int W, int H, int tile_size, int tile_row_begin, int tile_row_end, const int32_t *tile_ranges,
                   const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids,
                   const LazyLists *lazy, const void *records, const int32_t *order, int clip_row16_begin,
-                  int clip_row16_end, void *after_raster_event, void *stream);
+                  int clip_row16_end, void *after_raster_event, void *stream,
+                  // a differentiable frame: every 8x8 quad leaves the Gaussians that passed its reach test, in list order, for the
+                  // backward rasteriser -- quad_lists i32[M * quads per tile], quad_counts i32[tiles * quads per tile] (or null)
+                  int32_t *quad_lists = nullptr, int32_t *quad_counts = nullptr);
 
 // rasterize_bwd.hip: ms_rasterize_to_pixels_3dgs_bwd with the forward frame's ready-made records (or null) and its
 // heaviest-first order of the image's tiles (16-px tiles only; or null: the kernel's own counting sort)
@@ -190,7 +193,8 @@ int rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const float *
                         int front_threshold, const int32_t *skip_flag, const float *render_colors,
                         const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
                         float *packed_rows, const int32_t *order, void *stream,
-                        int tile_row_begin = 0, int tile_row_end = -1);   // (a band of tile rows; -1: to the last row)
+                        int tile_row_begin = 0, int tile_row_end = -1,
+                        const int32_t *quad_lists = nullptr, const int32_t *quad_counts = nullptr);   // (a band of tile rows; -1: to the last row | the forward's per-quad lists: rasterize_fwd)
 
 // ... and its launch for the tiles the forward's clean-up pass redid (their sorted front ran out with pixels alive): a wave
 // per (tile, block, quad) walks the whole-tile sorted ids the forward's k_redo_sort left (redo_flag[tile] == 2); a tile that

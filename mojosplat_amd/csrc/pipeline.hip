@@ -42,7 +42,7 @@ namespace {
 
 struct WsLayout {
     size_t off_isect, isect_bytes, off_means2d, off_conics, off_depths, off_radii, off_ranges, off_info, off_bin_ranges,
-        off_bin_more, off_records, total;
+        off_bin_more, off_records, off_quad_counts, total;
 };
 
 WsLayout ws_layout(int64_t N, int tw, int th) {
@@ -59,6 +59,7 @@ WsLayout ws_layout(int64_t N, int tw, int th) {
     L.off_bin_ranges = o; o += ms::align_up(T * 8, 256);   // split frames: ranges / flags of the 32-px bins
     L.off_bin_more = o;   o += ms::align_up(T * 4, 256);
     L.off_records = o;    o += ms::align_up(n * sizeof(ms::RasterRecord), 256);   // the rasteriser's ready-made records
+    L.off_quad_counts = o; o += ms::align_up(T * 16 * 4, 256);   // a differentiable frame: entries of every 8x8 quad's list (<= 16 quads a tile)
     L.total = o;
     return L;
 }
@@ -72,6 +73,22 @@ static int ms_lazy_enabled() {
         return e ? atoi(e) != 0 : 1;
     }();
     return v;
+}
+
+// A differentiable frame's per-quad lists (rasterize.hip, RasterArgs::quad_lists): MOJOSPLAT_BWD_LISTS=0 switches them off (the
+// backward then tests and compacts every tile's list per quad again).  Quads per tile the frame keeps lists for: 4 or 16
+// (tiles of 16 / 32 px); coarser bins would want 64 four-byte slots per pair.
+static int ms_bwd_lists_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_BWD_LISTS");
+        return e ? atoi(e) != 0 : 1;
+    }();
+    return v;
+}
+static int quad_list_nq(int tile_size) {
+    if (tile_size <= 0 || tile_size % 16 != 0) return 0;
+    const int nsub = (tile_size / 16) * (tile_size / 16);
+    return nsub <= 4 ? 4 * nsub : 0;
 }
 
 static int ms_band_cull_enabled() {
@@ -285,6 +302,11 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
     // the rasteriser's ready-made records (3-channel forward frames): written by the projection kernel
     const bool use_records = CDIM == 3 && opacities && colors;
     const bool aux_frame = render_alphas || last_ids;   // a differentiable frame: ids must stay Gaussian indices
+    // ... and, on the lean path, every 8x8 quad leaves the backward its list (quads per tile; 0: no lists): 4 bytes per
+    // (pair, quad of its tile) behind the sorted ids of the intersection buffer, the counts in the workspace
+    const int list_nq = (render_alphas && !last_ids && use_records && ((uintptr_t)(ws + L.off_records) & 15) == 0 && ms_bwd_lists_enabled())
+                            ? quad_list_nq(tile_size) : 0;
+    int32_t *quad_counts = list_nq ? (int32_t *)(ws + L.off_quad_counts) : nullptr;
     void *records = use_records ? (void *)(ws + L.off_records) : nullptr;
     // the rasteriser launches its blocks heaviest list first (the count pass leaves the order of the binning
     // grid's tiles in the isect workspace); MOJOSPLAT_RASTER_ORDER=0: image order interleaved over the XCDs
@@ -329,7 +351,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
         // Sync-free frame (see below) -- decided here because such a frame also DEFERS the scans' total pass into
         // its scatter launch (binning.hip, deferred_total): the size record then reaches the host behind that launch
         const int64_t cap = split ? (isect_bytes > 768 ? (int64_t)((isect_bytes - 768) / 28) : 0)
-                                  : (isect_bytes > 512 ? (int64_t)((isect_bytes - 512) / 12) : 0);
+                                  : (isect_bytes > 768 ? (int64_t)((isect_bytes - (list_nq ? 768 : 512)) / (12 + 4 * list_nq)) : 0);
         const bool speculate = sync_event && isect_buf && cap > 0 && N > 0;   // (an empty set has null inputs: exact path, M = 0)
         const bool deferred = speculate && mirror && (split ? b1 > b0 : r1 > r0);
         // the previous frame on this record (same scratch, same grid) had no tile beyond the small sort class:
@@ -455,13 +477,15 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                            render_colors, render_alphas, last_ids,
                                            // (a light frame has no sorted FRONT a pixel could outlive: no clean-up launch)
                                            lazy && !bet_light ? &lazy_lists : nullptr,
-                                           records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream))
+                                           records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream,
+                                           list_nq ? (int32_t *)((char *)ids + ms::align_up((size_t)c * 4, 256)) : nullptr, quad_counts))
                 return rc;
             // (bit 9: the rasteriser was given lazily sorted fronts -- front counts and redo flags are this frame's; bit 10: a
             // lazily sorted frame -- no merge scratch in the exact layout.  ms_render_bwd reads both.)
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits |
                            (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0) | ((cull & 32) ? 2048 : 0) |
-                           (lazy_lists.verdict ? 4096 : 0);   // (bit 12: the clean-up launches were left to the finishing half)
+                           (lazy_lists.verdict ? 4096 : 0) |   // (bit 12: the clean-up launches were left to the finishing half)
+                           (list_nq ? 8192 : 0);               // (bit 13: the quads' lists for the backward sit behind the ids)
 #ifdef MS_DIAG
             {
                 MS_HP_T(hp_t6);
@@ -481,7 +505,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
         else MS_HIP(hipStreamSynchronize(stream));
         speculated = (host_info[7] & 1) != 0;
         if (speculated) {
-            const int64_t cap = split ? (int64_t)((isect_bytes - 768) / 28) : (int64_t)((isect_bytes - 512) / 12);
+            const int64_t cap = split ? (int64_t)((isect_bytes - 768) / 28) : (int64_t)((isect_bytes - (list_nq ? 768 : 512)) / (12 + 4 * list_nq));
             const int64_t cmax = split ? ms_split_max_entries() : 0x7fffffffll;
             const int64_t c = cap > cmax ? cmax : cap;
             const int64_t Ms = host_info[0];
@@ -518,9 +542,11 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                tile_row_end, backgrounds, workspace, workspace_bytes, isect_buf, isect_bytes, host_info,
                                (resume & ~0xff) | MS_RENDER_WHOLE, render_colors, render_alphas, last_ids,
                                speculated ? nullptr : stage_events, sync_event, stream_);
-    const size_t need = split ? split_isect_bytes(M) : ms_render_isect_bytes(M, n_xl > 0 && !lazy);
+    const size_t need = split ? split_isect_bytes(M)
+                              : ms_render_isect_bytes(M, n_xl > 0 && !lazy) + (list_nq ? ms::align_up((size_t)(M > 0 ? M : 1) * list_nq * 4, 256) : 0);
     host_info[5] = (int64_t)need;
     host_info[7] |= 4;  // the lists the caller may read back are in the EXACT layout (below)
+    host_info[7] = (host_info[7] & ~8192ll) | (list_nq ? 8192 : 0);
     {
         const bool fronts = !split && lazy && host_info[2] + host_info[3] + host_info[4] > 0;
         host_info[7] = (host_info[7] & ~(512ll | 1024ll)) | (fronts ? 512 : 0) | (lazy ? 1024 : 0);
@@ -559,7 +585,8 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                    tile_size, r0, r1, ranges, ids, render_colors, render_alphas, last_ids,
                                    lazy && host_info[2] + host_info[3] + host_info[4] > 0 ? &lazy_lists : nullptr,
                                    records, order, clip0, clip1,
-                                   (!speculated && stage_events) ? stage_events[3] : nullptr, stream))
+                                   (!speculated && stage_events) ? stage_events[3] : nullptr, stream,
+                                   list_nq ? (int32_t *)((char *)ids + ms::align_up((size_t)(M > 0 ? M : 1) * 4, 256)) : nullptr, quad_counts))
         return rc;
     return MS_OK;
 }
@@ -616,18 +643,26 @@ static int render_bwd_rows_impl(int64_t N, int CDIM, int W, int H, int tile_size
     MS_REQUIRE(workspace_bytes >= L.total, MS_ERR_WORKSPACE, "render_bwd: workspace %zu < %zu", workspace_bytes, L.total);
     const char *ws = (const char *)workspace;
     const int32_t *ranges = (const int32_t *)(ws + L.off_ranges);
-    size_t ids_off;
+    // (bit 13 of the frame's flag word: its quads' lists sit behind the sorted ids -- rasterize.hip, RasterArgs::quad_lists)
+    const int list_nq = (host_info[7] & 8192) ? quad_list_nq(tile_size) : 0;
+    size_t ids_off, lists_off;
     if (host_info[7] & 4) {
         ids_off = ms::align_up((size_t)M * 8, 256) * (n_xl > 0 && !(host_info[7] & 1024) ? 2 : 1);
+        lists_off = ids_off + ms::align_up((size_t)M * 4, 256);
     } else {
-        MS_REQUIRE(isect_bytes > 512, MS_ERR_WORKSPACE, "render_bwd: intersection buffer too small");
-        int64_t cap = (int64_t)((isect_bytes - 512) / 12);
+        MS_REQUIRE(isect_bytes > 768, MS_ERR_WORKSPACE, "render_bwd: intersection buffer too small");
+        int64_t cap = (int64_t)((isect_bytes - (list_nq ? 768 : 512)) / (12 + 4 * list_nq));
         cap = cap > 0x7fffffffll ? 0x7fffffffll : cap;
         ids_off = ms::align_up((size_t)cap * 8, 256);
+        lists_off = ids_off + ms::align_up((size_t)cap * 4, 256);
     }
     MS_REQUIRE(ids_off + (size_t)M * 4 <= isect_bytes, MS_ERR_WORKSPACE, "render_bwd: intersection buffer %zu does not hold %lld ids",
                isect_bytes, (long long)M);
+    MS_REQUIRE(!list_nq || lists_off + (size_t)M * list_nq * 4 <= isect_bytes, MS_ERR_WORKSPACE,
+               "render_bwd: intersection buffer %zu does not hold the quads' lists", isect_bytes);
     const int32_t *ids = (const int32_t *)((const char *)isect_buf + ids_off);
+    const int32_t *quad_lists = list_nq ? (const int32_t *)((const char *)isect_buf + lists_off) : nullptr;
+    const int32_t *quad_counts = list_nq ? (const int32_t *)(ws + L.off_quad_counts) : nullptr;
     const void *records = (const void *)(ws + L.off_records);
     MS_HIP(hipMemsetAsync(rows, 0, (size_t)N * 16 * sizeof(float), stream));
     // a lazily sorted frame: the lists are sorted as deep as the forward rasteriser walked them -- the tiles whose
@@ -638,7 +673,8 @@ static int render_bwd_rows_impl(int64_t N, int CDIM, int W, int H, int tile_size
     const int32_t *order = ms_order_enabled() ? ms::isect_order_array(ws + L.off_isect, N, tw, th) : nullptr;
     if (int rc = ms::rasterize_bwd_quads(N, M, records, backgrounds, W, H, tile_size, ranges, ids, 1,
                                          fronts ? ll.front_count : nullptr, ll.front_threshold, fronts ? ll.redo_flag : nullptr,
-                                         render_colors, render_alphas, v_render_colors, v_render_alphas, rows, order, stream_, r0, r1))
+                                         render_colors, render_alphas, v_render_colors, v_render_alphas, rows, order, stream_, r0, r1,
+                                         quad_lists, quad_counts))
         return rc;
     if (fronts)
         if (int rc = ms::rasterize_bwd_redo(N, M, records, backgrounds, W, H, tile_size, ranges,
@@ -720,8 +756,9 @@ extern "C" int ms_render_bwd(int64_t N, const float *means3d, const float *scale
     if (host_info[7] & 4) {
         ids_off = ms::align_up((size_t)M * 8, 256) * (n_xl > 0 && !(host_info[7] & 1024) ? 2 : 1);
     } else {
-        MS_REQUIRE(isect_bytes > 512, MS_ERR_WORKSPACE, "render_bwd: intersection buffer too small");
-        int64_t cap = (int64_t)((isect_bytes - 512) / 12);
+        MS_REQUIRE(isect_bytes > 768, MS_ERR_WORKSPACE, "render_bwd: intersection buffer too small");
+        const int list_nq = (host_info[7] & 8192) ? quad_list_nq(tile_size) : 0;   // (as render_bwd_rows_impl)
+        int64_t cap = (int64_t)((isect_bytes - (list_nq ? 768 : 512)) / (12 + 4 * list_nq));
         cap = cap > 0x7fffffffll ? 0x7fffffffll : cap;
         ids_off = ms::align_up((size_t)cap * 8, 256);
     }

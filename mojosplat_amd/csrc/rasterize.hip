@@ -72,6 +72,12 @@ struct RasterArgs {
     int order_bins, row0, row1;
     const float4 *records; // ready-made ms::RasterRecord per Gaussian (3 channels), or null: stage from the arrays
     ms::LazyLists lazy;   // front_count == nullptr: every list is fully sorted
+    // A differentiable frame (round 5): every 8x8 quad leaves the Gaussians that passed its reach test, in list order, up to the
+    // batch in which its last pixel stopped -- quad `qd` (block * 4 + quad) of a tile whose list is [start, start + n) writes
+    // quad_lists[start * quad_nq + qd * n ...] and its count to quad_counts[tile * quad_nq + qd].  The backward rasteriser
+    // (rasterize_bwdq.hip) walks these instead of testing and compacting the tile's whole list again per quad.
+    int32_t *quad_lists, *quad_counts;
+    int quad_nq;           // quads per tile: 4 * nsub
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -189,9 +195,10 @@ struct RasterStage {
 
 // One wave's share of a 16x16 block: NQ quads of block `sub` of tile `tile`, starting at quad part * NQ.  s_q: the
 // wave's NQ staging blocks.
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false>
 __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile, const int sub, const int part,
                                             RasterStage<CP, AUX> *s_q, const int diag_slot) {
+    static_assert(!LISTS || (PACKED && !AUX), "quad lists: the plain 3-channel kernel on ready-made records");
     static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
     using Stage = RasterStage<CP, AUX>;
     constexpr int CS = Stage::CS;
@@ -201,7 +208,12 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
     if (!A.order_bins) {   // a band cut at 16-px rows inside coarser tiles: blocks outside it are not this call's
         const int by16 = tile_y * A.nsx + sub_y;
-        if (by16 < A.row0 || by16 >= A.row1) return;
+        if (by16 < A.row0 || by16 >= A.row1) {
+            if constexpr (LISTS) {   // (nothing of this block is rendered: its quads leave empty lists)
+                if ((threadIdx.x & 63) < NQ) A.quad_counts[(size_t)tile * A.quad_nq + sub * 4 + qbase + (threadIdx.x & 63)] = 0;
+            }
+            return;
+        }
     }
     const int lane = threadIdx.x & 63;
     const int lx = lane & 7, ly = lane >> 3;
@@ -246,6 +258,20 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     float r_ca = 0.f, r_cb = 0.f, r_cc = 0.f, r_op = 0.f;
     float r_col[CP];
     int r_g = 0;
+    // LISTS: the Gaussian whose record r_a / r_b / r_c hold; how many entries each quad has left so far; whether it still has
+    // a live pixel (wave-uniform)
+    int g_staged = 0;
+    int q_written[NQ];
+    bool q_live[NQ];
+    int32_t *q_list[NQ];
+    if constexpr (LISTS) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            q_written[qi] = 0;
+            q_live[qi] = __any(kq[qi] != 0.f);
+            q_list[qi] = A.quad_lists + ((size_t)start * A.quad_nq + (size_t)(sub * 4 + qbase + qi) * (size_t)(end_all - start));
+        }
+    }
     auto fetch_id = [&](int b0) {
         const int idx = b0 + lane;
         r_g = idx < end ? A.flatten_ids[idx] : 0;
@@ -256,6 +282,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
             // ids outside [0, N) can only come from a sync-free frame that overflowed its buffer (the
             // frame is then redone); clamp so that even that frame never reads out of bounds
             const int g = min(max(r_g, 0), A.n_gauss - 1);
+            if constexpr (LISTS) g_staged = g;
             if constexpr (PACKED) {
                 const float4 *rec = A.records + 3 * (size_t)g;
                 r_a = rec[0]; r_b = rec[1]; r_c = rec[2];
@@ -341,6 +368,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
             const int n = __popcll(b);
             if ((mask >> qi) & 1) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                if constexpr (LISTS) {
+                    if (q_live[qi]) q_list[qi][q_written[qi] + pos] = g_staged;
+                }
 #if MS_RASTER_EXPANDED
                 if (expanded) {
                     const int q = qbase + qi;
@@ -365,6 +395,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
 #pragma unroll
                     for (int k = 0; k < CP; ++k) S.col[pos * CS + k] = r_col[k];
                 }
+            }
+            if constexpr (LISTS) {
+                if (q_live[qi]) q_written[qi] += n;
             }
             if (lane < kGroup) {
                 S.a[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -507,12 +540,20 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 }
                 for (; k0 < n; k0 += kGroup) t = trip(k0, t);
                 T[qi] = t;
-                any_live = any_live || __any(kq[qi] != 0.f);
+                const bool ql = __any(kq[qi] != 0.f);
+                if constexpr (LISTS) q_live[qi] = ql;
+                any_live = any_live || ql;
             }
         };
         if (check_sigma) blend_batch(std::true_type{});
         else blend_batch(std::false_type{});
         if (!any_live) break;
+    }
+    if constexpr (LISTS) {
+        if (lane == 0) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) A.quad_counts[(size_t)tile * A.quad_nq + sub * 4 + qbase + qi] = q_written[qi];
+        }
     }
 
 #ifdef MS_DIAG
@@ -569,7 +610,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     }
 }
 
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED>
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false>
 __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
     // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
     // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
@@ -606,7 +647,7 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? M
         sub = item - bt * A.nsub;
         tile = A.tile0 + bt;
     }
-    raster_tile<CP, ColorT, AUX, NQ, PACKED>(A, tile, sub, part, s_stage, wg * kParts + part);
+    raster_tile<CP, ColorT, AUX, NQ, PACKED, LISTS>(A, tile, sub, part, s_stage, wg * kParts + part);
 }
 
 // ---- clean-up pass of a lazily sorted frame -----------------------------------------------------
@@ -1265,6 +1306,11 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
     if constexpr (CP == 3) {
         if (A.records) {
             if (aux) MS_LAUNCH_RASTER_NQ(true, true);
+            else if (A.quad_lists) {   // a differentiable frame that leaves its quads' lists for the backward
+                if (A.parts == 2) hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 2, true, true>), grid, dim3(64), 0, stream, A);
+                else if (A.parts == 4) hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 1, true, true>), grid, dim3(64), 0, stream, A);
+                else hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 4, true, true>), grid, dim3(64), 0, stream, A);
+            }
             else MS_LAUNCH_RASTER_NQ(false, true);
             done = true;
         }
@@ -1355,7 +1401,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
                       int tile_row_end, const int32_t *tile_ranges, const int32_t *flatten_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
                       const ms::LazyLists *lazy, const void *records, const int32_t *order, int clip_row16_begin,
-                      int clip_row16_end, void *after_raster_event, void *stream) {
+                      int clip_row16_end, void *after_raster_event, void *stream, int32_t *quad_lists, int32_t *quad_counts) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd: bad N/M");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_fwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_fwd: CDIM %d not in 1..32", CDIM);
@@ -1383,6 +1429,11 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.nsx = (tile_size + 15) / 16;
     A.nsub = A.nsx * A.nsx;
     A.cdim = CDIM;
+    // (the quads' lists for the backward: the plain 3-channel kernel on ready-made records only)
+    const bool lists = quad_lists && quad_counts && A.records && !last_ids;
+    A.quad_lists = lists ? quad_lists : nullptr;
+    A.quad_counts = lists ? quad_counts : nullptr;
+    A.quad_nq = 4 * A.nsub;
     MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th,
                MS_ERR_INVALID_ARG, "rasterize_fwd: bad tile row band [%d,%d) of %d", tile_row_begin,
                tile_row_end, th);
@@ -1455,6 +1506,7 @@ int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const 
     A.render_colors = render_colors; A.render_alphas = nullptr; A.last_ids = nullptr;
     A.order = order;
     A.order_bins = order ? 1 : 0; A.row0 = r0; A.row1 = r1;
+    A.quad_lists = nullptr; A.quad_counts = nullptr; A.quad_nq = 4;   // (a split frame is never differentiable)
     A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     A.lazy = *lazy;
     A.lazy.front_count = nullptr;   // block lists are walked to their end; the bin's flag says whether that was all

@@ -81,6 +81,11 @@ struct BwdQArgs {
     const int32_t *order;           // the binning grid's tiles, heaviest first (or null: image order)
     int W, H, ts, tw, nsx, nsub, ntiles, ngrid, max_isects, n_gauss;
     int tile0;                      // first tile of the band the launch covers (image-order launches; an order lists its own tiles)
+    // Round 5: the forward's per-quad lists (rasterize.hip, RasterArgs::quad_lists) -- the Gaussians that passed quad qd's reach
+    // test, in list order, up to the batch in which the quad's last pixel stopped: the walk stages 64 of THEM a round, no
+    // fetch of the tile's other entries, no test, no compaction.  Null: the tile's list, tested per quad as the forward did.
+    const int32_t *quad_lists, *quad_counts;
+    int quad_nq;
 };
 
 struct BwdQStage {
@@ -111,6 +116,7 @@ __device__ __forceinline__ void wave_lds_sync_q() {
 }
 
 // One wave: quad `q` (0..3) of 16x16 block `sub` of tile `tile`.
+template <bool LISTS = false>
 __device__ __forceinline__ void bwd_quad(const BwdQArgs &A, const int tile, const int sub, const int q, BwdQStage &S) {
     constexpr float kInf = __builtin_huge_valf();
     const int lane = threadIdx.x & 63;
@@ -300,13 +306,31 @@ __device__ __forceinline__ void bwd_quad(const BwdQArgs &A, const int tile, cons
         wave_lds_sync_q();
     };
 
-    fetch_id(start);
+    // LISTS: the walk's bounds become [0, count) of the quad's own list, whose entries are Gaussian indices
+    const int32_t *qlist = nullptr;
+    int walk_lo = start, walk_hi = end;
+    if (LISTS) {
+        const int qd = sub * 4 + q;
+        qlist = A.quad_lists + ((size_t)start * A.quad_nq + (size_t)qd * (size_t)(end_all - start));
+        walk_lo = 0;
+        walk_hi = min(max(A.quad_counts[(size_t)tile * A.quad_nq + qd], 0), end_all - start);
+        if (walk_hi <= 0) return;
+    }
+    auto fetch_next = [&](int b0) __attribute__((always_inline)) {
+        if constexpr (LISTS) id_next = qlist[min(b0 + lane, walk_hi - 1)];
+        else fetch_id(b0);
+    };
+    fetch_next(walk_lo);
     gather();
-    fetch_id(start + kBatch);
+    fetch_next(walk_lo + kBatch);
     bool live = true;
-    for (int b0 = start; b0 < end && live; b0 += kBatch) {
+    for (int b0 = walk_lo; b0 < walk_hi && live; b0 += kBatch) {
         // --- the quad test of the forward kernel (exact ellipse-vs-rectangle, in log2 units on the record)
         bool reach = false, npd = false;
+        if constexpr (LISTS) {   // (every entry of the quad's list passed it in the forward)
+            reach = b0 + lane < walk_hi && (kBatch == 64 || lane < kBatch);
+            npd = reach && r_c.y == kInf;
+        } else
         if (b0 + lane < end && (kBatch == 64 || lane < kBatch)) {
             const float smax = r_c.y, nb_c = r_c.z, nb_a = r_c.w;
             if (smax == kInf) {
@@ -348,9 +372,9 @@ __device__ __forceinline__ void bwd_quad(const BwdQArgs &A, const int tile, cons
             S.c[kTile + n + lane] = make_float2(0.f, 0.f);
         }
         wave_lds_sync_q();
-        if (b0 + kBatch < end) {
+        if (b0 + kBatch < walk_hi) {
             gather();
-            fetch_id(b0 + 2 * kBatch);
+            fetch_next(b0 + 2 * kBatch);
         }
 
         int tbase = tbase0;
@@ -451,7 +475,7 @@ __device__ __forceinline__ void bwd_quad(const BwdQArgs &A, const int tile, cons
         const int n_pad = (n + kGroup - 1) / kGroup * kGroup;
         fill = kTile + n_pad - tbase;
         live = __any(kq != 0.f);
-        if (fill > 0 && live && b0 + kBatch < end) {
+        if (fill > 0 && live && b0 + kBatch < walk_hi) {
             wave_lds_sync_q();
             float4 ca, cb; float2 cc;
             if (lane < fill) { ca = S.a[tbase + lane]; cb = S.b[tbase + lane]; cc = S.c[tbase + lane]; }
@@ -467,6 +491,7 @@ __device__ __forceinline__ void bwd_quad(const BwdQArgs &A, const int tile, cons
 #ifndef MS_BWDQ_WAVES
 #define MS_BWDQ_WAVES 5
 #endif
+template <bool LISTS>
 __global__ __launch_bounds__(64, MS_BWDQ_WAVES) void k_rasterize_bwd_quads(BwdQArgs A) {
     __shared__ BwdQStage s_stage;
     // as k_rasterize_fwd with one quad per wave: the four waves of a block sit 8 blockIdx apart (one XCD, one L2), the
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(64, MS_BWDQ_WAVES) void k_rasterize_bwd_quads(BwdQA
         tile += A.tile0;
     }
     if (A.skip_flag && A.skip_flag[tile]) return;
-    bwd_quad(A, tile, sub, part, s_stage);
+    bwd_quad<LISTS>(A, tile, sub, part, s_stage);
 }
 
 // ---- the tiles the forward's clean-up pass redid ------------------------------------------------------------------
@@ -583,7 +608,8 @@ int ms::rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const flo
                             const int32_t *tile_ranges, const int32_t *ids, int id_stride, const int32_t *front_count,
                             int front_threshold, const int32_t *skip_flag, const float *render_colors,
                             const float *render_alphas, const float *v_render_colors, const float *v_render_alphas,
-                            float *packed_rows, const int32_t *order, void *stream, int tile_row_begin, int tile_row_end) {
+                            float *packed_rows, const int32_t *order, void *stream, int tile_row_begin, int tile_row_end,
+                            const int32_t *quad_lists, const int32_t *quad_counts) {
     MS_REQUIRE(N > 0 && M > 0 && M <= 0x7fffffffll && N <= 0x3ffffffll, MS_ERR_INVALID_ARG, "rasterize_bwd_quads: bad N/M");   // (rows are addressed by 32-bit byte offsets)
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0 && tile_size % 16 == 0, MS_ERR_INVALID_ARG,
                "rasterize_bwd_quads: the tile size must be a multiple of 16");
@@ -619,7 +645,11 @@ int ms::rasterize_bwd_quads(int64_t N, int64_t M, const void *records, const flo
     // (the tree variant of this walk -- one wave per 16x16 block, the nine sums by v_permlane32/16_swap + DPP, one row per
     // block -- was built and measured in round 4: exact to 2e-6, 310 us against this kernel's 274; commit 215461d)
     const unsigned grid = (unsigned)(((A.ngrid + 7) / 8) * 8 * 4);
-    hipLaunchKernelGGL(k_rasterize_bwd_quads, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    A.quad_lists = quad_lists && quad_counts ? quad_lists : nullptr;
+    A.quad_counts = quad_lists && quad_counts ? quad_counts : nullptr;
+    A.quad_nq = 4 * A.nsub;
+    if (A.quad_lists) hipLaunchKernelGGL(k_rasterize_bwd_quads<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_rasterize_bwd_quads<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -636,6 +666,7 @@ int ms::rasterize_bwd_redo(int64_t N, int64_t M, const void *records, const floa
                    v_render_colors && packed_rows, MS_ERR_INVALID_ARG, "rasterize_bwd_redo: null pointer");
     BwdRedoArgs R;
     BwdQArgs &A = R.a;
+    A.quad_lists = nullptr; A.quad_counts = nullptr; A.quad_nq = 4;   // (a redone tile's lists are the clean-up pass's: walked whole)
     A.records = (const float4 *)records;
     A.tile_ranges = tile_ranges;
     A.ids = ids;
