@@ -514,7 +514,11 @@ int ms_render_band_finish(const ms_band_frame *frame, const ms_band_lane *lane, 
  * The sorted Gaussian ids are the i32 array at byte offset align256(8 * capacity) of isect_buf on a
  * frame that ran sync-free (capacity = (isect_bytes - 512) / 12 entries), and at
  * align256(8 * M) * (1 + merge) on one that took the exact path (host_info[7] & 4 after the call;
- * merge = host_info[4] > 0). */
+ * merge = host_info[4] > 0).
+ * A differentiable frame (render_alphas given, three channels, tiles of 16 or 32 px) also leaves, behind those ids, the
+ * lists of its 8x8 quads for ms_render_bwd (host_info[7] & 8192): q = 4 or 16 quads a tile, 4 q more bytes per entry --
+ * capacity = (isect_bytes - 768) / (12 + 4 q) on the sync-free path, + align256(4 q M) bytes on the exact one (the size
+ * ms_render_fwd asks for in host_info[5] includes them). */
 int ms_render_workspace_layout(int64_t N, int tile_w, int tile_h, size_t *offsets);
 
 /* ms_isect_tiles_emit without the host knowing M: `isect_info_dev` is the DEVICE record written

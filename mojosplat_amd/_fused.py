@@ -150,7 +150,9 @@ def _count_frame(stats, frame, host, grew, counts_valid=True):
             stats["redone_exact"] = stats.get("redone_exact", 0) + 1
             isect = frame.isect if frame.own else frame.st["isect"]
             nbytes = 0 if isect is None else isect.numel()
-            cap = (nbytes - 768) // 28 if flags & 8 else (nbytes - 512) // 12
+            # (bit 13: a differentiable frame keeps its quads' lists behind the ids -- 4 more bytes per entry and quad of a tile)
+            per = 12 + (4 * 4 * max(1, frame.head[19] // 16) ** 2 if (flags & 8192) and hasattr(frame, "head") else 0)
+            cap = (nbytes - 768) // 28 if flags & 8 else (nbytes - (768 if per > 12 else 512)) // per
             if grew or int(host[0]) > cap:
                 why = "overflow"
             elif (flags & 32) and heavy > 0:

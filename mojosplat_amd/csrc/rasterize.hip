@@ -261,16 +261,20 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     // LISTS: the Gaussian whose record r_a / r_b / r_c hold; how many entries each quad has left so far; whether it still has
     // a live pixel (wave-uniform)
     int g_staged = 0;
-    int q_written[NQ];
+    unsigned q_at[NQ];   // where the quad's next entry goes (element index into quad_lists: scalar; < 2^31 for the <= 16 quads a tile lists are kept for)
     bool q_live[NQ];
-    int32_t *q_list[NQ];
     if constexpr (LISTS) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
-            q_written[qi] = 0;
             q_live[qi] = __any(kq[qi] != 0.f);
-            q_list[qi] = A.quad_lists + ((size_t)start * A.quad_nq + (size_t)(sub * 4 + qbase + qi) * (size_t)(end_all - start));
+            q_at[qi] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)start * (unsigned)A.quad_nq +
+                                                                      (unsigned)(sub * 4 + qbase + qi) * (unsigned)(end_all - start)));
         }
+    }
+    unsigned q_at0[NQ];
+    if constexpr (LISTS) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) q_at0[qi] = q_at[qi];
     }
     auto fetch_id = [&](int b0) {
         const int idx = b0 + lane;
@@ -369,7 +373,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
             if ((mask >> qi) & 1) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
                 if constexpr (LISTS) {
-                    if (q_live[qi]) q_list[qi][q_written[qi] + pos] = g_staged;
+                    if (q_live[qi]) A.quad_lists[q_at[qi] + (unsigned)pos] = g_staged;
                 }
 #if MS_RASTER_EXPANDED
                 if (expanded) {
@@ -397,7 +401,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 }
             }
             if constexpr (LISTS) {
-                if (q_live[qi]) q_written[qi] += n;
+                if (q_live[qi]) q_at[qi] += (unsigned)n;
             }
             if (lane < kGroup) {
                 S.a[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -552,7 +556,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     if constexpr (LISTS) {
         if (lane == 0) {
 #pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) A.quad_counts[(size_t)tile * A.quad_nq + sub * 4 + qbase + qi] = q_written[qi];
+            for (int qi = 0; qi < NQ; ++qi) A.quad_counts[(size_t)tile * A.quad_nq + sub * 4 + qbase + qi] = (int)(q_at[qi] - q_at0[qi]);
         }
     }
 

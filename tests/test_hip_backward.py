@@ -326,3 +326,51 @@ def test_render_gaussians_itself_is_differentiable(device):
         assert not ms.render_gaussians(*leaves, cam, background_color=bg).requires_grad
     with pytest.raises(ValueError):
         ms.render_gaussians(*[sc[k].clone().requires_grad_(True) for k in names], cam, background_color=bg, async_op=True)
+
+
+@pytest.mark.parametrize("px", [16, 32, 64])
+def test_backward_from_the_forwards_quad_lists_equals_the_backward_without_them(device, px, tmp_path):
+    """Round 5: a differentiable frame's rasteriser leaves every 8x8 quad the Gaussians that passed its reach test, and the
+    backward rasteriser walks those lists (csrc/rasterize.hip RasterArgs::quad_lists, rasterize_bwdq.hip; tiles of 16 / 32 px --
+    64-px bins keep none).  The switch is read once per process, so a CHILD process computes the same step with
+    MOJOSPLAT_BWD_LISTS=0 -- the backward testing and compacting every tile's list per quad itself -- and the two steps'
+    images are equal bit for bit, their gradients within the order of the float atomics; the frame's flag word says which
+    path ran."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f'''
+import sys, torch
+sys.path.insert(0, {root!r})
+import mojosplat_amd as ms
+from mojosplat_amd import _fused
+from mojosplat_amd.autograd import render_gaussians_trainable
+from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
+dev = torch.device("cuda", 0)
+sc, cam = randscene_v1(120_000, 1024, 576, ell=-3.4, seed=17, device=dev)
+leaves = [sc[k].clone().requires_grad_(True) for k in ("means3d", "scales", "quats", "opacities", "features")]
+bg = torch.tensor(BACKGROUND_V1, device=dev)
+v = torch.rand((576, 1024, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+out = {{}}
+for rep in range(3):   # (the third step runs sync-free on the second's buffer size)
+    for t in leaves: t.grad = None
+    img = render_gaussians_trainable(*leaves, cam, background_color=bg)
+    img.backward(v)
+out["img"] = img.detach().cpu()
+out["grads"] = [t.grad.detach().cpu() for t in leaves]
+out["flags"] = int(_fused._dev_state(dev, 0)["host_np"][7])
+torch.save(out, sys.argv[1])
+'''
+    outs = {}
+    for lists in ("1", "0"):
+        path = str(tmp_path / f"step_{lists}.pt")
+        env = dict(os.environ, MOJOSPLAT_BWD_LISTS=lists, MOJOSPLAT_BIN_PX=str(px))
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs[lists] = torch.load(path)
+    a, b = outs["1"], outs["0"]
+    assert bool(a["flags"] & 8192) == (px <= 32) and not (b["flags"] & 8192), (hex(a["flags"]), hex(b["flags"]))
+    assert torch.equal(a["img"], b["img"])
+    for name, ga, gb in zip(("means3d", "scales", "quats", "opacities", "colors"), a["grads"], b["grads"]):
+        assert_grad_close(f"lists-vs-none/{px}/{name}", ga, gb, rel=2e-5, elem_rel=5e-3, elem_p999=1e-3)
