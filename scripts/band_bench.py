@@ -134,7 +134,13 @@ def main():
         best_b = min(x["blocking_us_median"] for x in ranks)
         print(json.dumps(dict(workload=args.workload, order=args.order, exchange=args.exchange, world=world, plan=label, bounds=bounds, frames=args.frames,
                               slowest_blocking_us_median=worst_b, rank_spread=round(worst_b / best_b, 3),
-                              slowest_pipelined_us=worst_p, fps_bound_pipelined=round(1e6 / worst_p, 1), ranks=ranks)),
+                              slowest_pipelined_us=worst_p, fps_bound_pipelined=round(1e6 / worst_p, 1),
+                              host_own_us_median_max=max(x["host_own_us_median"] for x in ranks),
+                              notes="host_us_median is the BLOCKING call's duration on the host: it contains the wait for the band's size record, "
+                                    "i.e. the band's GPU time up to its scatter launch (and, with the clean-up deferred, a pipelined frame's "
+                                    "finish waits for the band's end).  What the HOST itself spends on a band frame is host_own_us_median = "
+                                    "host_begin_us_median (the asynchronous entry point's begin half: never waits) + host_finish_us_median (its "
+                                    "finishing half called with the device drained)", ranks=ranks)),
               flush=True)
 
     for world in [int(v) for v in args.worlds.split(",")]:
