@@ -610,7 +610,7 @@ def morton_leg(ms, _fused, g, cam, bg, ref_img, given_ms, frames=200):
     from mojosplat_amd.scene_order import morton_permutation
     perm = morton_permutation(g[0])
     gm = tuple(t[perm].contiguous() for t in g)
-    _fused._state.clear()
+    _fused.release_scratch()
     for _ in range(64):
         img = ms.render_gaussians(*gm, cam, background_color=bg, backend="hip")
     torch.cuda.synchronize()
@@ -620,7 +620,7 @@ def morton_leg(ms, _fused, g, cam, bg, ref_img, given_ms, frames=200):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / frames * 1e3
     # (back to the given order's scratch and hints for the legs that follow: a fresh lane, warmed up again)
-    _fused._state.clear()
+    _fused.release_scratch()
     for _ in range(8):
         ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
     torch.cuda.synchronize()

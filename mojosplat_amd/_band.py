@@ -32,12 +32,42 @@ _scenes = {}    # key -> (Scene struct, tensors kept alive)
 _SCENE_CAP = 16
 
 
+def _tkey(t):
+    # (round 6, advisor: a view such as means3d[:k] shares its base's data pointer AND version counter -- the extent is part
+    # of what a cached ms_scene describes, so shape, strides and dtype are part of the key)
+    return (t.data_ptr(), t._version, tuple(t.shape), t.stride(), t.dtype)
+
+
+def _lane_fence(dev):
+    """Make the caller's current stream wait for everything enqueued on the band lanes of `dev` so far: tensors the lanes may
+    still be reading or writing are about to go back to the caching allocator, which only knows the caller's stream."""
+    from ._fused import _lane_streams_if_any
+    cur = torch.cuda.current_stream(dev)
+    for s in _lane_streams_if_any(dev):
+        ev = torch.cuda.Event()
+        ev.record(s)
+        cur.wait_event(ev)
+
+
+def clear_scenes():
+    """Drop every cached ms_scene (release_scratch; the caller has synchronised the devices)."""
+    with _fused._frame_lock:
+        _scenes.clear()
+
+
 def scene_struct(means3d, scales, quats, opacities, colors):
-    """-> (ms_scene ctypes struct, N, channels) for these tensors as they are now (cached)."""
-    key = (means3d.data_ptr(), means3d._version, scales.data_ptr(), scales._version, quats.data_ptr(), quats._version,
-           opacities.data_ptr(), opacities._version, colors.data_ptr(), colors._version, colors.dtype)
+    """-> the ms_scene ctypes struct for these tensors as they are now (cached)."""
+    with _fused._frame_lock:
+        return _scene_struct(means3d, scales, quats, opacities, colors)
+
+
+def _scene_struct(means3d, scales, quats, opacities, colors):
+    key = _tkey(means3d) + _tkey(scales) + _tkey(quats) + _tkey(opacities) + _tkey(colors)
     hit = _scenes.get(key)
     if hit is not None:
+        # (belt and braces: the struct's N is what band_begin sizes the workspace from)
+        if hit[0].N != means3d.shape[0]:
+            raise RuntimeError("cached ms_scene does not describe these tensors")
         return hit[0]
     from .scene_order import prepared_bounds
     N = means3d.shape[0]
@@ -55,12 +85,18 @@ def scene_struct(means3d, scales, quats, opacities, colors):
                    pb[0].data_ptr() if pb else None, pb[1] if pb else 0, pb[0].shape[0] if pb else 0)
     # an earlier VERSION of these very tensors (updated in place since: an animated or a training scene) is stale for good --
     # and may hold marshalled copies (float64 / strided inputs): drop it instead of waiting for sixteen newer scenes
-    for k_old in [k_ for k_, v_ in _scenes.items() if v_[1][0] is means3d]:
-        _scenes.pop(k_old)
-    if len(_scenes) >= _SCENE_CAP:
-        _scenes.pop(next(iter(_scenes)))
+    evicted = [k_ for k_, v_ in _scenes.items() if v_[1][0] is means3d]
+    if len(_scenes) - len(evicted) >= _SCENE_CAP:
+        evicted.append(next(k_ for k_ in _scenes if k_ not in evicted))
+    if evicted:
+        # (round 6, advisor: an evicted entry may own marshalled copies that a begun band on a lane stream still reads; the
+        # allocator re-issues them on the caller's stream, so that stream first waits for the lanes)
+        _lane_fence(means3d.device)
+        for k_old in evicted:
+            _scenes.pop(k_old)
     # (the originals too: a marshalled copy's source must not change under the key's version check unnoticed)
-    _scenes[key] = (S, (means3d, scales, quats, opacities, colors, m, sc, q, op, col, pb[0] if pb else None))
+    S._keep = (means3d, scales, quats, opacities, colors, m, sc, q, op, col, pb[0] if pb else None)
+    _scenes[key] = (S, S._keep)
     return S
 
 
@@ -168,7 +204,8 @@ def band_begin(means3d, scales, quats, opacities, colors, camera, bg, tile_size,
     st["busy"] = True
     h = BandHandle()
     h.rec, h.shape, h.level, h.mode, h.channels, h.done = rec, shape, level, mode, C, False
-    h.keep = (S, vm, bgc, out, evs)   # alive until the frame is finished
+    # alive until the frame is finished (the scene's tensors and marshalled copies too: the cache may evict the entry)
+    h.keep = (S, S._keep, vm, bgc, out, evs)
     return h
 
 
@@ -193,8 +230,12 @@ def band_finish(h, caller_stream):
             if rc == 2:   # MS_ERR_WORKSPACE: the intersection buffer is too small for this band's pairs
                 need = int(host[5])
                 grew = need > 0
-                if need > 0 and (st["isect"] is None or st["isect"].numel() < need):
-                    isect = _fused._grow(st, "isect", need, rec.dev, slack=1.25)
+                if need > 0:
+                    # (round 6, advisor: ALWAYS resume against the state's current buffer -- the lane struct may have been
+                    # built against an older, smaller one while st["isect"] is already large enough)
+                    isect = st["isect"]
+                    if isect is None or isect.numel() < need:
+                        isect = _fused._grow(st, "isect", need, rec.dev, slack=1.25)
                     lane.isect_buf, lane.isect_bytes = isect.data_ptr(), isect.numel()
                     rec.isect_id = isect.data_ptr()
                     rc = L.ms_render_band_finish(ctypes.byref(f), ctypes.byref(lane), caller_stream, 1, rec.status)

@@ -86,6 +86,10 @@ def release_scratch():
         for dev in devs:
             torch.cuda.synchronize(dev)
         _state.clear()
+        # (round 6, advisor: the scene caches pin whole scenes -- marshalled copies, prepared bounds -- on the device)
+        from . import _band, scene_order
+        _band.clear_scenes()
+        scene_order.clear_registry()
 
 
 def _dev_state(dev, lane=0):
@@ -610,6 +614,11 @@ def _pick_lane_pair(pair_ratio, with_current):
         if best is None or score < best[0] - 0.01:
             best = (score, (a, b))
     return best[1]
+
+
+def _lane_streams_if_any(dev):
+    """The lane streams of `dev` if a frame ever asked for them (no calibration is started here)."""
+    return list(_lanes.get(dev) or ())
 
 
 def _lane_streams(dev):

@@ -515,7 +515,16 @@ def render_gaussians_sharded(means3d, scales, quats, opacities, features, camera
             own_slot(buf).copy_(own[:n_own])                    # (on `now`, which band_finish has ordered behind the lane)
         img, works = exchange(buf, on_grid, m, culled)          # the collectives' stream waits for `now`
         return resolve(img, works)                              # ... and `now` for the exchange
-    return PendingFrame(finalize=finalize, on_drop=lambda st=h.rec.st: st.__setitem__("busy", False))
+    def on_drop(st=h.rec.st, lane_stream=lanes[lane]):
+        # (round 6, advisor) dropped without wait(): the lane's kernels may still be writing the framebuffer / slab, which the
+        # closure above is about to hand back to the caching allocator -- an allocator that only knows the caller's stream.
+        # record_stream defers their re-issue until the lane has passed this point.  (The scene's tensors and marshalled
+        # copies stay alive through the handle and the scene cache, whose eviction fences the lanes itself: _band.py.)
+        for t in (buf, own):
+            if t is not None:
+                t.record_stream(lane_stream)
+        st["busy"] = False
+    return PendingFrame(finalize=finalize, on_drop=on_drop)
 
 
 @torch.no_grad()

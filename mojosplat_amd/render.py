@@ -274,7 +274,10 @@ def render_gaussians(
     and every other call is the inference frame below, run under no_grad exactly as the reference runs.  (bin_size and
     async_op are inference-frame arguments; a differentiable call ignores bin_size -- the pixels and the gradients do not
     depend on the binning grid -- and refuses async_op.)"""
-    if backend == "hip" and torch.is_grad_enabled() and any(
+    # (round 6, advisor: the differentiable frame is for CUDA tensors only -- CPU inputs fall through to the reference's
+    # "must be CUDA tensors" ValueError below instead of failing inside the autograd wrapper)
+    if backend == "hip" and torch.is_grad_enabled() and all(
+            isinstance(t, torch.Tensor) and t.is_cuda for t in (means3d, scales, quats, opacities, features)) and any(
             isinstance(t, torch.Tensor) and t.requires_grad for t in (means3d, scales, quats, opacities, features, background_color)):
         if async_op:
             raise ValueError("async_op: a differentiable frame is rendered by the blocking call")

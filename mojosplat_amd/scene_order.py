@@ -55,7 +55,21 @@ class PreparedScene:
         return (self.means3d, self.scales, self.quats, self.opacities, self.features)
 
 
-_registry = {}   # id(means3d) -> (weakref to means3d, means version, scales weakref, scales version, PreparedScene)
+# id(means3d) -> (weakref to means3d, means version, scales weakref, scales version, block bounds, block size).  Round 6
+# (advisor): the entry holds NO strong reference to the scene's arrays -- a PreparedScene the caller has dropped frees its
+# Gaussians, and a finalizer on the means takes the entry (and the bounds buffer it keeps) out.
+_registry = {}
+_registry_lock = __import__("threading").Lock()
+
+
+def clear_registry():
+    with _registry_lock:
+        _registry.clear()
+
+
+def _forget(key):
+    with _registry_lock:
+        _registry.pop(key, None)
 
 
 def prepare_scene(means3d, scales, quats, opacities, features, block_size: int = BLOCK_SIZE, reorder: bool = True) -> PreparedScene:
@@ -84,18 +98,19 @@ def prepare_scene(means3d, scales, quats, opacities, features, block_size: int =
     # the view below keeps all of it alive and starts where the buffer does)
     nb = -(-N // block_size) if N > 0 else 0
     ps = PreparedScene(m, sc, quats, opacities, features, perm, bounds[:max(nb, 1) * 8].view(-1, 8), block_size)
-    if len(_registry) > 64:
-        _registry.clear()
-    _registry[id(m)] = (weakref.ref(m), m._version, weakref.ref(sc), sc._version, ps)
+    with _registry_lock:
+        _registry[id(m)] = (weakref.ref(m), m._version, weakref.ref(sc), sc._version, ps.block_bounds, block_size)
+    weakref.finalize(m, _forget, id(m))
     return ps
 
 
 def prepared_bounds(means3d, scales):
     """-> (block_bounds tensor, block_size) if these very tensors -- unmodified since -- belong to a prepared scene, else None."""
-    rec = _registry.get(id(means3d))
+    with _registry_lock:
+        rec = _registry.get(id(means3d))
     if rec is None:
         return None
-    m_ref, m_ver, s_ref, s_ver, ps = rec
+    m_ref, m_ver, s_ref, s_ver, bounds, block_size = rec
     if m_ref() is not means3d or s_ref() is not scales or means3d._version != m_ver or scales._version != s_ver:
         return None
-    return ps.block_bounds, ps.block_size
+    return bounds, block_size

@@ -315,7 +315,7 @@ def test_training_step_on_stranded_bins_is_exact_and_bounded(device):
             times.append(ms_)
             assert torch.equal(img, ref_img), f"step {k}: the image differs from the per-stage path"
             for name, a, b in zip(names, grads, ref_grads):
-                assert_grad_close(f"step {k} {name}", a, b, rel=2e-3, elem_rel=1e-1, elem_p999=5e-3)
+                assert_grad_close(f"step {k} {name}", a, b, rel=2e-3, elem_rel=5e-2, elem_p999=5e-3)
     finally:
         _fused.FRAME_STATS = None
         _fused._state.clear()

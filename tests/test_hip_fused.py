@@ -89,6 +89,35 @@ def test_band_calls_assemble_the_full_frame(device):
     assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True).wait(), ref)
 
 
+def test_sharded_path_tells_a_prefix_view_from_its_scene(device):
+    """Round-6 advisor finding: `means3d[:k]` shares its base's data pointer and version counter, so the cached ms_scene of
+    the full scene must not be handed to a render of the prefix (or the reverse): every call through the sharded path equals
+    the single-GPU frame of exactly the arrays it was given."""
+    from mojosplat_amd.distributed import band_plan, render_gaussians_sharded
+    sc, cam = randscene_v1(20_000, 480, 272, ell=-3.0, seed=3, device=device)
+    bg = torch.tensor(BACKGROUND_V1, device=device)
+    g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    for k in (20_000, 5_000, 20_000, 64, 5_000):
+        gk = tuple(t[:k] for t in g)
+        ref = ms.render_gaussians(*gk, cam, background_color=bg, backend="hip")
+        assert torch.equal(render_gaussians_sharded(*gk, cam, background_color=bg), ref), k
+        assert torch.equal(render_gaussians_sharded(*gk, cam, background_color=bg, async_op=True).wait(), ref), k
+        rows, bands = band_plan(-(-cam.H // 16), 2)
+        for r, (r0, r1) in enumerate(bands):
+            y0, y1 = min(r0 * 16, cam.H), min(r1 * 16, cam.H)
+            band = render_gaussians_sharded(*gk, cam, background_color=bg, rehearse=(r, 2))
+            assert torch.equal(band[y0:y1], ref[y0:y1]), (k, r)
+    # an in-place update that does not bump the version counter is the caller's to announce (release_scratch); one that does
+    # is noticed
+    g[0].add_(0.25)
+    ref = ms.render_gaussians(*g, cam, background_color=bg, backend="hip")
+    assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg), ref)
+    # a PendingFrame dropped unwaited gives its lane back and the next frames are unharmed
+    for _ in range(3):
+        render_gaussians_sharded(*g, cam, background_color=bg, async_op=True)
+    assert torch.equal(render_gaussians_sharded(*g, cam, background_color=bg, async_op=True).wait(), ref)
+
+
 def test_sharded_bands_with_an_explicit_tile_size_and_on_sparse_scenes(device):
     """(1) render_gaussians_sharded(tile_size=32 / 64): band plan, slab and the band handed to the library are in
     rows of THAT tile size (the 16-px-row mode belongs to rule-chosen bins under 16-px tiles only) -- every rehearsed

@@ -351,3 +351,37 @@ def test_lane_pair_choice_from_a_calibration():
     shared[(2, 5)] = 1.3
     assert _pick_lane_pair(shared, [1.2] * 6) == (2, 5)
     assert _pick_lane_pair({(0, 1): 1.95}, [1.9, 1.9]) == (0, 1)
+
+
+def test_scene_cache_key_tells_views_apart_and_registry_holds_no_scene():
+    """Round-6 advisor findings, the host logic that runs without a GPU: (1) the band path's ms_scene cache key includes
+    extent and strides -- a prefix view shares its base's data pointer and version counter; (2) the prepared-scene registry
+    keeps weak references only, and its entry goes when the means tensor does."""
+    import gc
+    import weakref
+
+    import torch
+    from mojosplat_amd import _band, scene_order
+    m = torch.zeros(100, 3)
+    assert m[:10].data_ptr() == m.data_ptr() and m[:10]._version == m._version
+    assert _band._tkey(m) != _band._tkey(m[:10])
+    assert _band._tkey(m) != _band._tkey(m.double())
+    assert _band._tkey(m) == _band._tkey(m)
+    v0 = _band._tkey(m)
+    m.add_(1.0)
+    assert _band._tkey(m) != v0
+    # the registry: an entry built by hand the way prepare_scene builds it
+    sc = torch.zeros(100, 3)
+    bounds = torch.zeros(1, 8)
+    with scene_order._registry_lock:
+        scene_order._registry[id(m)] = (weakref.ref(m), m._version, weakref.ref(sc), sc._version, bounds, 256)
+    weakref.finalize(m, scene_order._forget, id(m))
+    assert scene_order.prepared_bounds(m, sc) == (bounds, 256) or scene_order.prepared_bounds(m, sc)[1] == 256
+    assert scene_order.prepared_bounds(m[:10], sc) is None      # (a view is another object)
+    key = id(m)
+    sc.add_(1.0)
+    assert scene_order.prepared_bounds(m, sc) is None           # scales changed in place: bounds void
+    del m
+    gc.collect()
+    assert key not in scene_order._registry
+    scene_order.clear_registry()
