@@ -849,7 +849,11 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 depths[i] = o.d;
                 reinterpret_cast<int2 *>(radii)[i] = make_int2(o.r0, o.r1);
             }
+#ifdef MS_ABL_NOREC   // (measurement builds, profiles/r06_project_hist_isa.md: never the shipped library)
+            if (false) {
+#else
             if (rec && o.r0 > 0 && o.r1 > 0) {
+#endif
                 if constexpr (CUT) {
                     rec_pending = true;
                     rec_b0 = b0; rec_src = src;
@@ -861,7 +865,11 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             if (o.r0 > 0 && o.r1 > 0) {
                 on_grid = bin_box<PACK>(make_float2(o.m0, o.m1), make_int2(o.r0, o.r1), g, x0, x1, y0, y1, edges);
                 n = (x1 - x0) * (y1 - y0);
+#ifdef MS_ABL_NOMASK
+                if (false) {
+#else
                 if (masks) {
+#endif
                     if (LEAN == 2 && n > 32) mask = ~0ull;   // (a 12-byte record has room for 32 tiles' worth)
                     else
                     if (PACK && n <= 16 && n > 0)   // per half-tile cell (the 16x16 blocks of a 32-px bin)
@@ -931,7 +939,9 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
                 }
             }
         } else {
+#ifndef MS_ABL_NOWALK
             walk_boxes<PACK>(gi, x0, x1, y0, y1, n, edges, g, mask, count_plain, &bigq);
+#endif
         }
     }
     // (the boxes of more than kCoopThreshold tiles that the waves queued: all sixteen waves take them in turn)
