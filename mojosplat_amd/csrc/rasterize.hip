@@ -78,6 +78,7 @@ struct RasterArgs {
     // (rasterize_bwdq.hip) walks these instead of testing and compacting the tile's whole list again per quad.
     int32_t *quad_lists, *quad_counts;
     int quad_nq;           // quads per tile: 4 * nsub
+    int nvb;               // persistent launch (round 6): virtual workgroup indices in all (what a one-block-per-wave launch's grid would be)
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -157,6 +158,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef MS_RASTER_GROUP
 #define MS_RASTER_GROUP 2
 #endif
+#ifndef MS_RASTER_CHAINS
+#define MS_RASTER_CHAINS 0     // 1: the measurement variant of profiles/r06_raster_startup.md (waves that walk chains of blocks)
+#endif
 #ifndef MS_RASTER_EXPANDED
 #define MS_RASTER_EXPANDED 0   // 1: the measurement variant of profiles/r05_raster_expanded.md (never the shipped library)
 #endif
@@ -193,27 +197,57 @@ struct RasterStage {
     float4 b[kSlots];        // c', log2(opacity), (r, g | index in batch, -)
 };
 
+// Round 6: PERSISTENT waves (profiles/r06_raster_startup.md).  A wave that is its own workgroup pays its start-up chain --
+// tile range -> ids -> records -> LDS, three dependent round trips -- alone, before its first blend: 48 % of all wave cycles at
+// config 2, 28 % on an edge band of config 5, 14 % at config 3 (scripts/raster_waves.py).  A persistent wave walks several
+// blocks (virtual workgroup indices vb, vb + grid, ...) and issues the NEXT block's first ids and records where the current
+// block's list has none left to prefetch -- into the very registers the within-list prefetch uses, so no register is added:
+//   carry = 1: r_g holds the next block's first batch of ids;  2: r_a / r_b / r_c its records and r_g its second batch of ids.
+struct RasterNext {
+    int carry;            // in: what the previous block of this wave left for THIS block; out: what this block leaves
+    int valid;            // a next block exists and its list is not empty
+    int start, end;       // the next block's list (as raster_tile will compute it)
+};
+
+// a tile's list as the rasteriser walks it: [start, end) of the sorted ids, end_all = where the whole list ends
+__device__ __forceinline__ void raster_list_bounds(const RasterArgs &A, const int tile, int &start, int &end, int &end_all) {
+    // clamped to the list length the caller vouches for (a sync-free frame passes its buffer capacity)
+    end_all = min(A.tile_ranges[2 * tile + 1], A.max_isects);
+    start = min(A.tile_ranges[2 * tile], end_all);
+    // lazily sorted frame: a heavy tile's list is only sorted up to its front
+    end = end_all;
+    if (A.lazy.front_count && end_all - start > A.lazy.front_threshold) end = start + min(A.lazy.front_count[tile], end_all - start);
+}
+
+// (a band cut at 16-px rows inside coarser tiles: blocks outside it are not this call's)
+__device__ __forceinline__ bool raster_block_in_band(const RasterArgs &A, const int tile, const int sub) {
+    if (A.order_bins) return true;
+    const int by16 = (tile / A.tw) * A.nsx + sub / A.nsx;
+    return by16 >= A.row0 && by16 < A.row1;
+}
+
 // One wave's share of a 16x16 block: NQ quads of block `sub` of tile `tile`, starting at quad part * NQ.  s_q: the
 // wave's NQ staging blocks.
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false>
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false, bool PERSIST = false>
 __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile, const int sub, const int part,
-                                            RasterStage<CP, AUX> *s_q, const int diag_slot) {
+                                            RasterStage<CP, AUX> *s_q, const int diag_slot,
+                                            float4 &r_a, float4 &r_b, float4 &r_c, int &r_g, RasterNext &nx) {
+    static_assert(!PERSIST || (PACKED && !AUX && !LISTS), "persistent waves: the plain kernel on ready-made records");
     static_assert(!LISTS || (PACKED && !AUX), "quad lists: the plain 3-channel kernel on ready-made records");
     static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
     using Stage = RasterStage<CP, AUX>;
     constexpr int CS = Stage::CS;
-    MS_DIAG_ONLY(const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime(), diag_c0 = __builtin_amdgcn_s_memtime(); unsigned diag_evals = 0, diag_batches = 0;)
+    MS_DIAG_ONLY(const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime(), diag_c0 = __builtin_amdgcn_s_memtime(); unsigned diag_evals = 0, diag_batches = 0; unsigned long long diag_first = 0;)
     const int qbase = NQ == 4 ? 0 : part * NQ;
     const int tile_y = tile / A.tw, tile_x = tile - tile_y * A.tw;
     const int sub_y = sub / A.nsx, sub_x = sub - sub_y * A.nsx;
-    if (!A.order_bins) {   // a band cut at 16-px rows inside coarser tiles: blocks outside it are not this call's
-        const int by16 = tile_y * A.nsx + sub_y;
-        if (by16 < A.row0 || by16 >= A.row1) {
-            if constexpr (LISTS) {   // (nothing of this block is rendered: its quads leave empty lists)
-                if ((threadIdx.x & 63) < NQ) A.quad_counts[(size_t)tile * A.quad_nq + sub * 4 + qbase + (threadIdx.x & 63)] = 0;
-            }
-            return;
+    const int have = PERSIST ? nx.carry : 0;   // (wave-uniform) what the wave's previous block fetched of this one's list
+    if constexpr (PERSIST) nx.carry = 0;
+    if (!raster_block_in_band(A, tile, sub)) {   // a band cut at 16-px rows inside coarser tiles: blocks outside it are not this call's
+        if constexpr (LISTS) {   // (nothing of this block is rendered: its quads leave empty lists)
+            if ((threadIdx.x & 63) < NQ) A.quad_counts[(size_t)tile * A.quad_nq + sub * 4 + qbase + (threadIdx.x & 63)] = 0;
         }
+        return;
     }
     const int lane = threadIdx.x & 63;
     const int lx = lane & 7, ly = lane >> 3;
@@ -241,23 +275,18 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         for (int k = 0; k < CP; ++k) pix[qi][k] = 0.f;
     }
 
-    // clamped to the list length the caller vouches for (a sync-free frame passes its buffer capacity)
-    const int end_all = min(A.tile_ranges[2 * tile + 1], A.max_isects);
-    const int start = min(A.tile_ranges[2 * tile], end_all);
-    // lazily sorted frame: a heavy tile's list is only sorted up to its front
-    int end = end_all;
-    if (A.lazy.front_count && end_all - start > A.lazy.front_threshold) end = start + min(A.lazy.front_count[tile], end_all - start);
+    int start, end, end_all;
+    raster_list_bounds(A, tile, start, end, end_all);
     const ColorT *colors = reinterpret_cast<const ColorT *>(A.colors);
     const float fbx = (float)bx + 0.5f, fby = (float)by + 0.5f;
     // (here rather than at the kernel's first line: s_setreg is a scheduling barrier, and up there it cost the
     // headline variant a spilled VGPR -- 8 MB of scratch writes per frame, WRITE_SIZE 25.7 -> 33.6 MB)
     flush_fp32_denormals();
 
-    // what the staging lane holds of its entry: the record's three words (PACKED), or the per-stage fields
-    float4 r_a = make_float4(0.f, 0.f, 0.f, 0.f), r_b = r_a, r_c = r_a;
+    // what the staging lane holds of its entry: the record's three words (PACKED: r_a / r_b / r_c, the caller's -- a persistent
+    // wave carries them from block to block), or the per-stage fields
     float r_ca = 0.f, r_cb = 0.f, r_cc = 0.f, r_op = 0.f;
     float r_col[CP];
-    int r_g = 0;
     // LISTS: the Gaussian whose record r_a / r_b / r_c hold; how many entries each quad has left so far; whether it still has
     // a live pixel (wave-uniform)
     int g_staged = 0;
@@ -301,10 +330,39 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         }
     };
 
+    // PERSIST: the next block's first ids go where this list has nothing left to fetch ahead (r_g is free then); its records
+    // follow on this list's last batch, once that batch is staged (r_a / r_b / r_c are free then)
+    bool rg_next = false;   // r_g holds (or is loading) the next block's first batch of ids
+    int rg_age = 0;         // blend loops since they were asked for: >= 1 -> they have landed behind one
+    auto fetch_ahead = [&](int b) __attribute__((always_inline)) {
+        if (b < end) fetch_id(b);
+        else if constexpr (PERSIST) {
+            if (nx.valid && !rg_next) {
+                const int idx = nx.start + lane;
+                r_g = idx < nx.end ? A.flatten_ids[idx] : 0;
+                rg_next = true;
+                rg_age = 0;
+            }
+        }
+    };
+    auto gather_next = [&]() __attribute__((always_inline)) {
+        if constexpr (PERSIST) {
+            const int idx = nx.start + lane;
+            if (idx < nx.end) {
+                const int g = min(max(r_g, 0), A.n_gauss - 1);
+                const float4 *rec = A.records + 3 * (size_t)g;
+                r_a = rec[0]; r_b = rec[1]; r_c = rec[2];
+            }
+            const int idx2 = idx + kBatch;
+            r_g = idx2 < nx.end ? A.flatten_ids[idx2] : 0;
+            rg_next = false;
+            nx.carry = 2;
+        }
+    };
     if (start < end) {
-        fetch_id(start);
-        gather(start);
-        fetch_id(start + kBatch);
+        if (have == 0) fetch_id(start);
+        if (have <= 1) gather(start);
+        if (have <= 1 || start + kBatch >= end) fetch_ahead(start + kBatch);
     }
     for (int b0 = start; b0 < end; b0 += kBatch) {
         // --- stage this batch: reach of the alpha >= 1/255 ellipse -> quad votes -> compacted records in LDS
@@ -404,11 +462,15 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 if (q_live[qi]) q_at[qi] += (unsigned)n;
             }
             if (lane < kGroup) {
-                S.a[n + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-                S.b[n + lane] = make_float4(0.f, -kInf, 0.f, 0.f);   // log2(alpha) = -inf: alpha = 0, never a hit
+                // (the two constants are made HERE: hoisted out of the batch loop as eight registers of zeros and -inf they
+                // were the first thing the persistent kernel spilled)
+                float zero = 0.f, ninf = -kInf;
+                if constexpr (PERSIST) asm volatile("" : "+v"(zero), "+v"(ninf));
+                S.a[n + lane] = make_float4(zero, zero, zero, zero);
+                S.b[n + lane] = make_float4(zero, ninf, zero, zero);   // log2(alpha) = -inf: alpha = 0, never a hit
                 if constexpr (CP == 3) {
                     if constexpr (AUX) reinterpret_cast<float2 *>(S.col)[n + lane] = make_float2(0.f, 0.f);
-                    else S.col[n + lane] = 0.f;
+                    else S.col[n + lane] = zero;
                 }
                 else {
 #pragma unroll
@@ -419,9 +481,13 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         wave_lds_sync();
         if (b0 + kBatch < end) {  // next batch's data and the one after's ids fly during compositing
             gather(b0 + kBatch);
-            fetch_id(b0 + 2 * kBatch);
+            fetch_ahead(b0 + 2 * kBatch);
+        } else if constexpr (PERSIST) {
+            // the list's last batch is staged: the next block's records fly during its compositing (ids asked for a blend
+            // loop ago have landed; a one-batch list's are still in flight -- its records go out behind the loop instead)
+            if (rg_next && rg_age >= 1) gather_next();
         }
-        MS_DIAG_ONLY(++diag_batches;)
+        MS_DIAG_ONLY(if (diag_batches == 0) diag_first = __builtin_amdgcn_s_memtime() - diag_c0; ++diag_batches;)   // (first batch staged: the start-up chain range -> ids -> records -> LDS is behind the wave)
 
         // sigma < 0 (skipped by the reference, rasterization.mojo:144) cannot happen for a positive
         // definite conic, and alpha = o exp(-sigma) <= o cannot exceed 0.999 unless o does: only a
@@ -551,7 +617,14 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         };
         if (check_sigma) blend_batch(std::true_type{});
         else blend_batch(std::false_type{});
+        if constexpr (PERSIST) {
+            ++rg_age;
+            if (rg_next && b0 + kBatch >= end) gather_next();
+        }
         if (!any_live) break;
+    }
+    if constexpr (PERSIST) {
+        if (rg_next) nx.carry = 1;   // (the walk ended early: the ids are all the next block gets)
     }
     if constexpr (LISTS) {
         if (lane == 0) {
@@ -566,6 +639,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         d[0] = diag_t0;                               // 100 MHz, chip-wide
         d[1] = __builtin_amdgcn_s_memrealtime();
         d[4] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this wave's life
+        d[5] = diag_first;                              // ... of which before its first blend loop (0: an empty list)
         d[2] = ((unsigned long long)diag_batches << 32) | diag_evals;
         d[3] = ((unsigned long long)(end_all - start) << 32) | (unsigned)(__builtin_amdgcn_s_getreg((4 << 11) | 20) & 0xf) << 24 | (unsigned)(tile & 0xffffff);
     }
@@ -614,35 +688,36 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     }
 }
 
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false>
-__global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
+// virtual workgroup index -> (16x16 block of a tile, which of the block's waves); false: nothing to rasterise there
+template <int NQ>
+__device__ __forceinline__ bool raster_map_block(const RasterArgs &A, const int vb, int &tile, int &sub, int &part, int &slot) {
     // Every wave is a workgroup of its own (wave slots refill one by one; four-wave workgroups measured the same
-    // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at blockIdx b, b + 8, b + 16,
+    // kernel time at 78 % instead of 86 % residency); the 4 / NQ waves of a block sit at index b, b + 8, b + 16,
     // ...: dealt round-robin over the 8 XCDs, they land on ONE XCD back to back and share its L2 for the list they
     // all stage (speed only, never correctness)
     constexpr int kParts = 4 / NQ;
-    __shared__ RasterStage<CP, AUX> s_stage[NQ];
-    int wg = blockIdx.x, part = 0;   // workgroup index in units of blocks, and which of the block's waves this is
+    int wg = vb;   // workgroup index in units of blocks, and which of the block's waves this is
+    part = 0;
     if constexpr (kParts > 1) {
-        const int j = blockIdx.x >> 3;
+        const int j = vb >> 3;
         part = j % kParts;
-        wg = ((j / kParts) << 3) | (blockIdx.x & 7);
-        if (wg >= A.ngrid) return;
+        wg = ((j / kParts) << 3) | (vb & 7);
+        if (wg >= A.ngrid) return false;
     }
-    // blockIdx -> 16x16 block: heaviest first when the binning stage has left an order, else image order
+    slot = wg * kParts + part;
+    // index -> 16x16 block: heaviest first when the binning stage has left an order, else image order
     // interleaved over the XCDs
-    int tile, sub;
     if (A.order && A.order_bins) {   // split frame: the order lists 32-px bins, four workgroups (blocks) per bin
         const int e = A.order[wg >> 2], sb = wg & 3;
         const int by16 = 2 * (e / A.lazy.bin_w) + (sb >> 1), bx16 = 2 * (e % A.lazy.bin_w) + (sb & 1);
-        if (bx16 >= A.tw || by16 < A.row0 || by16 >= A.row1) return;   // (uniform per workgroup; no barrier anywhere)
+        if (bx16 >= A.tw || by16 < A.row0 || by16 >= A.row1) return false;   // (uniform per workgroup; no barrier anywhere)
         tile = by16 * A.tw + bx16;
         sub = 0;
     } else if (A.order) {
         // the nsub 16x16 blocks of a coarse tile on ONE XCD (wg & 7 labels it), back to back: they gather the
         // same records, so the tile's list and records cross into that L2 once instead of nsub times
         const int e = ((wg >> 3) / A.nsub) * 8 + (wg & 7);
-        if (e >= A.nblocks / A.nsub) return;   // (uniform per workgroup; the grid is padded to 8 tiles)
+        if (e >= A.nblocks / A.nsub) return false;   // (uniform per workgroup; the grid is padded to 8 tiles)
         tile = A.order[e];
         sub = (wg >> 3) % A.nsub;
     } else {
@@ -651,7 +726,62 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? M
         sub = item - bt * A.nsub;
         tile = A.tile0 + bt;
     }
-    raster_tile<CP, ColorT, AUX, NQ, PACKED, LISTS>(A, tile, sub, part, s_stage, wg * kParts + part);
+    return true;
+}
+
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false, bool PERSIST = false>
+__global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
+    __shared__ RasterStage<CP, AUX> s_stage[NQ];
+    float4 r_a = make_float4(0.f, 0.f, 0.f, 0.f), r_b = r_a, r_c = r_a;
+    int r_g = 0;
+    RasterNext nx{0, 0, 0, 0};
+    if constexpr (!PERSIST) {
+        int tile, sub, part, slot;
+        if (!raster_map_block<NQ>(A, (int)blockIdx.x, tile, sub, part, slot)) return;
+        raster_tile<CP, ColorT, AUX, NQ, PACKED, LISTS, false>(A, tile, sub, part, s_stage, slot, r_a, r_b, r_c, r_g, nx);
+    } else {
+        // A persistent wave: virtual indices blockIdx, blockIdx + grid, ... (the grid is a multiple of 8 x the waves per
+        // block, so an index keeps its XCD label and a block's waves stay neighbours).  Odd rounds run through the grid
+        // backwards WITHIN the XCD's share: the order is heaviest first, so a wave that drew a heavy block of one round
+        // draws a light one of the next.  Launched for frames with a heaviest-first order of whole tiles only (nsub a power
+        // of two: 1, 4, 16): the index -> block mapping is then shifts and one load, nothing to keep in scalar registers
+        // across a block (the general mapping's divisions spilled 66 of them to vector lanes).
+        constexpr int kParts = 4 / NQ;
+        const int G = (int)gridDim.x;
+        const int sh = A.nsx == 1 ? 0 : A.nsx == 2 ? 2 : 4;   // log2(nsub)
+        // -> tile | sub << 24 | part << 28, or -1
+        auto block_of = [&](int round) __attribute__((always_inline)) -> int {
+            const int w = (int)blockIdx.x;
+            const int x = (round & 1) ? ((((G >> 3) - 1 - (w >> 3)) << 3) | (w & 7)) : w;
+            const int vb = round * G + x;
+            if (vb >= A.nvb) return -1;
+            const int j = vb >> 3;
+            const int part = kParts > 1 ? j % kParts : 0;
+            const int wg = kParts > 1 ? (((j / kParts) << 3) | (vb & 7)) : vb;
+            if (wg >= A.ngrid) return -1;
+            const int e = (((wg >> 3) >> sh) << 3) | (wg & 7);
+            if (e >= (A.nblocks >> sh)) return -1;   // (the grid is padded to 8 tiles)
+            return A.order[e] | (((wg >> 3) & ((1 << sh) - 1)) << 24) | (part << 28);
+        };
+        int cur = block_of(0);
+        for (int round = 0; round * G < A.nvb; ++round) {
+            // the block after this one: its list's bounds are needed before this block's last batch
+            const int nxt = block_of(round + 1);
+            nx.valid = 0;
+            if (nxt >= 0 && raster_block_in_band(A, nxt & 0xffffff, (nxt >> 24) & 15)) {
+                int e_all;
+                raster_list_bounds(A, nxt & 0xffffff, nx.start, nx.end, e_all);
+                nx.valid = nx.start < nx.end ? 1 : 0;
+            }
+            if (cur >= 0) {
+                const int tile = cur & 0xffffff, sub = (cur >> 24) & 15, part = cur >> 28;
+                int slot = 0;
+                MS_DIAG_ONLY(slot = (round * G + (int)blockIdx.x);)   // (diagnostic stamps: one slot per (wave, round))
+                raster_tile<CP, ColorT, AUX, NQ, PACKED, LISTS, true>(A, tile, sub, part, s_stage, slot, r_a, r_b, r_c, r_g, nx);
+            } else nx.carry = 0;
+            cur = nxt;
+        }
+    }
 }
 
 // ---- clean-up pass of a lazily sorted frame -----------------------------------------------------
@@ -1260,6 +1390,17 @@ static int raster_parts_override() {
     return v;
 }
 
+// MOJOSPLAT_RASTER_CHAIN=k: blocks a rasteriser wave walks one after the other (1: one block per wave, as rounds 2-5;
+// A/B: profiles/r06_raster_startup.md)
+static int raster_chain() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_RASTER_CHAIN");
+        const int k = e ? atoi(e) : 1;
+        return k >= 1 && k <= 16 ? k : 1;
+    }();
+    return v;
+}
+
 static unsigned redo_grid(const RasterArgs &A) { return (unsigned)(A.lazy.redo_grid >= 1 && A.lazy.redo_grid <= 4096 ? A.lazy.redo_grid : 64); }
 
 // The clean-up launches behind a lazily sorted frame's rasteriser: empty on almost every frame.
@@ -1307,7 +1448,33 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
         else MS_LAUNCH_RASTER(AUXV, 4, PK);                    \
     } while (0)
     bool done = false;
+#if MS_RASTER_CHAINS   // (measurement builds, profiles/r06_raster_startup.md: -DMS_RASTER_CHAINS=1; never the shipped library)
     if constexpr (CP == 3) {
+        if (A.records && !aux && !A.quad_lists && A.order && !A.order_bins && (A.nsx == 1 || A.nsx == 2 || A.nsx == 4) && (raster_chain() > 1 || getenv("MOJOSPLAT_RASTER_CHAIN_KERNEL"))) {   // (the second: the chain kernel walking one block, to tell its code from its schedule)
+            // persistent waves (round 6): as many as the chip holds at once, each walking blocks index, index + grid, ...
+            RasterArgs P = A;
+            P.nvb = (int)grid.x;
+            // CHAINS of blocks: a wave walks `chain` blocks -- index, index + grid, ... with grid = indices / chain -- and the
+            // waves are still dispatched one by one as slots come free.  (All waves resident at once and each walking a
+            // fixed share of ALL blocks was measured first: the static shares end 25 % apart -- 125 us against 96 at
+            // config 3, resident waves falling from 60 % of the kernel on: profiles/r06_raster_startup.md.)
+            const int chain = raster_chain();
+            auto launch_p = [&](auto kernel, int parts) {
+                const int unit = 8 * parts;
+                int g = ((P.nvb + chain - 1) / chain + unit - 1) / unit * unit;
+                if (g <= 0) g = unit;
+                hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(64), 0, stream, P);
+            };
+            if (A.parts == 2) launch_p(k_rasterize_fwd<CP, ColorT, false, 2, true, false, true>, 2);
+            else if (A.parts == 4) launch_p(k_rasterize_fwd<CP, ColorT, false, 1, true, false, true>, 4);
+            else launch_p(k_rasterize_fwd<CP, ColorT, false, 4, true, false, true>, 1);
+            done = true;
+        }
+    }
+#endif
+    if constexpr (CP == 3) {
+        if (done) {
+        } else
         if (A.records) {
             if (aux) MS_LAUNCH_RASTER_NQ(true, true);
             else if (A.quad_lists) {   // a differentiable frame that leaves its quads' lists for the backward

@@ -20,7 +20,8 @@ import mojosplat_amd as ms  # noqa: E402
 from mojosplat_amd import _hip  # noqa: E402
 from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1  # noqa: E402
 
-CFG = {"cfg2": (100_000, 1920, 1080, -4.0), "cfg3": (1_000_000, 1920, 1080, -4.0), "cfg5": (5_000_000, 3840, 2160, -4.0),
+CFG = {"cfg5edge": (5_000_000, 3840, 2160, -4.0),   # the first of eight balanced bands of config 5 (rows 0-16 of 135)
+       "cfg2": (100_000, 1920, 1080, -4.0), "cfg3": (1_000_000, 1920, 1080, -4.0), "cfg5": (5_000_000, 3840, 2160, -4.0),
        "cfg3-heavy": (1_000_000, 1920, 1080, -3.0)}
 
 
@@ -34,12 +35,21 @@ def main():
     sc, cam = randscene_v1(N, W, H, ell=ell, device=dev)
     bg = torch.tensor(BACKGROUND_V1, device=dev)
     g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+    band = None
+    if name == "cfg5edge":
+        from mojosplat_amd import _fused
+        band = (0, 17)
+
+    def frame():
+        if band is None:
+            return ms.render_gaussians(*g, cam, background_color=bg)
+        return _fused.render_fwd_hip(*g, cam, bg, 16, row_range=band)
     for _ in range(5):
-        ms.render_gaussians(*g, cam, background_color=bg)
+        frame()
     nmax = 4 * (-(-W // 16) + 2) * (-(-H // 16) + 2)
     buf = torch.zeros(nmax * 8, dtype=torch.int64, device=dev)
     _hip.check(L.ms_diag_set_stamps(ctypes.c_void_p(buf.data_ptr())), "diag")
-    ms.render_gaussians(*g, cam, background_color=bg)
+    frame()
     torch.cuda.synchronize()
     _hip.check(L.ms_diag_set_stamps(None), "diag")
     d = buf.cpu().numpy().reshape(-1, 8)
@@ -74,6 +84,20 @@ def main():
         m = (crowd[sel] >= lo) & (crowd[sel] < hi)
         if m.any():
             out[f"cycles_per_eval_when_{lo}_{hi}_waves_resident"] = float(np.median(tpe[m]))
+    # round 6: the start-up chain (wave start -> first batch staged: tile range -> ids -> records -> LDS, three dependent
+    # round trips) against the wave's life
+    first = d[:, 5].astype(np.float64)
+    has = first > 0
+    if has.any():
+        out["startup_cycles"] = {k: float(np.percentile(first[has], q)) for k, q in (("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99))}
+        out["startup_share_of_wave_life_p50"] = float(np.median(first[has] / np.maximum(cyc[has], 1.0)))
+        out["startup_share_of_all_wave_cycles"] = float(first[has].sum() / cyc.sum())
+        out["waves_with_an_empty_list"] = int((~has).sum())
+        one = has & (batches <= 1)
+        out["one_batch_waves"] = int(one.sum())
+        if one.any():
+            out["one_batch_wave_life_cycles_p50"] = float(np.median(cyc[one]))
+            out["one_batch_startup_cycles_p50"] = float(np.median(first[one]))
     out["xcc_wave_counts"] = np.bincount(xcc, minlength=8).tolist()
     out["xcc_end_percent"] = [float((t1[xcc == x].max() - base) / span * 100) if (xcc == x).any() else None for x in range(8)]
     print(json.dumps(out))
