@@ -158,6 +158,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef MS_RASTER_GROUP
 #define MS_RASTER_GROUP 2
 #endif
+#ifndef MS_RASTER_LOCAL_CONST
+#define MS_RASTER_LOCAL_CONST 1
+#endif
 #ifndef MS_RASTER_CHAINS
 #define MS_RASTER_CHAINS 0     // 1: the measurement variant of profiles/r06_raster_startup.md (waves that walk chains of blocks)
 #endif
@@ -465,7 +468,11 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 // (the two constants are made HERE: hoisted out of the batch loop as eight registers of zeros and -inf they
                 // were the first thing the persistent kernel spilled)
                 float zero = 0.f, ninf = -kInf;
+#if MS_RASTER_LOCAL_CONST
+                asm volatile("" : "+v"(zero), "+v"(ninf));
+#else
                 if constexpr (PERSIST) asm volatile("" : "+v"(zero), "+v"(ninf));
+#endif
                 S.a[n + lane] = make_float4(zero, zero, zero, zero);
                 S.b[n + lane] = make_float4(zero, ninf, zero, zero);   // log2(alpha) = -inf: alpha = 0, never a hit
                 if constexpr (CP == 3) {
