@@ -59,7 +59,7 @@ WsLayout ws_layout(int64_t N, int tw, int th) {
     L.off_bin_ranges = o; o += ms::align_up(T * 8, 256);   // split frames: ranges / flags of the 32-px bins
     L.off_bin_more = o;   o += ms::align_up(T * 4, 256);
     L.off_records = o;    o += ms::align_up(n * sizeof(ms::RasterRecord), 256);   // the rasteriser's ready-made records
-    L.off_quad_counts = o; o += ms::align_up(T * 16 * 4, 256);   // a differentiable frame: entries of every 8x8 quad's list (<= 16 quads a tile)
+    L.off_quad_counts = o; o += ms::align_up(T * 64 * 4, 256);   // a differentiable frame: entries of every 8x8 quad's list (<= 64 quads a tile: bins of 64 px)
     L.total = o;
     return L;
 }
@@ -76,8 +76,11 @@ static int ms_lazy_enabled() {
 }
 
 // A differentiable frame's per-quad lists (rasterize.hip, RasterArgs::quad_lists): MOJOSPLAT_BWD_LISTS=0 switches them off (the
-// backward then tests and compacts every tile's list per quad again).  Quads per tile the frame keeps lists for: 4 or 16
-// (tiles of 16 / 32 px); coarser bins would want 64 four-byte slots per pair.
+// backward then tests and compacts every tile's list per quad again).  Quads per tile the frame keeps lists for: 4, 16 or
+// -- round 6 -- 64 (tiles of 16 / 32 / 64 px).  64 four-byte slots per pair are address space more than memory: a slot is
+// written only where a quad is reached (~1.5 of a pair's 64), the rest of the 268 bytes a pair reserves is never touched; what
+// it costs is the caching allocator's block (config 5 on 64-px bins: 3.3 GB of the GPU's 288 a frame in flight) --
+// MOJOSPLAT_BWD_LISTS_MAX_NQ=16 keeps rounds 5's limit.
 static int ms_bwd_lists_enabled() {
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_BWD_LISTS");
@@ -88,7 +91,12 @@ static int ms_bwd_lists_enabled() {
 static int quad_list_nq(int tile_size) {
     if (tile_size <= 0 || tile_size % 16 != 0) return 0;
     const int nsub = (tile_size / 16) * (tile_size / 16);
-    return nsub <= 4 ? 4 * nsub : 0;
+    static const int max_nq = [] {
+        const char *e = getenv("MOJOSPLAT_BWD_LISTS_MAX_NQ");
+        const int v = e ? atoi(e) : 64;
+        return v == 4 || v == 16 ? v : 64;
+    }();
+    return 4 * nsub <= max_nq ? 4 * nsub : 0;
 }
 
 static int ms_band_cull_enabled() {

@@ -293,17 +293,17 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
     // LISTS: the Gaussian whose record r_a / r_b / r_c hold; how many entries each quad has left so far; whether it still has
     // a live pixel (wave-uniform)
     int g_staged = 0;
-    unsigned q_at[NQ];   // where the quad's next entry goes (element index into quad_lists: scalar; < 2^31 for the <= 16 quads a tile lists are kept for)
+    unsigned long long q_at[NQ];   // where the quad's next entry goes (element index into quad_lists: scalar; 64 slots a pair on 64-px bins pass 2^32 from 67 M pairs on)
     bool q_live[NQ];
     if constexpr (LISTS) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
             q_live[qi] = __any(kq[qi] != 0.f);
-            q_at[qi] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)start * (unsigned)A.quad_nq +
-                                                                      (unsigned)(sub * 4 + qbase + qi) * (unsigned)(end_all - start)));
+            q_at[qi] = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(start) * (unsigned long long)(unsigned)A.quad_nq +
+                       (unsigned long long)(unsigned)(sub * 4 + qbase + qi) * (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(end_all - start);
         }
     }
-    unsigned q_at0[NQ];
+    unsigned long long q_at0[NQ];
     if constexpr (LISTS) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) q_at0[qi] = q_at[qi];
@@ -434,7 +434,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
             if ((mask >> qi) & 1) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
                 if constexpr (LISTS) {
-                    if (q_live[qi]) A.quad_lists[q_at[qi] + (unsigned)pos] = g_staged;
+                    if (q_live[qi]) A.quad_lists[q_at[qi] + (unsigned long long)(unsigned)pos] = g_staged;
                 }
 #if MS_RASTER_EXPANDED
                 if (expanded) {
@@ -462,7 +462,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 }
             }
             if constexpr (LISTS) {
-                if (q_live[qi]) q_at[qi] += (unsigned)n;
+                if (q_live[qi]) q_at[qi] += (unsigned long long)(unsigned)n;
             }
             if (lane < kGroup) {
                 // (the two constants are made HERE: hoisted out of the batch loop as eight registers of zeros and -inf they

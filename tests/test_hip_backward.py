@@ -331,8 +331,8 @@ def test_render_gaussians_itself_is_differentiable(device):
 @pytest.mark.parametrize("px", [16, 32, 64])
 def test_backward_from_the_forwards_quad_lists_equals_the_backward_without_them(device, px, tmp_path):
     """Round 5: a differentiable frame's rasteriser leaves every 8x8 quad the Gaussians that passed its reach test, and the
-    backward rasteriser walks those lists (csrc/rasterize.hip RasterArgs::quad_lists, rasterize_bwdq.hip; tiles of 16 / 32 px --
-    64-px bins keep none).  The switch is read once per process, so a CHILD process computes the same step with
+    backward rasteriser walks those lists (csrc/rasterize.hip RasterArgs::quad_lists, rasterize_bwdq.hip; tiles of 16 / 32 px and,
+    since round 6, 64-px bins: 64 slots a pair).  The switch is read once per process, so a CHILD process computes the same step with
     MOJOSPLAT_BWD_LISTS=0 -- the backward testing and compacting every tile's list per quad itself -- and the two steps'
     images are equal bit for bit, their gradients within the order of the float atomics; the frame's flag word says which
     path ran."""
@@ -370,7 +370,7 @@ torch.save(out, sys.argv[1])
         assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
         outs[lists] = torch.load(path)
     a, b = outs["1"], outs["0"]
-    assert bool(a["flags"] & 8192) == (px <= 32) and not (b["flags"] & 8192), (hex(a["flags"]), hex(b["flags"]))
+    assert (a["flags"] & 8192) and not (b["flags"] & 8192), (hex(a["flags"]), hex(b["flags"]))   # (round 6: lists on 64-px bins too)
     assert torch.equal(a["img"], b["img"])
     for name, ga, gb in zip(("means3d", "scales", "quats", "opacities", "colors"), a["grads"], b["grads"]):
         assert_grad_close(f"lists-vs-none/{px}/{name}", ga, gb, rel=2e-5, elem_rel=5e-3, elem_p999=1e-3)
