@@ -38,6 +38,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -721,7 +722,14 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     const void *__restrict__ colors, int color_f16, float4 *__restrict__ rec, Candidates cand,
     LeanRec *__restrict__ lean, uint32_t *__restrict__ wg_depth, const uint32_t *__restrict__ tau,
     uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp, LeanRec *__restrict__ near_recs,
-    int keep_arrays, int64_t near_cap, unsigned int big_q_off, unsigned int big_q_cap) {
+    int keep_arrays, int64_t near_cap, unsigned int big_q_off, unsigned int big_q_cap,
+    // Round 6 (claimed rows): tile_total != null -> the workgroup does not leave its counts as a histogram row for a prefix
+    // kernel; it CLAIMS its stretch of every tile's segment with one returning atomic per tile it holds pairs of
+    // (row[t] = atomicAdd(tile_total[t], count): which workgroup comes first within a tile is irrelevant -- every list is
+    // sorted by (depth bits, index) keys afterwards), and tile_total ends up as the tile counts.  k_tile_scan_wg -- 4 MB read,
+    // 4 MB written and a kernel boundary: 7.6 us of config 3's frame -- is not launched.  Workgroup 0 zeroes tile_total first
+    // and publishes the frame's stamp in *zero_flag; a workgroup reads the flag before its first claim (by then ~20 us old).
+    uint32_t *__restrict__ tile_total, unsigned long long *__restrict__ zero_flag, unsigned long long zero_stamp) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes] [+ the queue of big boxes]
     const int T_local = (g.row_end - g.row_begin) * g.tw;
     unsigned int &s_on_grid = s_cnt[T_local];
@@ -751,7 +759,15 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     // lean frames: the range of the depth bits of everything this workgroup's Gaussians can emit, for k_tile_front's
     // buckets (the scatter kernel -- a chain of round trips -- otherwise ends with this reduction and its barriers)
     uint32_t dmin = 0xffffffffu, dmax = 0u;
+    if (tile_total && blockIdx.x == 0) {
+        // write-through stores (the XCDs' L2s are not coherent with each other), drained by the storing wave itself before the
+        // barrier, then the flag: the hand-off pattern of k_tile_scan_wg
+        for (int t = threadIdx.x; t < T_local; t += kHistThreads) __hip_atomic_store(&tile_total[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
+    if (tile_total && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(zero_flag, zero_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     __shared__ uint32_t s_pref[kMaxG + 1];
     CandMap map{s_pref};
     const int wg = chunk_of_block(blockIdx.x, gridDim.x);   // this workgroup's histogram row (and share of the positions: Deal)
@@ -965,9 +981,19 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
         }
     }
     MS_BIN_STAMP(0, 1);
+    if (tile_total && threadIdx.x == 0) {
+        // (workgroup 0 is dispatched first and zeroes before anything else: the flag is there long before a workgroup gets here)
+        while (__hip_atomic_load(zero_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != zero_stamp) __builtin_amdgcn_s_sleep(2);
+    }
     __syncthreads();
     MS_BIN_STAMP(0, 2);
     uint32_t *row = hist + (size_t)wg * T_local;
+    if (tile_total) {
+        for (int t = threadIdx.x; t < T_local; t += kHistThreads) {
+            const uint32_t c = s_cnt[t];
+            row[t] = c ? __hip_atomic_fetch_add(&tile_total[t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+    } else
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
     if (threadIdx.x == 0) wg_on_grid[wg] = s_on_grid;
     if (threadIdx.x == 0 && blockIdx.x == 0) wg_on_grid[kMaxG] = 0;   // k_tile_scan_wg's arrival ticket
@@ -2618,6 +2644,14 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
         MS_LAUNCH_CHECK();
         cand = Candidates{(const int32_t *)(ws + p.off_cand), seg_count, p.G, p.chunk};
     }
+    // claimed rows (round 6): sync-free frames, whose total pass rides in the scatter launch, on a band that has tiles.
+    // MEASURED AND OFF by default (MOJOSPLAT_CLAIMED_ROWS=1 switches it on; profiles/r06_claimed_rows.md): the prefix kernel's
+    // 7.8 us go, but the claims' returning atomics add 4.2 us to this kernel's tail and the scatter kernel loses 3.0 us -- the
+    // stretches of a tile's segment now fall to the workgroups in order of arrival, so the eight XCDs interleave inside
+    // every line again (chunk_of_block's reason for being) -- 0.6 us of the frame in all.
+    static const bool claim_enabled = [] { const char *e = getenv("MOJOSPLAT_CLAIMED_ROWS"); return e && e[0] == '1'; }();
+    static std::atomic<unsigned long long> claim_stamps{0x5ca1ab1e00000000ull};   // (never a value fresh memory is likely to hold)
+    const bool claimed = claim_enabled && (tight & kDeferTotal) && p.T_local > 0;
     {   // also for N == 0 (one workgroup that walks nothing): the histogram row and the on-grid slot the
         // scans read must exist
         // lean frame: LeanRecs instead of the projected arrays (the caller vouches that nobody reads those)
@@ -2645,9 +2679,12 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                            (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg),
                            cut ? (const uint32_t *)(ws + p.off_tau) + (size_t)((tight >> 9) & 1) * p.T : nullptr, (uint32_t *)(ws + p.off_wg_far),
                            (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near), (tight & ms::kTightKeepArrays) ? 1 : 0, p.near_cap,
-                           big_q_off, big_q_cap);
+                           big_q_off, big_q_cap, claimed ? count : nullptr,
+                           // (the flag: two words of the 256-byte block the clean-up counts start -- words 0-2 -- 8-byte aligned)
+                           (unsigned long long *)(ws + p.off_redo_count + 64), claimed ? ++claim_stamps : 0ull);
         MS_LAUNCH_CHECK();
     }
+    if (claimed) return MS_OK;   // (the rows are exclusive offsets already, `count` the tile counts: no prefix kernel)
     return count_tail(p, g, ws, hist, count, medium, large, xl, on_grid, p.G, tile_ranges, isect_info,
                       (tight & 2) ? 1 : 0, isect_info_mirror, stream, (tight & kDeferTotal) != 0);
 }
