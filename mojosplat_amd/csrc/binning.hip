@@ -724,11 +724,14 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     uint32_t *__restrict__ wg_far, uint32_t *__restrict__ has_far, uint32_t cut_stamp, LeanRec *__restrict__ near_recs,
     int keep_arrays, int64_t near_cap, unsigned int big_q_off, unsigned int big_q_cap,
     // Round 6 (claimed rows): tile_total != null -> the workgroup does not leave its counts as a histogram row for a prefix
-    // kernel; it CLAIMS its stretch of every tile's segment with one returning atomic per tile it holds pairs of
-    // (row[t] = atomicAdd(tile_total[t], count): which workgroup comes first within a tile is irrelevant -- every list is
-    // sorted by (depth bits, index) keys afterwards), and tile_total ends up as the tile counts.  k_tile_scan_wg -- 4 MB read,
-    // 4 MB written and a kernel boundary: 7.6 us of config 3's frame -- is not launched.  Workgroup 0 zeroes tile_total first
-    // and publishes the frame's stamp in *zero_flag; a workgroup reads the flag before its first claim (by then ~20 us old).
+    // kernel; it CLAIMS its stretch of every tile's segment with one returning atomic per tile it holds pairs of, from the
+    // counters of its XCD (eight arrays of T_local: row[t] = atomicAdd(tile_total[xcd][t], count)).  Which workgroup comes
+    // first within an XCD's stretch is irrelevant -- every list is sorted by (depth bits, index) keys afterwards -- and the
+    // XCDs keep contiguous stretches of every segment (chunk_of_block); a tile's count is the sum of its eight counters, the
+    // stretch of XCD x starts behind those before it (the scatter kernel's cursors: tile_prefix_lds).  k_tile_scan_wg -- 4 MB
+    // read, 4 MB written and a kernel boundary: 7.6 us of config 3's frame -- is not launched.  Workgroup 0 zeroes the
+    // counters first and publishes the frame's stamp in *zero_flag; a workgroup reads the flag before its first claim (by
+    // then ~20 us old): nothing is carried from frame to frame.
     uint32_t *__restrict__ tile_total, unsigned long long *__restrict__ zero_flag, unsigned long long zero_stamp) {
     extern __shared__ uint32_t s_cnt[];  // T_local tile counters + the on-grid counter (+ a lean frame's depth range) [+ T_local cut-offs + T_local flag bytes] [+ the queue of big boxes]
     const int T_local = (g.row_end - g.row_begin) * g.tw;
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     if (tile_total && blockIdx.x == 0) {
         // write-through stores (the XCDs' L2s are not coherent with each other), drained by the storing wave itself before the
         // barrier, then the flag: the hand-off pattern of k_tile_scan_wg
-        for (int t = threadIdx.x; t < T_local; t += kHistThreads) __hip_atomic_store(&tile_total[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t = threadIdx.x; t < 8 * T_local; t += kHistThreads) __hip_atomic_store(&tile_total[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -991,7 +994,9 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     if (tile_total) {
         for (int t = threadIdx.x; t < T_local; t += kHistThreads) {
             const uint32_t c = s_cnt[t];
-            row[t] = c ? __hip_atomic_fetch_add(&tile_total[t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            // (the counters of this workgroup's XCD -- blockIdx & 7, the eighth of the rows chunk_of_block gives it: the XCDs keep
+            // contiguous stretches of every tile's segment, which the scatter kernel's write merging lives on)
+            row[t] = c ? __hip_atomic_fetch_add(&tile_total[(size_t)(blockIdx.x & 7) * T_local + t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
     } else
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
@@ -1060,7 +1065,20 @@ struct ScanTotalArgs {
     const LeanRec *near_recs;   // the records that keep a pair, compacted per count workgroup (wg_far[kMaxG + g] of them from g * near_cap on)
     int64_t near_cap;
     uint32_t *far_zero;   // 2 T words the clean-up launches count the regenerated pairs in: zeroed by the total pass
+    // claimed rows (round 6, MOJOSPLAT_CLAIMED_ROWS=1): the count kernel's workgroups claimed their stretches of every tile's
+    // segment from eight counter arrays, one per XCD (xtot[x * T_local + t]): a tile's count is their sum (the total pass
+    // writes it to tile_count), and the stretch of XCD x starts behind those of the XCDs before it
+    const uint32_t *xtot;
 };
+
+// a tile's count in the deferred passes: the prefix kernel's, or the sum of the eight XCDs' claims
+__device__ __forceinline__ uint32_t tile_count_of(const ScanTotalArgs &A, int t, int T_local) {
+    if (!A.xtot) return A.tile_count[t];
+    uint32_t c = 0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) c += A.xtot[(size_t)x * T_local + t];
+    return c;
+}
 
 // HANDOFF: the counts were written by other workgroups of the SAME launch (k_tile_scan_wg's last workgroup runs
 // this): agent-scope loads; a launch of its own reads them plainly.
@@ -1309,19 +1327,36 @@ __global__ __launch_bounds__(1024) void k_tile_scan_total(ScanTotalArgs A) { til
 // ceil(T / 1024) consecutive entries, wave scans + the 16 wave totals, each thread writes its run back.
 // add: an optional row of T words added to the prefix as it is written back (the scatter kernel's histogram row:
 // its loads are issued before the first barrier when a thread's run is at most four entries).
+// xtot / x_mine (claimed rows): the counts are the sums of the eight XCDs' claims, and what is added to the prefix is the
+// row's claim plus the claims of the XCDs before x_mine.
 __device__ __forceinline__ unsigned long long tile_prefix_lds(const uint32_t *__restrict__ count, int T, uint32_t *s,
-                                                              const uint32_t *__restrict__ add = nullptr) {
+                                                              const uint32_t *__restrict__ add = nullptr,
+                                                              const uint32_t *__restrict__ xtot = nullptr, int x_mine = 0) {
     __shared__ unsigned long long s_wtot[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (T + kHistThreads - 1) / kHistThreads;
     const int j0 = min(T, tid * per), j1 = min(T, j0 + per);
     uint32_t addv[4] = {0u, 0u, 0u, 0u};
     const bool pre = add && per <= 4;
+    auto add_of = [&](int j) __attribute__((always_inline)) -> uint32_t {
+        uint32_t v = add[j];
+        if (xtot)
+            for (int x = 0; x < x_mine; ++x) v += xtot[(size_t)x * T + j];
+        return v;
+    };
     if (pre) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (j0 + k < j1) addv[k] = add[j0 + k];
+            if (j0 + k < j1) addv[k] = add_of(j0 + k);
     }
+    if (xtot) {
+        for (int t = tid; t < T; t += kHistThreads) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) c += xtot[(size_t)x * T + t];
+            s[t] = c;
+        }
+    } else
     for (int t = tid; t < T; t += kHistThreads) s[t] = count[t];
     __syncthreads();
     unsigned long long sum = 0;
@@ -1351,7 +1386,7 @@ __device__ __forceinline__ unsigned long long tile_prefix_lds(const uint32_t *__
     } else {
         for (int j = j0; j < j1; ++j) {
             const uint32_t v = s[j];
-            s[j] = (uint32_t)min(run, 0x7fffffffull) + (add ? add[j] : 0u);
+            s[j] = (uint32_t)min(run, 0x7fffffffull) + (add ? add_of(j) : 0u);
             run += v;
         }
     }
@@ -1382,7 +1417,7 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
         };
         if (tid < 128) s_bkt[tid] = 0;
         __syncthreads();
-        for (int t = tid; t < T_local; t += kHistThreads) atomicAdd(&s_bkt[bucket_of(A.tile_count[t])], 1u);
+        for (int t = tid; t < T_local; t += kHistThreads) atomicAdd(&s_bkt[bucket_of(tile_count_of(A, t, T_local))], 1u);
         __syncthreads();
         if (tid < 64) {   // s_base[b] = tiles in heavier buckets: suffix sums, lane 0 owns the heaviest two
             const unsigned int c0 = s_bkt[127 - 2 * lane], c1 = s_bkt[126 - 2 * lane];
@@ -1400,7 +1435,7 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
         if (tid == 0 && A.wg_on_grid) const_cast<uint32_t *>(A.wg_on_grid)[kMaxG + 1] = s_base[kLightBucket];   // (see tile_scan_total)
         __syncthreads();
         for (int t = tid; t < T_local; t += kHistThreads)
-            A.order[atomicAdd(&s_base[bucket_of(A.tile_count[t])], 1u)] = band0 + t;
+            A.order[atomicAdd(&s_base[bucket_of(tile_count_of(A, t, T_local))], 1u)] = band0 + t;
         return;
     }
     if (A.far_zero)   // (depth-cut frame: the clean-up launches' per-tile counts and cursors; every tile of the grid)
@@ -1410,7 +1445,7 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
     const int prev_redo = (tid == 0 && A.redo_count[2] == redo_signature(A.g)) ? *A.redo_count : 0;
     unsigned int on_grid_part = tid < A.G ? A.wg_on_grid[tid] : 0u;   // G <= kMaxG <= blockDim
     unsigned int far_part = (A.wg_far && tid < A.G) ? A.wg_far[tid] : 0u;   // depth-cut frame: the far log's length
-    const unsigned long long grand = tile_prefix_lds(A.tile_count, T_local, s);   // (its barriers also publish the zeros above)
+    const unsigned long long grand = tile_prefix_lds(A.tile_count, T_local, s, nullptr, A.xtot);   // (its barriers also publish the zeros above)
     if (tid == 0) s[T_local] = (uint32_t)min(grand, 0x7fffffffull);    // the end of the last tile (the LDS block's spare words)
     __syncthreads();
 #pragma unroll
@@ -1426,6 +1461,7 @@ __device__ __forceinline__ void deferred_total(int which, const ScanTotalArgs &A
         const int at = band0 + t;
         reinterpret_cast<int2 *>(A.tile_ranges)[at] = make_int2((int32_t)b, (int32_t)e);
         A.redo_flag[at] = 0;
+        if (A.xtot) const_cast<uint32_t *>(A.tile_count)[t] = c;   // (claimed rows: the counts, for whoever reads them after this launch)
         lmax = max(lmax, c);
         // (a saturated prefix makes c meaningless; such a frame is rejected by the host on info[0])
         if (c > (unsigned)kLargeCapDecl) A.xl_list[atomicAdd(&s_nxl, 1u)] = at;
@@ -1587,11 +1623,15 @@ __global__ __launch_bounds__(kHistThreads, (LEAN == 2 ? MS_SCATTER_WAVES : 4)) v
     if (cut)
         for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_tau[t] = A.tau[band0 + t];
     if constexpr (DEFER) {
-        (void)tile_prefix_lds(A.tile_count, T_local, s_cur, row);   // (its last barrier publishes the cursors, and a cut frame's cut-offs)
+        (void)tile_prefix_lds(A.tile_count, T_local, s_cur, row, A.xtot, (int)(blockIdx.x & 7));   // (its last barrier publishes the cursors, and a cut frame's cut-offs)
         MS_BIN_STAMP(2, 2);
     } else {
-        for (int t = threadIdx.x; t < T_local; t += kHistThreads)
-            s_cur[t] = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
+        for (int t = threadIdx.x; t < T_local; t += kHistThreads) {
+            uint32_t c = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
+            if (A.xtot)
+                for (int x = 0; x < (int)(blockIdx.x & 7); ++x) c += A.xtot[(size_t)x * T_local + t];
+            s_cur[t] = c;
+        }
         __syncthreads();
     }
     // depth bits (order preserving for the positive depths that survive) of everything this workgroup
@@ -2011,6 +2051,7 @@ struct Plan {
     int64_t near_cap;   // depth-cut frames: the stride of a count workgroup's compacted records (>= what any workgroup walks, band candidates included)
     int T, T_local;
     size_t lds_bytes;
+    size_t off_xtot;   // claimed rows: eight arrays of T counters, one per XCD
     size_t off_hist, off_count, off_medium, off_large, off_xl, off_on_grid, off_mask, off_front, off_redo_flag,
         off_redo_list, off_redo_count, off_depth_wg, off_order, off_tau, off_has_far, off_wg_far, off_far_seg, off_cand_count, off_cand, off_lean, off_near, total;
 };
@@ -2032,6 +2073,7 @@ bool make_plan(int64_t N, int tw, int th, int row_begin, int row_end, Plan &p) {
     size_t o = 0;
     p.off_hist = o;   o += ms::align_up((size_t)kMaxG * p.T * 4, 256);
     p.off_count = o;  o += ms::align_up((size_t)p.T * 4, 256);
+    p.off_xtot = o;   o += ms::align_up((size_t)8 * p.T * 4, 256);
     p.off_medium = o; o += ms::align_up((size_t)p.T * 4, 256);
     p.off_large = o;  o += ms::align_up((size_t)p.T * 4, 256);
     p.off_xl = o;     o += ms::align_up((size_t)p.T * 4, 256);
@@ -2102,7 +2144,7 @@ int count_tail(const Plan &p, const Grid &g, char *ws, uint32_t *hist, uint32_t 
                int64_t *isect_info, int band_only, int64_t *info_mirror, hipStream_t stream, bool defer_total = false) {
     ScanTotalArgs A{g, count, tile_ranges, medium, large, xl, wg_on_grid, n_wg, (int32_t *)(ws + p.off_redo_flag),
                     (int32_t *)(ws + p.off_redo_count), band_only, isect_info, info_mirror, (int32_t *)(ws + p.off_order),
-                    (uint32_t *)wg_on_grid + kMaxG, nullptr, nullptr, 0u, nullptr, 0, nullptr};
+                    (uint32_t *)wg_on_grid + kMaxG, nullptr, nullptr, 0u, nullptr, 0, nullptr, nullptr};
     if (defer_total && p.T_local > 0) {
         // the per-tile prefix over the partial rows alone: the total pass rides in the scatter launch (deferred_total)
         A.ticket = nullptr;
@@ -2644,14 +2686,10 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
         MS_LAUNCH_CHECK();
         cand = Candidates{(const int32_t *)(ws + p.off_cand), seg_count, p.G, p.chunk};
     }
-    // claimed rows (round 6): sync-free frames, whose total pass rides in the scatter launch, on a band that has tiles.
-    // MEASURED AND OFF by default (MOJOSPLAT_CLAIMED_ROWS=1 switches it on; profiles/r06_claimed_rows.md): the prefix kernel's
-    // 7.8 us go, but the claims' returning atomics add 4.2 us to this kernel's tail and the scatter kernel loses 3.0 us -- the
-    // stretches of a tile's segment now fall to the workgroups in order of arrival, so the eight XCDs interleave inside
-    // every line again (chunk_of_block's reason for being) -- 0.6 us of the frame in all.
-    static const bool claim_enabled = [] { const char *e = getenv("MOJOSPLAT_CLAIMED_ROWS"); return e && e[0] == '1'; }();
+    // claimed rows (round 6; ms::kTightClaimed, set by ms_render_fwd for sync-free frames whose total pass rides in the scatter
+    // launch): no prefix kernel behind this one (profiles/r06_claimed_rows.md)
     static std::atomic<unsigned long long> claim_stamps{0x5ca1ab1e00000000ull};   // (never a value fresh memory is likely to hold)
-    const bool claimed = claim_enabled && (tight & kDeferTotal) && p.T_local > 0;
+    const bool claimed = (tight & ms::kTightClaimed) && (tight & kDeferTotal) && p.T_local > 0;
     {   // also for N == 0 (one workgroup that walks nothing): the histogram row and the on-grid slot the
         // scans read must exist
         // lean frame: LeanRecs instead of the projected arrays (the caller vouches that nobody reads those)
@@ -2679,7 +2717,7 @@ int ms::project_isect_count(int64_t N, const float *means3d, const float *scales
                            (LeanRec *)(ws + p.off_lean), (uint32_t *)(ws + p.off_depth_wg),
                            cut ? (const uint32_t *)(ws + p.off_tau) + (size_t)((tight >> 9) & 1) * p.T : nullptr, (uint32_t *)(ws + p.off_wg_far),
                            (uint32_t *)(ws + p.off_has_far), cut_stamp, (LeanRec *)(ws + p.off_near), (tight & ms::kTightKeepArrays) ? 1 : 0, p.near_cap,
-                           big_q_off, big_q_cap, claimed ? count : nullptr,
+                           big_q_off, big_q_cap, claimed ? (uint32_t *)(ws + p.off_xtot) : nullptr,
                            // (the flag: two words of the 256-byte block the clean-up counts start -- words 0-2 -- 8-byte aligned)
                            (unsigned long long *)(ws + p.off_redo_count + 64), claimed ? ++claim_stamps : 0ull);
         MS_LAUNCH_CHECK();
@@ -2726,12 +2764,16 @@ int emit_impl(int64_t N, const float *means2d, const int32_t *radii, const float
         const bool lean12 = lean && !pack && tile_w <= 255 && tile_h <= 255;
         const bool deferred = defer && p.T_local > 0;
         ScanTotalArgs A{};
+        // (claimed rows: the count pass of this frame claimed its rows per XCD -- the cursors of either scatter form add the
+        // stretches of the XCDs before the workgroup's own)
+        const uint32_t *xtot = (tight & ms::kTightClaimed) && p.T_local > 0 ? (const uint32_t *)(ws + p.off_xtot) : nullptr;
+        A.xtot = xtot;
         if (deferred) {
             A = ScanTotalArgs{g, (const uint32_t *)(ws + p.off_count), const_cast<int32_t *>(tile_ranges), (int32_t *)(ws + p.off_medium),
                               (int32_t *)(ws + p.off_large), (int32_t *)(ws + p.off_xl), (const uint32_t *)(ws + p.off_on_grid), p.G,
                               (int32_t *)(ws + p.off_redo_flag), (int32_t *)(ws + p.off_redo_count), defer->band_only,
                               defer->info, defer->info_mirror, (int32_t *)(ws + p.off_order), nullptr,
-                              nullptr, nullptr, 0u, nullptr, 0, nullptr};
+                              nullptr, nullptr, 0u, nullptr, 0, nullptr, xtot};
             if (defer->cut_stamp) {
                 MS_REQUIRE(lean12 && lazy, MS_ERR_INVALID_ARG, "isect emit: a depth-cut frame must be a lean, lazily sorted frame on plain bins");
                 A.wg_far = (const uint32_t *)(ws + p.off_wg_far);

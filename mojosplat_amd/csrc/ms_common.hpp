@@ -224,6 +224,7 @@ struct DeferredTotal {
 };
 // bits of the `tight` flags that only ms_render_fwd sets (the C entry points mask them off)
 constexpr int kTightLean = 64, kTightDeferTotal = 128, kTightDepthCutBuf = 512, kTightKeepArrays = 1024;   // (bit 10: a lean frame writes the projected arrays too)
+constexpr int kTightClaimed = 2048;   // (bit 11, round 6: the count pass claims its rows -- binning.hip, k_project_hist's tile_total; every emit of the frame must carry it too)
 //   // (bit 9: a depth-cut frame reads its cut-offs from buffer 1)
 // DEPTH CUT (sync-free lean frames on plain bins; binning.hip, k_project_hist): pairs behind their tile's cut-off
 // are counted but never written; a tile that outlives its list gets them back from the clean-up launch.

@@ -99,6 +99,17 @@ static int quad_list_nq(int tile_size) {
     return 4 * nsub <= max_nq ? 4 * nsub : 0;
 }
 
+// Claimed rows (round 6): the count kernel claims its rows with returning atomics, per XCD, and the prefix kernel
+// (k_tile_scan_wg) is not launched -- config 3's frame -2.5 us, config 4's -5 (profiles/r06_claimed_rows.md).
+// MOJOSPLAT_CLAIMED_ROWS=0: the prefix kernel, as rounds 1-5.
+static int ms_claimed_rows_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_CLAIMED_ROWS");
+        return e && e[0] == '0' ? 0 : 1;
+    }();
+    return v;
+}
+
 static int ms_band_cull_enabled() {
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_BAND_CULL");
@@ -362,6 +373,11 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                   : (isect_bytes > 768 ? (int64_t)((isect_bytes - (list_nq ? 768 : 512)) / (12 + 4 * list_nq)) : 0);
         const bool speculate = sync_event && isect_buf && cap > 0 && N > 0;   // (an empty set has null inputs: exact path, M = 0)
         const bool deferred = speculate && mirror && (split ? b1 > b0 : r1 > r0);
+        // claimed rows (round 6, MOJOSPLAT_CLAIMED_ROWS=1; binning.hip, k_project_hist's tile_total): the frame's count pass and
+        // EVERY emit of the frame -- the speculative one and an exact redo, in this call or a resumed one: bit 14 of the
+        // record's flag word carries it there -- must agree on what a histogram row holds
+        const int claim_bit = deferred && ms_claimed_rows_enabled() ? ms::kTightClaimed : 0;
+        const int64_t claim_flag = claim_bit ? 16384 : 0;
         // the previous frame on this record (same scratch, same grid) had no tile beyond the small sort class:
         // bet that this one has none either (bit 5 of host_info[7]; checked against the size record below)
         const bool bet_light = !split && lazy && prev[0] > 0 && prev[2] + prev[3] + prev[4] == 0 && !(prev[7] & 4);
@@ -397,7 +413,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
         // for the band's end.)
         const bool late_cleanup = defer_cleanup && mirror && phase == MS_RENDER_BEGIN && speculate && !split && lazy && !bet_light;
         const ms::DeferredTotal defer{1, info, (int64_t *)mirror, late_cleanup ? nullptr : sync_event, cut_stamp};
-        const int defer_bit = (deferred ? ms::kTightDeferTotal : 0) | (cut && cut_in ? ms::kTightDepthCutBuf : 0);
+        const int defer_bit = (deferred ? ms::kTightDeferTotal : 0) | (cut && cut_in ? ms::kTightDepthCutBuf : 0) | claim_bit;
         const ms::CutInputs cut_inputs{means3d, scales, quats, opacities, viewmat, colors, color_dtype == MS_COLOR_F16 ? 1 : 0, fx, fy, cx, cy, W, H,
                                        eps2d, near_plane, far_plane, scales_are_log, records, tile_size, r0, r1, N, ws + L.off_isect, (cull & 32) ? 1 : 0};
         const int64_t cut_bits = (cut ? 64 : 0) | (leaves_cutoffs ? (128 | (cut_out << 8) | cut_grid) : 0);
@@ -416,7 +432,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
         MS_HP_T(hp_t3);
         MS_HP_ADD(2, hp_t2, hp_t3);
         // (bit 11: the band's Gaussians were pre-culled -- host_info[6] counts the band's candidates on the grid, not all Gaussians')
-        host_info[7] = (no_split ? 16 : 0) | ((cull & 32) ? 2048 : 0);
+        host_info[7] = (no_split ? 16 : 0) | ((cull & 32) ? 2048 : 0) | claim_flag;
         if (!mirror) MS_HIP(hipMemcpyAsync(host_info, info, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         if (sync_event && !deferred && !late_cleanup) MS_HIP(hipEventRecord((hipEvent_t)sync_event, stream));   // (deferred: behind the scatter launch)
         // Sync-free frame: if the caller's intersection buffer has room for `cap` entries (it was
@@ -434,7 +450,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
             if (split) {
                 const ms::BlockLists lists{ranges, (int32_t *)((char *)ids + ms::align_up((size_t)c * 4, 256)), bin_more, tw, th};
                 if (int rc = ms::isect_emit_bins(N, means2d, radii, depths, bw, bh, b0, b1, ws + L.off_isect,
-                                                 L.isect_bytes, bin_ranges, prev, info, c, bin_flags, lazy,
+                                                 L.isect_bytes, bin_ranges, prev, info, c, bin_flags | claim_bit, lazy,
                                                  near_plane, far_plane, keys, &lists, deferred ? &defer : nullptr, stream))
                     return rc;
                 mark(2);
@@ -445,12 +461,12 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                                      bin_ranges, &lists, render_colors, &lazy_lists, records, order,
                                                      stage_events ? stage_events[3] : nullptr, stream))
                     return rc;
-                host_info[7] = 1 | 8 | ((cull & 32) ? 2048 : 0);
+                host_info[7] = 1 | 8 | ((cull & 32) ? 2048 : 0) | claim_flag;
                 if (phase == MS_RENDER_BEGIN) return MS_OK;
             } else {
             if (int rc = ms::isect_emit_speculative(N, means2d, radii, depths, tile_size, tw, th, r0, r1,
                                                     ws + L.off_isect, L.isect_bytes, ranges, info, c, prev,
-                                                    /*tight=*/(opacities != nullptr ? 1 : 0) | cull,
+                                                    /*tight=*/(opacities != nullptr ? 1 : 0) | cull | claim_bit,
                                                     lazy | (bet_light ? 8 : 0) | (leaves_cutoffs ? 32 | (cut_out << 4) : 0),
                                                     near_plane, far_plane, keys, ids, deferred ? &defer : nullptr, stream))
                 return rc;
@@ -493,6 +509,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
             host_info[7] = 1 | (prev[3] > 0 ? 2 : 0) | (no_split ? 16 : 0) | (bet_light ? 32 : 0) | cut_bits |
                            (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0) | ((cull & 32) ? 2048 : 0) |
                            (lazy_lists.verdict ? 4096 : 0) |   // (bit 12: the clean-up launches were left to the finishing half)
+                           claim_flag |                        // (bit 14: the histogram rows are per-XCD claims)
                            (list_nq ? 8192 : 0);               // (bit 13: the quads' lists for the backward sit behind the ids)
 #ifdef MS_DIAG
             {
@@ -572,7 +589,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
         const int64_t c = M > 0 ? M : 1;
         const ms::BlockLists lists{ranges, (int32_t *)((char *)ids + ms::align_up((size_t)M * 4, 256)), bin_more, tw, th};
         if (int rc = ms::isect_emit_bins(N, means2d, radii, depths, bw, bh, b0, b1, ws + L.off_isect, L.isect_bytes,
-                                         bin_ranges, host_info, nullptr, c, bin_flags, lazy, near_plane, far_plane,
+                                         bin_ranges, host_info, nullptr, c, bin_flags | ((host_info[7] & 16384) ? ms::kTightClaimed : 0), lazy, near_plane, far_plane,
                                          keys, &lists, nullptr, stream))
             return rc;
         if (!speculated) mark(2);
@@ -583,7 +600,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                        (!speculated && stage_events) ? stage_events[3] : nullptr, stream);
     }
     if (int rc = ms::isect_emit_exact(N, means2d, radii, depths, tile_size, tw, th, r0, r1, ws + L.off_isect,
-                                      L.isect_bytes, ranges, host_info, /*tight=*/(opacities != nullptr ? 1 : 0) | cull, lazy, near_plane, far_plane,
+                                      L.isect_bytes, ranges, host_info, /*tight=*/(opacities != nullptr ? 1 : 0) | cull | ((host_info[7] & 16384) ? ms::kTightClaimed : 0), lazy, near_plane, far_plane,
                                       keys, tmp, ids, stream))
         return rc;
     if (!speculated) mark(2);
