@@ -64,6 +64,12 @@ namespace {
 #define MS_PH_WAVES 8
 #endif
 constexpr int kHistThreads = 1024;
+#ifndef MS_CLAIM_GROUPS
+#define MS_CLAIM_GROUPS 4   // (config 3: count kernel + scatter 52.4 us with four arrays -- a pair of XCDs each -- against 53.1 with eight and 56.2 with two)
+#endif
+constexpr int kClaimGroups = MS_CLAIM_GROUPS;   // claimed rows: counter arrays per tile grid -- one per XCD (8), per pair (4), ...
+constexpr int kClaimShift = kClaimGroups == 8 ? 0 : kClaimGroups == 4 ? 1 : kClaimGroups == 2 ? 2 : 3;
+static_assert(kClaimGroups == 8 || kClaimGroups == 4 || kClaimGroups == 2 || kClaimGroups == 1, "claim groups: a power of two <= 8");
 constexpr int kMaxG = 512;
 constexpr int kSmallCapDecl = 1024, kMediumCapDecl = 8192, kLargeCapDecl = 16384;  // per-tile sort classes
 constexpr int kCoopThreshold = 32; // boxes touching more tiles are walked by a whole wave
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
     if (tile_total && blockIdx.x == 0) {
         // write-through stores (the XCDs' L2s are not coherent with each other), drained by the storing wave itself before the
         // barrier, then the flag: the hand-off pattern of k_tile_scan_wg
-        for (int t = threadIdx.x; t < 8 * T_local; t += kHistThreads) __hip_atomic_store(&tile_total[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t = threadIdx.x; t < kClaimGroups * T_local; t += kHistThreads) __hip_atomic_store(&tile_total[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(kHistThreads, MS_PH_WAVES) void k_project_hist(
             const uint32_t c = s_cnt[t];
             // (the counters of this workgroup's XCD -- blockIdx & 7, the eighth of the rows chunk_of_block gives it: the XCDs keep
             // contiguous stretches of every tile's segment, which the scatter kernel's write merging lives on)
-            row[t] = c ? __hip_atomic_fetch_add(&tile_total[(size_t)(blockIdx.x & 7) * T_local + t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            row[t] = c ? __hip_atomic_fetch_add(&tile_total[(size_t)((blockIdx.x & 7) >> kClaimShift) * T_local + t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
     } else
     for (int t = threadIdx.x; t < T_local; t += kHistThreads) row[t] = s_cnt[t];
@@ -1076,7 +1082,7 @@ __device__ __forceinline__ uint32_t tile_count_of(const ScanTotalArgs &A, int t,
     if (!A.xtot) return A.tile_count[t];
     uint32_t c = 0;
 #pragma unroll
-    for (int x = 0; x < 8; ++x) c += A.xtot[(size_t)x * T_local + t];
+    for (int x = 0; x < kClaimGroups; ++x) c += A.xtot[(size_t)x * T_local + t];
     return c;
 }
 
@@ -1353,7 +1359,7 @@ __device__ __forceinline__ unsigned long long tile_prefix_lds(const uint32_t *__
         for (int t = tid; t < T; t += kHistThreads) {
             uint32_t c = 0;
 #pragma unroll
-            for (int x = 0; x < 8; ++x) c += xtot[(size_t)x * T + t];
+            for (int x = 0; x < kClaimGroups; ++x) c += xtot[(size_t)x * T + t];
             s[t] = c;
         }
     } else
@@ -1623,13 +1629,13 @@ __global__ __launch_bounds__(kHistThreads, (LEAN == 2 ? MS_SCATTER_WAVES : 4)) v
     if (cut)
         for (int t = threadIdx.x; t < T_local; t += kHistThreads) s_tau[t] = A.tau[band0 + t];
     if constexpr (DEFER) {
-        (void)tile_prefix_lds(A.tile_count, T_local, s_cur, row, A.xtot, (int)(blockIdx.x & 7));   // (its last barrier publishes the cursors, and a cut frame's cut-offs)
+        (void)tile_prefix_lds(A.tile_count, T_local, s_cur, row, A.xtot, (int)(blockIdx.x & 7) >> kClaimShift);   // (its last barrier publishes the cursors, and a cut frame's cut-offs)
         MS_BIN_STAMP(2, 2);
     } else {
         for (int t = threadIdx.x; t < T_local; t += kHistThreads) {
             uint32_t c = (uint32_t)tile_ranges[2 * (band0 + t)] + row[t];
             if (A.xtot)
-                for (int x = 0; x < (int)(blockIdx.x & 7); ++x) c += A.xtot[(size_t)x * T_local + t];
+                for (int x = 0; x < ((int)(blockIdx.x & 7) >> kClaimShift); ++x) c += A.xtot[(size_t)x * T_local + t];
             s_cur[t] = c;
         }
         __syncthreads();
