@@ -1169,3 +1169,57 @@ def test_pipelined_band_fuzz_with_deferred_clean_up(device, seed, dense=False):
         LAST_CUT_FUZZ_STATS.update(_fused.FRAME_STATS or {})
         _fused.FRAME_STATS = None
         _fused._state.clear()
+
+
+def test_claimed_rows_and_the_prefix_kernel_give_the_same_frames(device, tmp_path):
+    """Round 6: the count kernel CLAIMS its stretch of every tile's segment with returning atomics (per-XCD-pair counters) and the
+    prefix kernel is not launched (csrc/binning.hip, k_project_hist's tile_total; profiles/r06_claimed_rows.md).  Which
+    workgroup gets which stretch changes where a pair sits in the UNSORTED buffer and nothing else: a child process with
+    MOJOSPLAT_CLAIMED_ROWS=0 (the switch is read once) renders the same frames -- whole frames on all three binning grids,
+    a band, a frame that overflows its buffer and is redone on the exact path, a depth-cut pair of frames -- bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f'''
+import sys, torch
+sys.path.insert(0, {root!r})
+import mojosplat_amd as ms
+from mojosplat_amd import _fused, _hip
+from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
+dev = torch.device("cuda", 0)
+bg = torch.tensor(BACKGROUND_V1, device=dev)
+out = {{}}
+sc, cam = randscene_v1(150_000, 1024, 576, ell=-3.2, seed=5, device=dev)
+g = (sc["means3d"], sc["scales"], sc["quats"], sc["opacities"], sc["features"])
+for px in (16, 32, 64):
+    for rep in range(3):   # (first frame: exact path; then sync-free frames on the learnt buffer)
+        img = ms.render_gaussians(*g, cam, background_color=bg, bin_size=px)
+    out[f"bin{{px}}"] = img.cpu()
+_, m = _fused.render_fwd_hip(*g, cam, bg, 16, row_range=(5, 17))
+out["band"] = _fused.render_fwd_hip(*g, cam, bg, 16, row_range=(5, 17))[0].cpu()
+# a denser scene on the same lane: the speculated buffer overflows, the frame is redone exactly
+sc2, cam2 = randscene_v1(150_000, 1024, 576, ell=-2.6, seed=6, device=dev)
+g2 = (sc2["means3d"], sc2["scales"], sc2["quats"], sc2["opacities"], sc2["features"])
+out["overflow"] = ms.render_gaussians(*g2, cam2, background_color=bg).cpu()
+out["after"] = ms.render_gaussians(*g2, cam2, background_color=bg).cpu()
+_hip.config_depth_cut(2, 0)
+for rep in range(3):
+    img = ms.render_gaussians(*g2, cam2, background_color=bg, bin_size=32)
+out["cut"] = img.cpu()
+out["cut_flag"] = int(_fused._dev_state(dev, 0)["host_np"][7]) & 64
+torch.save(out, sys.argv[1])
+'''
+    outs = {}
+    for claimed in ("1", "0"):
+        path = str(tmp_path / f"frames_{claimed}.pt")
+        env = dict(os.environ, MOJOSPLAT_CLAIMED_ROWS=claimed)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs[claimed] = torch.load(path)
+    a, b = outs["1"], outs["0"]
+    assert a["cut_flag"] and b["cut_flag"]          # (the last frames did take the depth cut)
+    for k in a:
+        if k != "cut_flag":
+            assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["bin32"], a["overflow"])
