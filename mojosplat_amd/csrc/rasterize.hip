@@ -161,6 +161,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef MS_RASTER_LOCAL_CONST
 #define MS_RASTER_LOCAL_CONST 1
 #endif
+#ifndef MS_RASTER_HALF_STREAMS
+#define MS_RASTER_HALF_STREAMS 0   // 1: the measurement variant of profiles/r06_raster_halfquad.md (a stream per 8x4 half-quad)
+#endif
 #ifndef MS_RASTER_CHAINS
 #define MS_RASTER_CHAINS 0     // 1: the measurement variant of profiles/r06_raster_startup.md (waves that walk chains of blocks)
 #endif
@@ -231,11 +234,16 @@ __device__ __forceinline__ bool raster_block_in_band(const RasterArgs &A, const 
 
 // One wave's share of a 16x16 block: NQ quads of block `sub` of tile `tile`, starting at quad part * NQ.  s_q: the
 // wave's NQ staging blocks.
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false, bool PERSIST = false>
+// HALF (round 6, NQ == 1 only): the wave's two 32-lane halves -- rows 0-3 and rows 4-7 of its 8x8 quad -- walk compacted
+// streams of their OWN: an entry that reaches only one half costs the other half nothing, and the loop runs for the longer
+// of the two streams (profiles/r06_raster_halfquad.md).
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false, bool PERSIST = false, bool HALF = false>
 __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile, const int sub, const int part,
                                             RasterStage<CP, AUX> *s_q, const int diag_slot,
                                             float4 &r_a, float4 &r_b, float4 &r_c, int &r_g, RasterNext &nx) {
     static_assert(!PERSIST || (PACKED && !AUX && !LISTS), "persistent waves: the plain kernel on ready-made records");
+    static_assert(!HALF || (NQ == 1 && PACKED && !AUX && !LISTS && !PERSIST && CP == 3), "half-quad streams: the plain one-quad kernel");
+    constexpr int NS = HALF ? 2 : NQ;   // compacted streams a wave keeps (and votes on)
     static_assert(!LISTS || (PACKED && !AUX), "quad lists: the plain 3-channel kernel on ready-made records");
     static_assert(!PACKED || CP == 3, "ready-made records carry three channels");
     using Stage = RasterStage<CP, AUX>;
@@ -388,10 +396,10 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 npd = true;
             } else if (smax > -kInf) {
 #pragma unroll
-                for (int qi = 0; qi < NQ; ++qi) {
-                    const int q = qbase + qi;
+                for (int qi = 0; qi < NS; ++qi) {
+                    const int q = HALF ? qbase : qbase + qi;
                     const float xl = fbx + (float)((q & 1) * 8) - r_a.x, xh = xl + 7.0f;   // rectangle - mean
-                    const float yl = fby + (float)((q >> 1) * 8) - r_a.y, yh = yl + 7.0f;
+                    const float yl = fby + (float)((q >> 1) * 8 + (HALF ? 4 * qi : 0)) - r_a.y, yh = yl + (HALF ? 3.0f : 7.0f);
                     const bool in_x = xl <= 0.f && xh >= 0.f, in_y = yl <= 0.f && yh >= 0.f;
                     float best = (in_x && in_y) ? 0.f : 3.0e38f;
                     if (!in_x) {
@@ -408,9 +416,11 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 }
             }
         }
-        unsigned long long B[NQ];
+        unsigned long long B[NS];
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) B[qi] = __ballot((mask >> qi) & 1);
+        for (int qi = 0; qi < NS; ++qi) B[qi] = __ballot((mask >> qi) & 1);
+        int n_loop = 0;   // HALF: the longer of the two streams
+        if constexpr (HALF) n_loop = max(__popcll(B[0]), __popcll(B[1]));
 #if MS_RASTER_EXPANDED
         // (measurement variant, round 5: log2(alpha) as the quadratic EXPANDED about the quad's centre -- five FMAs on two
         // lane constants instead of two subtractions + five: the staging lane leaves a', b', c', D, E, F per reached quad.
@@ -427,7 +437,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
         if constexpr (CP == 3) r_c.y = __int_as_float(lane);
         else r_b.z = __int_as_float(lane);
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
+        for (int qi = 0; qi < NS; ++qi) {
             Stage &S = s_q[qi];
             const unsigned long long b = B[qi];
             const int n = __popcll(b);
@@ -464,7 +474,8 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
             if constexpr (LISTS) {
                 if (q_live[qi]) q_at[qi] += (unsigned long long)(unsigned)n;
             }
-            if (lane < kGroup) {
+            // (HALF: the shorter stream is padded with neutral records up to the longer one's end: the halves walk in lockstep)
+            if (HALF ? (n + lane < n_loop + kGroup) : (lane < kGroup)) {
                 // (the two constants are made HERE: hoisted out of the batch loop as eight registers of zeros and -inf they
                 // were the first thing the persistent kernel spilled)
                 float zero = 0.f, ninf = -kInf;
@@ -508,8 +519,8 @@ __device__ __forceinline__ void raster_tile(const RasterArgs &A, const int tile,
                 const int q = qbase + qi;
                 if (!__any(kq[qi] != 0.f)) continue;  // every pixel of this quad is finished (or outside)
                 const float px = px0 + (float)((q & 1) * 8), py = py0 + (float)((q >> 1) * 8);
-                const Stage &S = s_q[qi];
-                const int n = __popcll(B[qi]);
+                const Stage &S = s_q[HALF ? (lane >> 5) : qi];   // (HALF: a per-lane LDS base, the same offsets)
+                const int n = HALF ? n_loop : __popcll(B[qi]);
                 // kGroup records per trip: their LDS reads go out together, the kGroup log2(alpha) chains and
                 // exp2 are independent of each other (and of the T chain), then the blends run in list order
                 // one trip: kGroup records from LDS address k0, transmittance t in and out (by value, so that two
@@ -736,16 +747,16 @@ __device__ __forceinline__ bool raster_map_block(const RasterArgs &A, const int 
     return true;
 }
 
-template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false, bool PERSIST = false>
+template <int CP, typename ColorT, bool AUX, int NQ, bool PACKED, bool LISTS = false, bool PERSIST = false, bool HALF = false>
 __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? MS_RASTER_MINW_AUX : MS_RASTER_MINW) : 1)) void k_rasterize_fwd(RasterArgs A) {
-    __shared__ RasterStage<CP, AUX> s_stage[NQ];
+    __shared__ RasterStage<CP, AUX> s_stage[HALF ? 2 : NQ];
     float4 r_a = make_float4(0.f, 0.f, 0.f, 0.f), r_b = r_a, r_c = r_a;
     int r_g = 0;
     RasterNext nx{0, 0, 0, 0};
     if constexpr (!PERSIST) {
         int tile, sub, part, slot;
         if (!raster_map_block<NQ>(A, (int)blockIdx.x, tile, sub, part, slot)) return;
-        raster_tile<CP, ColorT, AUX, NQ, PACKED, LISTS, false>(A, tile, sub, part, s_stage, slot, r_a, r_b, r_c, r_g, nx);
+        raster_tile<CP, ColorT, AUX, NQ, PACKED, LISTS, false, HALF>(A, tile, sub, part, s_stage, slot, r_a, r_b, r_c, r_g, nx);
     } else {
         // A persistent wave: virtual indices blockIdx, blockIdx + grid, ... (the grid is a multiple of 8 x the waves per
         // block, so an index keeps its XCD label and a block's waves stay neighbours).  Odd rounds run through the grid
@@ -1397,6 +1408,15 @@ static int raster_parts_override() {
     return v;
 }
 
+// MOJOSPLAT_RASTER_HALF=1: one-quad waves keep a compacted stream per 8x4 half (A/B: profiles/r06_raster_halfquad.md)
+static bool raster_half() {
+    static const bool v = [] {
+        const char *e = getenv("MOJOSPLAT_RASTER_HALF");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 // MOJOSPLAT_RASTER_CHAIN=k: blocks a rasteriser wave walks one after the other (1: one block per wave, as rounds 2-5;
 // A/B: profiles/r06_raster_startup.md)
 static int raster_chain() {
@@ -1482,6 +1502,13 @@ void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event
     if constexpr (CP == 3) {
         if (done) {
         } else
+#if MS_RASTER_HALF_STREAMS   // (measurement builds, profiles/r06_raster_halfquad.md: -DMS_RASTER_HALF_STREAMS=1 + MOJOSPLAT_RASTER_HALF=1)
+        if (A.records && !aux && !A.quad_lists && A.parts == 4 && raster_half()) {
+            // one quad a wave, its two halves walking streams of their own
+            hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, false, 1, true, false, false, true>), grid, dim3(64), 0, stream, A);
+            done = true;
+        } else
+#endif
         if (A.records) {
             if (aux) MS_LAUNCH_RASTER_NQ(true, true);
             else if (A.quad_lists) {   // a differentiable frame that leaves its quads' lists for the backward
