@@ -329,6 +329,114 @@ __global__ __launch_bounds__(64, WAVES) void k_mfma32(const Rec *recs, float *ou
     out[blockIdx.x * 64 + lane] = p0 + p1 + p2 + acc + kq;
 }
 
+// ---- the exact form: v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate), no split: the staging lane only computes D, E, F.
+// K = 6 monomials = two instructions per 16 records x 16 pixels (k 0-3: ux^2, ux uy, uy^2, ux; k 4-7: uy, 1, 0, 0); a lane holds
+// ONE float of A (record l & 15, k = l >> 4) and of B (k = l >> 4, pixel l & 15) per instruction; the transpose as k_mfma.
+__global__ __launch_bounds__(64, WAVES) void k_mfma_f32(const Rec *recs, float *out, int iters, float *la_err) {
+    __shared__ float sK[kN * 8];     // coefficients: record r at sK[r * 8 + k]
+    __shared__ float4 sC[kN];
+    const int lane = threadIdx.x;
+    const int lx = lane & 7, ly = lane >> 3;
+    Rec mine = recs[(blockIdx.x % 64) * kN + lane];
+    {
+        const float U = mine.mx - 3.5f, V = mine.my - 3.5f;
+        const float D = -fmaf(2.0f * mine.a, U, mine.b * V), E = -fmaf(2.0f * mine.c, V, mine.b * U);
+        const float F = fmaf(U, fmaf(mine.a, U, mine.b * V), fmaf(mine.c * V, V, mine.lo));
+        *reinterpret_cast<float4 *>(sK + lane * 8) = make_float4(mine.a, mine.b, mine.c, D);
+        *reinterpret_cast<float4 *>(sK + lane * 8 + 4) = make_float4(E, F, 0.f, 0.f);
+        sC[lane] = make_float4(mine.r, mine.g, mine.bl, 0.f);
+    }
+    float Bm[4][2];   // [pixel block][k group]
+    {
+        const int c = lane & 15, kk = lane >> 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float ux = (float)(c & 7) - 3.5f, uy = (float)(2 * p + (c >> 3)) - 3.5f;
+            const float m0[4] = {ux * ux, ux * uy, uy * uy, ux}, m1[4] = {uy, 1.0f, 0.f, 0.f};
+            Bm[p][0] = kk == 0 ? m0[0] : kk == 1 ? m0[1] : kk == 2 ? m0[2] : m0[3];
+            Bm[p][1] = kk == 0 ? m1[0] : kk == 1 ? m1[1] : 0.f;
+        }
+    }
+    __syncthreads();
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, kq = kFlushK, acc = 0.f, worst = 0.f;
+    const int a_off = (lane & 15) * 8 + (lane >> 4);   // float index of this lane's k-group-0 coefficient inside a chunk (+4: group 1)
+    for (int it = 0; it < iters; ++it) {
+        float t = kTScale;
+        int base = 0;
+        asm volatile("" : "+s"(base));
+#pragma unroll 1
+        for (int ch = base; ch < base + kN / 16; ++ch) {
+            const float A0 = sK[ch * 128 + a_off], A1 = sK[ch * 128 + a_off + 4];
+            f32x4 X[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, Bm[p][0], z, 0, 0, 0);
+                X[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, Bm[p][1], z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[p][i]), __float_as_uint(X[p + 2][i]), false, false);
+                    X[p][i] = __uint_as_float(r[0]); X[p + 2][i] = __uint_as_float(r[1]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int p = 0; p < 4; p += 2) {
+                    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[p][i]), __float_as_uint(X[p + 1][i]), false, false);
+                    X[p][i] = __uint_as_float(r[0]); X[p + 1][i] = __uint_as_float(r[1]);
+                }
+            }
+            if (la_err && it == 0) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const Rec r = recs[(blockIdx.x % 64) * kN + ch * 16 + g];
+                    const float dx = r.mx - (float)lx, dy = r.my - (float)ly;
+                    const float la = fmaf(dx, fmaf(r.a, dx, r.b * dy), fmaf(r.c * dy, dy, r.lo));
+                    if (la > -9.f) worst = fmaxf(worst, fabsf(X[g >> 2][g & 3] - la));
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; g += 2) {
+                float m[2], v[2];
+                float4 col[2];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    col[j] = sC[ch * 16 + g + j];
+                    m[j] = __builtin_amdgcn_exp2f(X[(g + j) >> 2][(g + j) & 3]) * kq;
+                    asm volatile("" : "+v"(m[j]));
+                }
+                const float t_in = t;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { v[j] = m[j] * t; t = fmaf(v[j], -kAlphaOfV, t); }
+                if (__ballot(!(t > kStop * kTScale))) {
+                    asm volatile("" ::: "memory");
+                    t = t_in;
+                    bool dead = false;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float vj = m[j] * t, nt = fmaf(vj, -kAlphaOfV, t);
+                        dead = dead || !(nt > kStop * kTScale);
+                        v[j] = dead ? 0.f : vj;
+                        t = dead ? t : nt;
+                    }
+                    kq = dead ? 0.f : kq;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { p0 += col[j].x * v[j]; p1 += col[j].y * v[j]; p2 += col[j].z * v[j]; }
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
+            }
+        }
+        acc += t * 0x1p-126f;
+    }
+    out[blockIdx.x * 64 + lane] = p0 + p1 + p2 + acc + kq;
+    if (la_err) la_err[blockIdx.x * 64 + lane] = worst;
+}
+
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000, blocks = 256 * 4 * WAVES * 4;
     std::vector<Rec> h(64 * kN);
@@ -362,6 +470,15 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < o.size(); ++i) d32 = fmaxf(d32, fabsf(o[i] - o3[i]));
         printf("check: max |pixel sum base - mfma32| (255 x colour units): %.3g\n", d32);
     }
+    {
+        hipLaunchKernelGGL(k_mfma_f32, dim3(64), dim3(64), 0, 0, d_r, d_o2, 1, d_e);
+        std::vector<float> o3(64 * 64), e3(64 * 64);
+        hipMemcpy(o3.data(), d_o2, o3.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(e3.data(), d_e, e3.size() * 4, hipMemcpyDeviceToHost);
+        float d32 = 0.f, w3 = 0.f;
+        for (size_t i = 0; i < o.size(); ++i) { d32 = fmaxf(d32, fabsf(o[i] - o3[i])); w3 = fmaxf(w3, e3[i]); }
+        printf("check: fp32 matrix form: max |log2(alpha) - direct| where > -9: %.3g ; max |pixel sum base - mfma_f32|: %.3g\n", w3, d32);
+    }
     printf("check: max |log2(alpha) mfma - direct| where log2(alpha) > -9: %.3g ; max |pixel sum base - mfma| (255 x colour units): %.3g\n", worst, dpix);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
@@ -382,6 +499,11 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(k_mfma32, dim3(blocks), dim3(64), 0, 0, d_r, d_o2, iters);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("mfma32(WAVES=%d) %.3f ms  %.2f ns per evaluation and SIMD\n", WAVES, ms, ms * 1e6 / evals_per_simd);
+        hipLaunchKernelGGL(k_mfma_f32, dim3(blocks), dim3(64), 0, 0, d_r, d_o2, 10, (float *)nullptr);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_mfma_f32, dim3(blocks), dim3(64), 0, 0, d_r, d_o2, iters, (float *)nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("mfmaf32(WAVES=%d) %.3f ms  %.2f ns per evaluation and SIMD\n", WAVES, ms, ms * 1e6 / evals_per_simd);
     }
     return 0;
 }
