@@ -51,14 +51,29 @@ def _lane_fence(dev):
 
 def clear_scenes():
     """Drop every cached ms_scene (release_scratch; the caller has synchronised the devices)."""
+    global _last
     with _fused._frame_lock:
         _scenes.clear()
+        _last = None
+
+
+_last = None   # (the five tensor OBJECTS of the previous call, their versions, the struct): a render loop's fast path
 
 
 def scene_struct(means3d, scales, quats, opacities, colors):
     """-> the ms_scene ctypes struct for these tensors as they are now (cached)."""
+    global _last
     with _fused._frame_lock:
-        return _scene_struct(means3d, scales, quats, opacities, colors)
+        L = _last
+        # the very same tensor objects, unmodified since (a view such as means3d[:k] is a NEW object each time: slow path)
+        if (L is not None and L[0] is means3d and L[1] is scales and L[2] is quats and L[3] is opacities and L[4] is colors and
+                L[5] == (means3d._version, scales._version, quats._version, opacities._version, colors._version) and
+                L[6].N == means3d.shape[0] and L[7] in _scenes):
+            return L[6]
+        S = _scene_struct(means3d, scales, quats, opacities, colors)
+        _last = (means3d, scales, quats, opacities, colors,
+                 (means3d._version, scales._version, quats._version, opacities._version, colors._version), S, S._key)
+        return S
 
 
 def _scene_struct(means3d, scales, quats, opacities, colors):
@@ -68,6 +83,7 @@ def _scene_struct(means3d, scales, quats, opacities, colors):
         # (belt and braces: the struct's N is what band_begin sizes the workspace from)
         if hit[0].N != means3d.shape[0]:
             raise RuntimeError("cached ms_scene does not describe these tensors")
+        hit[0]._key = key
         return hit[0]
     from .scene_order import prepared_bounds
     N = means3d.shape[0]
@@ -96,6 +112,7 @@ def _scene_struct(means3d, scales, quats, opacities, colors):
             _scenes.pop(k_old)
     # (the originals too: a marshalled copy's source must not change under the key's version check unnoticed)
     S._keep = (means3d, scales, quats, opacities, colors, m, sc, q, op, col, pb[0] if pb else None)
+    S._key = key
     _scenes[key] = (S, S._keep)
     return S
 
