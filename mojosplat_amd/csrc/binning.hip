@@ -17,7 +17,10 @@
 //   k_isect_hist      G workgroups, each histograms a contiguous chunk of Gaussians into LDS
 //   k_project_hist    the same fused with the projection itself (what ms_render_fwd runs)
 //   k_tile_scan_wg    per tile: exclusive prefix over the G partial counts; on grids up to 4 096 tiles its last
-//                     workgroup to arrive also runs the total pass (tile_scan_total) in the same launch
+//                     workgroup to arrive also runs the total pass (tile_scan_total) in the same launch.  Round 6: NOT
+//                     launched by ms_render_fwd's sync-free frames any more -- k_project_hist claims its stretches of the
+//                     tiles' segments with returning atomics (tile_total; profiles/r06_claimed_rows.md); the per-stage
+//                     entry points and MOJOSPLAT_CLAIMED_ROWS=0 still use it
 //   k_tile_scan_total one workgroup: exclusive scan over tiles -> tile_ranges, M, work lists, launch order, size
 //                     record (a launch of its own on larger grids and for empty bands)
 //   k_isect_scatter   same chunks; LDS cursors hand out slots inside each tile segment
