@@ -42,8 +42,11 @@ def _lane_fence(dev):
     """Make the caller's current stream wait for everything enqueued on the band lanes of `dev` so far: tensors the lanes may
     still be reading or writing are about to go back to the caching allocator, which only knows the caller's stream."""
     from ._fused import _lane_streams_if_any
+    lanes = _lane_streams_if_any(dev)
+    if not lanes:   # (no frame ever ran on a lane of this device: nothing to wait for -- and no CUDA call for CPU tensors)
+        return
     cur = torch.cuda.current_stream(dev)
-    for s in _lane_streams_if_any(dev):
+    for s in lanes:
         ev = torch.cuda.Event()
         ev.record(s)
         cur.wait_event(ev)

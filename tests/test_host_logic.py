@@ -385,3 +385,33 @@ def test_scene_cache_key_tells_views_apart_and_registry_holds_no_scene():
     gc.collect()
     assert key not in scene_order._registry
     scene_order.clear_registry()
+
+
+def test_band_scene_cache_on_cpu_tensors_prefix_views_and_the_fast_path():
+    """The band path's ms_scene cache (mojosplat_amd/_band.py) is host logic: the struct is built from data pointers and
+    shapes, no GPU call.  Round-6 advisor scenario on CPU tensors: the full scene, then a prefix view (same data pointer, same
+    version counter), then the full scene again -- every struct carries ITS tensors' N; the one-entry fast path returns the
+    cached struct for the very same tensor objects and notices an in-place update."""
+    import torch
+    from mojosplat_amd import _band
+    _band.clear_scenes()
+    n = 300
+    g = (torch.randn(n, 3), torch.randn(n, 3), torch.randn(n, 4), torch.rand(n), torch.rand(n, 3))
+    S_full = _band.scene_struct(*g)
+    assert S_full.N == n and S_full.CDIM == 3
+    assert _band.scene_struct(*g) is S_full                      # fast path: same objects, same versions
+    gk = tuple(t[:40] for t in g)
+    S_k = _band.scene_struct(*gk)
+    assert S_k is not S_full and S_k.N == 40
+    assert S_k.means3d == S_full.means3d                         # (the very aliasing the key must see through)
+    assert _band.scene_struct(*g) is S_full and _band.scene_struct(*tuple(t[:40] for t in g)).N == 40
+    g[0].add_(1.0)                                               # in-place update: a new version -> a new struct, the old one dropped
+    S2 = _band.scene_struct(*g)
+    assert S2 is not S_full and S2.N == n
+    assert all(v[0] is not S_full for v in _band._scenes.values())
+    # a float64 / strided scene is marshalled: the struct points at the copies, which the entry keeps alive
+    gd = (g[0].double(), g[1][:, [2, 1, 0]], g[2], g[3], g[4])
+    S3 = _band.scene_struct(*gd)
+    assert S3.N == n and S3.means3d != gd[0].data_ptr() and any(t.dtype == torch.float32 and t.data_ptr() == S3.means3d for t in S3._keep)
+    _band.clear_scenes()
+    assert not _band._scenes and _band._last is None
