@@ -255,6 +255,10 @@ int ms_config_depth_cut(int mode, long long min_pairs);
  * ms_render_bwd == rows(0, tile_h) + finish.  redo_counts_host (nullable): pinned HOST i32[2] that a lazily sorted frame's
  * redo launch fills with the frame's clean-up counts (as ms_render_redo_counts would, without a copy of its own; valid once an
  * event recorded behind the call has completed; untouched for a fully sorted frame).
+ * Round 6: the workspace of ms_render_fwd ends with a region of ms_render_bwd_rows_bytes(N) bytes (at
+ * ms_render_workspace_bytes(N, tile_w, tile_h) - ms_render_bwd_rows_bytes(N)) that a differentiable 3-channel frame's
+ * rasteriser zeroes on its way (bit 15 of host_info[7] says it did): handed exactly that address as `rows`, the call skips its
+ * own memset; any other buffer is zeroed by the call as before.
  * No reference counterpart (render.py:11; README.md:145). */
 size_t ms_render_bwd_rows_bytes(int64_t N);
 int ms_render_bwd_rows(int64_t N, int CDIM, int W, int H, int tile_size, int tile_row_begin, int tile_row_end,

@@ -166,14 +166,17 @@ class _RenderFusedHip(torch.autograd.Function):
         v_img = _hip.f32c(v_img)
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # overwritten by the library
         v_means3d, v_scales, v_quats, v_opac, v_colors = z(N, 3), z(N, 3), z(N, 4), z(N), z(N, C)
+        lean_own = ctx.own_learn is not None and C == 3 and last is None
+        # (round 6: a lean differentiable frame's rasteriser zeroed the rows of raw sums inside the frame's own workspace -- bit 15 of
+        # its flag word; the backward then needs no scratch of its own and the library skips its 10-us memset)
+        rows_in_ws = lean_own and bool(int(host[7]) & 32768)
         bws_bytes = L.ms_render_bwd_workspace_bytes(N, C)
-        bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+        bws = None if rows_in_ws else torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
         vm = cam._viewmat_f32().to(dev)
         bev = _BWD_HOOK() if _BWD_HOOK is not None else None
         with _hip.on_device(dev):
             if bev:
                 bev[0].record()
-            lean_own = ctx.own_learn is not None and C == 3 and last is None
             if lean_own:
                 # (round 5: the two halves of ms_render_bwd, so that a lazily sorted frame's redo launch can leave the frame's
                 # clean-up counts in this thread's pinned words on its way -- what the next differentiable frame learns from)
@@ -181,8 +184,13 @@ class _RenderFusedHip(torch.autograd.Function):
                 st, shape, mode, level, heavy, grid = ctx.own_learn
                 fronts = bool(int(host[7]) & 512)
                 mirror = _fused.own_mirror(st) if fronts else None
-                rows = bws[:L.ms_render_bwd_rows_bytes(N)].view(torch.float32)
                 th_ = -(-cam.H // ts)
+                rows_bytes = L.ms_render_bwd_rows_bytes(N)
+                if rows_in_ws:   # (the workspace's last region: include/mojosplat_hip.h, ms_render_bwd_rows)
+                    off = L.ms_render_workspace_bytes(N, -(-cam.W // ts), th_) - rows_bytes
+                    rows = ws[off:off + rows_bytes].view(torch.float32)
+                else:
+                    rows = bws[:rows_bytes].view(torch.float32)
                 _hip.check(L.ms_render_bwd_rows(N, 3, cam.W, cam.H, ts, 0, th_, _hip.ptr(bg), _hip.ptr(ws), ws.numel(), _hip.ptr(isect),
                                                 0 if isect is None else isect.numel(), host.ctypes.data, _hip.ptr(img), _hip.ptr(alphas),
                                                 _hip.ptr(v_img), None, _hip.ptr(rows),

@@ -172,7 +172,11 @@ int rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *means
                   int clip_row16_end, void *after_raster_event, void *stream,
                   // a differentiable frame: every 8x8 quad leaves the Gaussians that passed its reach test, in list order, for the
                   // backward rasteriser -- quad_lists i32[M * quads per tile], quad_counts i32[tiles * quads per tile] (or null)
-                  int32_t *quad_lists = nullptr, int32_t *quad_counts = nullptr);
+                  int32_t *quad_lists = nullptr, int32_t *quad_counts = nullptr,
+                  // round 6: zero_bytes of memory every wave of the launch zeroes a slice of on its way (a differentiable frame's
+                  // rows of raw gradient sums: the kernel is issue-bound and moves 70 MB in 90 us -- the 64 N bytes ride along
+                  // instead of costing the backward a 10-us memset); null: nothing
+                  void *zero_mem = nullptr, size_t zero_bytes = 0);
 
 // rasterize_bwd.hip: ms_rasterize_to_pixels_3dgs_bwd with the forward frame's ready-made records (or null) and its
 // heaviest-first order of the image's tiles (16-px tiles only; or null: the kernel's own counting sort)

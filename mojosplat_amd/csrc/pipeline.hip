@@ -42,7 +42,7 @@ namespace {
 
 struct WsLayout {
     size_t off_isect, isect_bytes, off_means2d, off_conics, off_depths, off_radii, off_ranges, off_info, off_bin_ranges,
-        off_bin_more, off_records, off_quad_counts, total;
+        off_bin_more, off_records, off_quad_counts, off_rows, total;
 };
 
 WsLayout ws_layout(int64_t N, int tw, int th) {
@@ -60,6 +60,10 @@ WsLayout ws_layout(int64_t N, int tw, int th) {
     L.off_bin_more = o;   o += ms::align_up(T * 4, 256);
     L.off_records = o;    o += ms::align_up(n * sizeof(ms::RasterRecord), 256);   // the rasteriser's ready-made records
     L.off_quad_counts = o; o += ms::align_up(T * 64 * 4, 256);   // a differentiable frame: entries of every 8x8 quad's list (<= 64 quads a tile: bins of 64 px)
+    // round 6: a differentiable frame's rows of raw gradient sums (ms_render_bwd_rows: f32[N][16]) -- the LAST region, so that a
+    // caller finds it at ms_render_workspace_bytes() - ms_render_bwd_rows_bytes(N): the frame's rasteriser zeroes it on its way
+    // (bit 15 of the record's flag word says so) and ms_render_bwd_rows, handed exactly this address, skips its memset
+    L.off_rows = o; o += ms::align_up(n * 16 * sizeof(float), 256);
     L.total = o;
     return L;
 }
@@ -102,6 +106,14 @@ static int quad_list_nq(int tile_size) {
 // Claimed rows (round 6): the count kernel claims its rows with returning atomics, per XCD, and the prefix kernel
 // (k_tile_scan_wg) is not launched -- config 3's frame -2.5 us, config 4's -5 (profiles/r06_claimed_rows.md).
 // MOJOSPLAT_CLAIMED_ROWS=0: the prefix kernel, as rounds 1-5.
+static int ms_bwd_zero_rows_enabled() {
+    static const int v = [] {
+        const char *e = getenv("MOJOSPLAT_BWD_ZERO_ROWS");
+        return e && e[0] == '0' ? 0 : 1;
+    }();
+    return v;
+}
+
 static int ms_claimed_rows_enabled() {
     static const int v = [] {
         const char *e = getenv("MOJOSPLAT_CLAIMED_ROWS");
@@ -326,6 +338,10 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
     const int list_nq = (render_alphas && !last_ids && use_records && ((uintptr_t)(ws + L.off_records) & 15) == 0 && ms_bwd_lists_enabled())
                             ? quad_list_nq(tile_size) : 0;
     int32_t *quad_counts = list_nq ? (int32_t *)(ws + L.off_quad_counts) : nullptr;
+    // ... and its rasteriser zeroes the backward's rows of raw sums while it is at it (MOJOSPLAT_BWD_ZERO_ROWS=0: the
+    // backward's own memset, as rounds 4-5)
+    void *zero_rows = (render_alphas && !last_ids && use_records && ms_bwd_zero_rows_enabled()) ? (void *)(ws + L.off_rows) : nullptr;
+    const size_t zero_rows_bytes = zero_rows ? (size_t)(N > 0 ? N : 1) * 16 * sizeof(float) : 0;
     void *records = use_records ? (void *)(ws + L.off_records) : nullptr;
     // the rasteriser launches its blocks heaviest list first (the count pass leaves the order of the binning
     // grid's tiles in the isect workspace); MOJOSPLAT_RASTER_ORDER=0: image order interleaved over the XCDs
@@ -502,7 +518,8 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                            // (a light frame has no sorted FRONT a pixel could outlive: no clean-up launch)
                                            lazy && !bet_light ? &lazy_lists : nullptr,
                                            records, order, clip0, clip1, stage_events ? stage_events[3] : nullptr, stream,
-                                           list_nq ? (int32_t *)((char *)ids + ms::align_up((size_t)c * 4, 256)) : nullptr, quad_counts))
+                                           list_nq ? (int32_t *)((char *)ids + ms::align_up((size_t)c * 4, 256)) : nullptr, quad_counts,
+                                           zero_rows, zero_rows_bytes))
                 return rc;
             // (bit 9: the rasteriser was given lazily sorted fronts -- front counts and redo flags are this frame's; bit 10: a
             // lazily sorted frame -- no merge scratch in the exact layout.  ms_render_bwd reads both.)
@@ -510,6 +527,7 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                            (lazy && !bet_light ? 512 : 0) | (lazy ? 1024 : 0) | ((cull & 32) ? 2048 : 0) |
                            (lazy_lists.verdict ? 4096 : 0) |   // (bit 12: the clean-up launches were left to the finishing half)
                            claim_flag |                        // (bit 14: the histogram rows are per-XCD claims)
+                           (zero_rows && r1 > r0 ? 32768 : 0) |   // (bit 15: the rasteriser zeroed the backward's rows in the workspace)
                            (list_nq ? 8192 : 0);               // (bit 13: the quads' lists for the backward sit behind the ids)
 #ifdef MS_DIAG
             {
@@ -611,8 +629,10 @@ static int render_fwd_impl(const ms_scene *prepared, int restart, int64_t N, con
                                    lazy && host_info[2] + host_info[3] + host_info[4] > 0 ? &lazy_lists : nullptr,
                                    records, order, clip0, clip1,
                                    (!speculated && stage_events) ? stage_events[3] : nullptr, stream,
-                                   list_nq ? (int32_t *)((char *)ids + ms::align_up((size_t)(M > 0 ? M : 1) * 4, 256)) : nullptr, quad_counts))
+                                   list_nq ? (int32_t *)((char *)ids + ms::align_up((size_t)(M > 0 ? M : 1) * 4, 256)) : nullptr, quad_counts,
+                                   zero_rows, zero_rows_bytes))
         return rc;
+    host_info[7] = (host_info[7] & ~32768ll) | (zero_rows && r1 > r0 ? 32768 : 0);
     return MS_OK;
 }
 
@@ -689,7 +709,9 @@ static int render_bwd_rows_impl(int64_t N, int CDIM, int W, int H, int tile_size
     const int32_t *quad_lists = list_nq ? (const int32_t *)((const char *)isect_buf + lists_off) : nullptr;
     const int32_t *quad_counts = list_nq ? (const int32_t *)(ws + L.off_quad_counts) : nullptr;
     const void *records = (const void *)(ws + L.off_records);
-    MS_HIP(hipMemsetAsync(rows, 0, (size_t)N * 16 * sizeof(float), stream));
+    // (bit 15: the frame's rasteriser zeroed the workspace's own rows -- handed exactly those, the call has nothing to zero)
+    if (!((host_info[7] & 32768) && (const char *)rows == ws + L.off_rows))
+        MS_HIP(hipMemsetAsync(rows, 0, (size_t)N * 16 * sizeof(float), stream));
     // a lazily sorted frame: the lists are sorted as deep as the forward rasteriser walked them -- the tiles whose
     // front ran out were redone by the forward's clean-up pass and are this call's second launch (normally empty)
     ms::LazyLists ll{};

@@ -78,6 +78,9 @@ struct RasterArgs {
     // (rasterize_bwdq.hip) walks these instead of testing and compacting the tile's whole list again per quad.
     int32_t *quad_lists, *quad_counts;
     int quad_nq;           // quads per tile: 4 * nsub
+    float4 *zero_mem;      // round 6: memory the launch zeroes on its way (16-byte units: zero_total of them, zero_per_wave a wave), or null
+    unsigned zero_per_wave;
+    size_t zero_total;
     int nvb;               // persistent launch (round 6): virtual workgroup indices in all (what a one-block-per-wave launch's grid would be)
 };
 
@@ -753,6 +756,11 @@ __global__ __launch_bounds__(64, (CP <= 4 ? (NQ == 2 ? MS_RASTER_MINW2 : AUX ? M
     float4 r_a = make_float4(0.f, 0.f, 0.f, 0.f), r_b = r_a, r_c = r_a;
     int r_g = 0;
     RasterNext nx{0, 0, 0, 0};
+    if (A.zero_mem) {   // (uniform) this wave's slice of the memory the launch zeroes: stores nobody waits for
+        const size_t i0 = (size_t)blockIdx.x * A.zero_per_wave;
+        for (unsigned i = threadIdx.x & 63u; i < A.zero_per_wave; i += 64u)
+            if (i0 + i < A.zero_total) A.zero_mem[i0 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if constexpr (!PERSIST) {
         int tile, sub, part, slot;
         if (!raster_map_block<NQ>(A, (int)blockIdx.x, tile, sub, part, slot)) return;
@@ -1462,10 +1470,16 @@ void stash_cleanup(const RasterArgs &A, void (*launch)(const RasterArgs &, hipSt
 }
 
 template <int CP, typename ColorT>
-void launch_cp(const RasterArgs &A, hipStream_t stream, void *after_raster_event) {
+void launch_cp(const RasterArgs &A_in, hipStream_t stream, void *after_raster_event) {
+    RasterArgs A = A_in;
+    A.zero_mem = nullptr; A.zero_per_wave = 0; A.zero_total = 0;
     const bool aux = A.last_ids != nullptr;   // (the per-entry index bookkeeping; render_alphas alone costs the plain kernel one store)
     // parts single-wave workgroups per block, the block count rounded up to the 8 XCDs
     const dim3 grid(A.parts > 1 ? (unsigned)(((A.ngrid + 7) / 8) * 8 * A.parts) : (unsigned)A.ngrid);
+    if (A_in.zero_mem) {
+        A.zero_mem = A_in.zero_mem; A.zero_total = A_in.zero_total;
+        A.zero_per_wave = (unsigned)((A_in.zero_total + grid.x - 1) / grid.x);
+    }
 #define MS_LAUNCH_RASTER(AUXV, NQV, PK) \
     hipLaunchKernelGGL((k_rasterize_fwd<CP, ColorT, AUXV, NQV, PK>), grid, dim3(64), 0, stream, A)
 #define MS_LAUNCH_RASTER_NQ(AUXV, PK)                          \
@@ -1606,8 +1620,11 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
                       int tile_row_end, const int32_t *tile_ranges, const int32_t *flatten_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
                       const ms::LazyLists *lazy, const void *records, const int32_t *order, int clip_row16_begin,
-                      int clip_row16_end, void *after_raster_event, void *stream, int32_t *quad_lists, int32_t *quad_counts) {
+                      int clip_row16_end, void *after_raster_event, void *stream, int32_t *quad_lists, int32_t *quad_counts,
+                      void *zero_mem, size_t zero_bytes) {
     MS_REQUIRE(N >= 0 && M >= 0 && M <= 0x7fffffffll, MS_ERR_INVALID_ARG, "rasterize_fwd: bad N/M");
+    MS_REQUIRE(!zero_mem || (((uintptr_t)zero_mem & 15) == 0 && (zero_bytes & 15) == 0), MS_ERR_INVALID_ARG,
+               "rasterize_fwd: the memory to zero must be 16-byte aligned and a multiple of 16 bytes");
     MS_REQUIRE(W > 0 && H > 0 && tile_size > 0, MS_ERR_INVALID_ARG, "rasterize_fwd: bad image/tile size");
     MS_REQUIRE(CDIM >= 1 && CDIM <= 32, MS_ERR_INVALID_ARG, "rasterize_fwd: CDIM %d not in 1..32", CDIM);
     MS_REQUIRE(color_dtype == MS_COLOR_F32 || color_dtype == MS_COLOR_F16, MS_ERR_INVALID_ARG,
@@ -1639,6 +1656,7 @@ int ms::rasterize_fwd(int64_t N, int64_t M, int64_t density_hint, const float *m
     A.quad_lists = lists ? quad_lists : nullptr;
     A.quad_counts = lists ? quad_counts : nullptr;
     A.quad_nq = 4 * A.nsub;
+    A.zero_mem = (float4 *)zero_mem; A.zero_total = zero_mem ? zero_bytes / 16 : 0; A.zero_per_wave = 0;
     MS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= th,
                MS_ERR_INVALID_ARG, "rasterize_fwd: bad tile row band [%d,%d) of %d", tile_row_begin,
                tile_row_end, th);
@@ -1712,6 +1730,7 @@ int ms::rasterize_fwd_split(int64_t N, int64_t cap, int64_t density_hint, const 
     A.order = order;
     A.order_bins = order ? 1 : 0; A.row0 = r0; A.row1 = r1;
     A.quad_lists = nullptr; A.quad_counts = nullptr; A.quad_nq = 4;   // (a split frame is never differentiable)
+    A.zero_mem = nullptr; A.zero_per_wave = 0; A.zero_total = 0;
     A.records = (CDIM == 3 && ((uintptr_t)records & 15) == 0) ? (const float4 *)records : nullptr;
     A.lazy = *lazy;
     A.lazy.front_count = nullptr;   // block lists are walked to their end; the bin's flag says whether that was all

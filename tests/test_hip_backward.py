@@ -374,3 +374,46 @@ torch.save(out, sys.argv[1])
     assert torch.equal(a["img"], b["img"])
     for name, ga, gb in zip(("means3d", "scales", "quats", "opacities", "colors"), a["grads"], b["grads"]):
         assert_grad_close(f"lists-vs-none/{px}/{name}", ga, gb, rel=2e-5, elem_rel=5e-3, elem_p999=1e-3)
+
+
+def test_the_forward_zeroes_the_backwards_rows_and_says_so(device):
+    """Round 6: a lean differentiable frame's rasteriser zeroes the rows of raw gradient sums inside the frame's own workspace
+    (every wave a slice, on its way) and sets bit 15 of the frame's flag word; the backward then takes those rows and the
+    library skips its memset.  The flag is set on such a frame, and the gradients equal a step whose backward zeroed a
+    buffer of its own (MOJOSPLAT_BWD_ZERO_ROWS=0 in a child process) to the order of the float atomics."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f'''
+import sys, torch
+sys.path.insert(0, {root!r})
+from mojosplat_amd import _fused
+from mojosplat_amd.autograd import render_gaussians_trainable
+from mojosplat_amd.scenes import BACKGROUND_V1, randscene_v1
+dev = torch.device("cuda", 0)
+sc, cam = randscene_v1(60_000, 800, 448, ell=-3.3, seed=23, device=dev)
+leaves = [sc[k].clone().requires_grad_(True) for k in ("means3d", "scales", "quats", "opacities", "features")]
+bg = torch.tensor(BACKGROUND_V1, device=dev)
+v = torch.rand((448, 800, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+for rep in range(3):
+    for t in leaves: t.grad = None
+    # (garbage where the rows will be: a forward that did not zero them would show)
+    junk = torch.full((64_000_000,), float("nan"), device=dev); del junk
+    img = render_gaussians_trainable(*leaves, cam, background_color=bg)
+    img.backward(v)
+torch.save({{"grads": [t.grad.detach().cpu() for t in leaves], "flags": int(_fused._dev_state(dev, 0)["host_np"][7])}}, sys.argv[1])
+'''
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for z in ("1", "0"):
+            path = os.path.join(d, f"z{z}.pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MOJOSPLAT_BWD_ZERO_ROWS=z),
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+            outs[z] = torch.load(path)
+    assert (outs["1"]["flags"] & 32768) and not (outs["0"]["flags"] & 32768)
+    for name, a, b in zip(("means3d", "scales", "quats", "opacities", "colors"), outs["1"]["grads"], outs["0"]["grads"]):
+        assert torch.isfinite(a).all(), name
+        assert_grad_close(name, a, b, rel=2e-3, elem_rel=5e-3, elem_p999=1e-3)
