@@ -196,6 +196,10 @@ class _RenderFusedHip(torch.autograd.Function):
                                                 _hip.ptr(v_img), None, _hip.ptr(rows),
                                                 None if mirror is None else ctypes.c_void_p(mirror.data_ptr()), _hip.stream(dev)),
                            "ms_render_bwd_rows")
+                if rows_in_ws:
+                    # (the rows now hold this backward's sums: a second backward through the same graph -- retain_graph=True --
+                    # must not add to them: the frame's record no longer vouches for zeroed rows, the next call zeroes its own)
+                    host[7] = int(host[7]) & ~32768
                 if bev:
                     bev[1].record()
                 _hip.check(L.ms_render_bwd_finish(N, _hip.ptr(m3), _hip.ptr(sc), 1, _hip.ptr(qu), _hip.ptr(op), 3, _hip.ptr(vm), cam.fx,

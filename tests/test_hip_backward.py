@@ -417,3 +417,20 @@ torch.save({{"grads": [t.grad.detach().cpu() for t in leaves], "flags": int(_fus
     for name, a, b in zip(("means3d", "scales", "quats", "opacities", "colors"), outs["1"]["grads"], outs["0"]["grads"]):
         assert torch.isfinite(a).all(), name
         assert_grad_close(name, a, b, rel=2e-3, elem_rel=5e-3, elem_p999=1e-3)
+
+
+def test_a_second_backward_through_the_same_frame_gives_the_same_gradients(device):
+    """retain_graph=True: the first backward consumed the rows the forward zeroed in the frame's workspace; the second must not
+    add to them (round 6: the frame's record stops vouching for zeroed rows after the first use)."""
+    sc, cam = randscene_v1(20_000, 480, 272, ell=-3.0, seed=31, device=device)
+    leaves = [sc[k].clone().requires_grad_(True) for k in ("means3d", "scales", "quats", "opacities", "features")]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+    v = torch.rand((272, 480, 3), device=device, generator=torch.Generator(device=device).manual_seed(9))
+    img = render_gaussians_trainable(*leaves, cam, background_color=bg)
+    img.backward(v, retain_graph=True)
+    first = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    img.backward(v)
+    for name, a, b in zip(("means3d", "scales", "quats", "opacities", "colors"), first, [t.grad for t in leaves]):
+        assert_grad_close(name, b, a, rel=2e-3, elem_rel=5e-3, elem_p999=1e-3)
